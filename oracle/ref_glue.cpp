@@ -1,0 +1,241 @@
+// oracle/ref_glue.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin extern "C" glue that instantiates the *reference's own* templates from the
+// headers where they lie under /root/reference (nothing is copied into this repo)
+// so that tests can pin oracle/vlg_oracle.c against the real implementation.
+//
+// What is reference code here (compiled from /root/reference/include/sdsl + lib/*.cpp):
+//   * wt_huff<> = wt_pc<huff_shape,...>   ctor / rank / inverse_select / operator[]
+//                                         (include/sdsl/wt_pc.hpp:197-248,318-402)
+//   * rank_support_v<1,1>, rank_support_v5<1,1>, rrr_vector<63>+rank_support_rrr
+//                                         (rank_support_v.hpp:67-124, rank_support_v5.hpp:65-134,
+//                                          rrr_vector.hpp:145-237,444-480)
+//   * byte_alphabet                       (lib/csa_alphabet_strategy.cpp:25-55)
+//   * LF trait traverse_csa_wt            (suffix_array_helper.hpp:336-349)
+//
+// What is NOT buildable in this image (see DESIGN.md "Oracle"):
+//   csa_wt.hpp / wavelet_trees.hpp / suffix_arrays.hpp / vlg_index.hpp / index_sasearch.hpp all
+//   pull construct_sa.hpp, which #includes "divsufsort.h" from an empty git submodule, and
+//   suffix_array_algorithm.hpp names csa_wt<> in its signatures, so backward_search / locate /
+//   forward_search cannot be instantiated either.  No stand-in is written for any of them.
+//   The `ref_csa` adapter below only gives the reference LF trait (traverse_csa_wt) the members
+//   it reads (wavelet_tree, C, char2comp); its operator[] is a 5-line restatement of
+//   csa_wt.hpp:335-348 + csa_sampling_strategy.hpp:85-111 and is labelled as such.
+#include <sdsl/int_vector.hpp>
+#include <sdsl/int_vector_buffer.hpp>
+#include <sdsl/rank_support.hpp>
+#include <sdsl/rank_support_v.hpp>
+#include <sdsl/rank_support_v5.hpp>
+#include <sdsl/rrr_vector.hpp>
+#include <sdsl/wt_huff.hpp>
+#include <sdsl/csa_alphabet_strategy.hpp>
+#include <sdsl/suffix_array_helper.hpp>
+#include <sdsl/io.hpp>
+#include <vector>
+#include <string>
+#include <atomic>
+#include <cstring>
+
+using namespace sdsl;
+
+namespace {
+
+std::atomic<uint64_t> g_seq(0);
+
+struct ref_base {
+    virtual ~ref_base() {}
+    virtual uint64_t size() const = 0;
+    virtual uint64_t wt_rank(uint64_t i, uint8_t c) const = 0;
+    virtual uint64_t inverse_select(uint64_t i, uint8_t* c) const = 0;
+    virtual uint64_t bv_size() const = 0;
+    virtual uint64_t bv_rank1(uint64_t idx) const = 0;
+    virtual int bv_get(uint64_t idx) const = 0;
+    virtual uint64_t n_nodes() const = 0;
+    virtual void node(uint64_t v, uint64_t* bv_pos, uint64_t* sz, int* leaf, int* sym, int* c0, int* c1) const = 0;
+    virtual void alphabet(uint8_t* c2c, uint64_t* C, uint32_t* sigma) const = 0;
+    virtual uint64_t sa(uint64_t i) const = 0;
+    virtual uint64_t lf_at(uint64_t i) const = 0;
+};
+
+// Minimal csa_tag model for the reference's generic algorithms.
+template<class t_wt>
+struct ref_csa : ref_base {
+    typedef csa_tag                          index_category;
+    typedef byte_alphabet_tag                alphabet_category;
+    typedef uint64_t                         size_type;
+    typedef uint64_t                         value_type;
+    typedef uint8_t                          char_type;
+    typedef ptrdiff_t                        difference_type;
+    typedef byte_alphabet                    alphabet_type;
+    typedef t_wt                             wavelet_tree_type;
+    enum { sa_sample_dens = 32 };
+
+    t_wt           wavelet_tree;
+    byte_alphabet  m_alphabet;
+    int_vector<>   sa_sample;   // SA[0], SA[32], ... width bits::hi(n)+1  (csa_sampling_strategy.hpp:85-98)
+    const typename byte_alphabet::char2comp_type& char2comp;
+    const typename byte_alphabet::comp2char_type& comp2char;
+    const typename byte_alphabet::C_type&         C;
+    const typename byte_alphabet::sigma_type&     sigma;
+    const bwt_of_csa_wt<ref_csa>                  bwt;
+    const traverse_csa_wt<ref_csa, false>         lf;
+
+    ref_csa(const uint8_t* bwt_in, const uint64_t* sa_in, uint64_t n)
+        : char2comp(m_alphabet.char2comp), comp2char(m_alphabet.comp2char), C(m_alphabet.C),
+          sigma(m_alphabet.sigma), bwt(*this), lf(*this)
+    {
+        std::string f = "@vref_bwt_" + std::to_string(g_seq++);
+        {
+            int_vector<8> b(n);
+            for (uint64_t i = 0; i < n; ++i) b[i] = bwt_in[i];
+            store_to_file(b, f);
+        }
+        {
+            int_vector_buffer<8> buf(f);
+            byte_alphabet tmp(buf, n);              // reference ctor
+            m_alphabet.swap(tmp);
+        }
+        {
+            int_vector_buffer<8> buf(f);
+            t_wt tmp(buf, n);                       // reference wt_pc ctor
+            wavelet_tree.swap(tmp);
+        }
+        sdsl::remove(f);
+        if (sa_in) {
+            sa_sample.width(bits::hi(n) + 1);
+            sa_sample.resize((n + sa_sample_dens - 1) / sa_sample_dens);
+            for (uint64_t i = 0, j = 0; i < n; i += sa_sample_dens) sa_sample[j++] = sa_in[i];
+        }
+    }
+
+    uint64_t size() const { return wavelet_tree.size(); }
+    size_type rank_bwt(size_type i, const char_type c) const { return wavelet_tree.rank(i, c); }
+    size_type select(size_type, const char_type) const { return 0; }
+
+    // csa_wt.hpp:335-348 with _sa_order_sampling::is_sampled (csa_sampling_strategy.hpp:102-111)
+    value_type operator[](size_type i) const
+    {
+        size_type off = 0;
+        while (i % sa_sample_dens) { i = lf[i]; ++off; }
+        value_type result = sa_sample[i / sa_sample_dens];
+        return (result + off < size()) ? result + off : result + off - size();
+    }
+
+    uint64_t wt_rank(uint64_t i, uint8_t c) const { return wavelet_tree.rank(i, c); }
+    uint64_t inverse_select(uint64_t i, uint8_t* c) const
+    {
+        auto rc = wavelet_tree.inverse_select(i);
+        *c = rc.second;
+        return rc.first;
+    }
+    uint64_t bv_size() const { return wavelet_tree.bv.size(); }
+    uint64_t bv_rank1(uint64_t idx) const
+    {
+        typename t_wt::rank_1_type rs(&wavelet_tree.bv);
+        return rs.rank(idx);
+    }
+    int bv_get(uint64_t idx) const { return wavelet_tree.bv[idx]; }
+    uint64_t n_nodes() const { return wavelet_tree.sigma ? 2 * (uint64_t)wavelet_tree.sigma - 1 : 0; }
+    void node(uint64_t v, uint64_t* bv_pos, uint64_t* sz, int* leaf, int* sym, int* c0, int* c1) const
+    {
+        typename t_wt::node_type nv = (typename t_wt::node_type)v;
+        *leaf = wavelet_tree.is_leaf(nv);
+        *sz = wavelet_tree.size(nv);
+        if (*leaf) {
+            *sym = wavelet_tree.sym(nv);
+            *bv_pos = 0; *c0 = *c1 = -1;
+        } else {
+            *sym = -1;
+            auto ch = wavelet_tree.expand(nv);
+            *c0 = ch[0]; *c1 = ch[1];
+            *bv_pos = wavelet_tree.bit_vec(nv).begin() - wavelet_tree.bv.begin();
+        }
+    }
+    void alphabet(uint8_t* c2c, uint64_t* Cout, uint32_t* sg) const
+    {
+        for (int i = 0; i < 256; ++i) c2c[i] = char2comp[i];
+        for (uint32_t i = 0; i <= sigma; ++i) Cout[i] = C[i];
+        *sg = sigma;
+    }
+    uint64_t sa(uint64_t i) const { return (*this)[i]; }
+    uint64_t lf_at(uint64_t i) const { return lf[i]; }
+};
+
+typedef wt_huff<bit_vector, rank_support_v<>>  wt_v;
+typedef wt_huff<bit_vector, rank_support_v5<>> wt_v5;
+typedef wt_huff<rrr_vector<63>>                wt_rrr;
+
+} // namespace
+
+extern "C" {
+
+// variant: 0 = wt_huff<bit_vector,rank_support_v>, 1 = rank_support_v5, 2 = rrr_vector<63>
+void* vref_create(const uint8_t* bwt, const uint64_t* sa, uint64_t n, int variant)
+{
+    try {
+        switch (variant) {
+            case 0: return new ref_csa<wt_v>(bwt, sa, n);
+            case 1: return new ref_csa<wt_v5>(bwt, sa, n);
+            case 2: return new ref_csa<wt_rrr>(bwt, sa, n);
+        }
+    } catch (...) {}
+    return nullptr;
+}
+void vref_destroy(void* h) { delete (ref_base*)h; }
+uint64_t vref_size(void* h) { return ((ref_base*)h)->size(); }
+uint64_t vref_wt_rank(void* h, uint64_t i, uint8_t c) { return ((ref_base*)h)->wt_rank(i, c); }
+uint64_t vref_inverse_select(void* h, uint64_t i, uint8_t* c) { return ((ref_base*)h)->inverse_select(i, c); }
+uint64_t vref_bv_size(void* h) { return ((ref_base*)h)->bv_size(); }
+uint64_t vref_bv_rank1(void* h, uint64_t idx) { return ((ref_base*)h)->bv_rank1(idx); }
+void vref_bv_bits(void* h, uint64_t* words)
+{
+    ref_base* b = (ref_base*)h;
+    uint64_t n = b->bv_size();
+    for (uint64_t i = 0; i < (n + 63) / 64; ++i) words[i] = 0;
+    for (uint64_t i = 0; i < n; ++i) if (b->bv_get(i)) words[i >> 6] |= 1ULL << (i & 63);
+}
+uint64_t vref_n_nodes(void* h) { return ((ref_base*)h)->n_nodes(); }
+void vref_node(void* h, uint64_t v, uint64_t* bv_pos, uint64_t* sz, int* leaf, int* sym, int* c0, int* c1)
+{
+    ((ref_base*)h)->node(v, bv_pos, sz, leaf, sym, c0, c1);
+}
+void vref_alphabet(void* h, uint8_t* c2c, uint64_t* C, uint32_t* sigma) { ((ref_base*)h)->alphabet(c2c, C, sigma); }
+uint64_t vref_sa(void* h, uint64_t i) { return ((ref_base*)h)->sa(i); }
+uint64_t vref_lf(void* h, uint64_t i) { return ((ref_base*)h)->lf_at(i); }
+
+// Stand-alone bit-vector rank: variant 0 = rank_support_v<1,1>, 1 = rank_support_v5<1,1>, 2 = rrr_vector<63>.
+void vref_bitrank(const uint64_t* words, uint64_t nbits, int variant,
+                  const uint64_t* idx, uint64_t k, uint64_t* out)
+{
+    bit_vector bv(nbits, 0);
+    for (uint64_t i = 0; i < nbits; ++i) bv[i] = (words[i >> 6] >> (i & 63)) & 1;
+    if (variant == 0) {
+        rank_support_v<1, 1> rs(&bv);
+        for (uint64_t j = 0; j < k; ++j) out[j] = rs.rank(idx[j]);
+    } else if (variant == 1) {
+        rank_support_v5<1, 1> rs(&bv);
+        for (uint64_t j = 0; j < k; ++j) out[j] = rs.rank(idx[j]);
+    } else {
+        rrr_vector<63> rv(bv);
+        rrr_vector<63>::rank_1_type rs(&rv);
+        for (uint64_t j = 0; j < k; ++j) out[j] = rs.rank(idx[j]);
+    }
+}
+
+// Raw rank_support_v block array (rank_support_v.hpp:75-105) for layout parity of the oracle.
+uint64_t vref_rank_v_blocks(const uint64_t* words, uint64_t nbits, uint64_t* out, uint64_t cap)
+{
+    bit_vector bv(nbits, 0);
+    for (uint64_t i = 0; i < nbits; ++i) bv[i] = (words[i >> 6] >> (i & 63)) & 1;
+    rank_support_v<1, 1> rs(&bv);
+    std::stringstream ss;
+    rs.serialize(ss);
+    std::string s = ss.str();          // int_vector<64>: u64 size-in-bits, then words
+    uint64_t bits = 0;
+    memcpy(&bits, s.data(), 8);
+    uint64_t nw = bits / 64;
+    for (uint64_t i = 0; i < nw && i < cap; ++i) memcpy(&out[i], s.data() + 8 + 8 * i, 8);
+    return nw;
+}
+
+} // extern "C"

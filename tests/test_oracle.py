@@ -1,0 +1,197 @@
+"""The CPU oracle against (1) the reference's known answers, (2) the reference's own code
+(oracle/_ref, compiled from /root/reference), (3) brute force.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from util import (bwt_from_sa, dna_text, naive_occurrences, naive_sa, reference_semantics_join, skewed_text)
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "vlg_known_answers.json")
+CASES = json.load(open(GOLD))["cases"]
+
+# the reference's own tiny fixtures (test/test_cases/*.txt), restated as data
+FIXTURE_TEXTS = {
+    "one_byte": b"a",
+    "100a": b"a" * 100,
+    "abc_abc_abc": b"abc abc abc",
+    "all_symbols": bytes(range(1, 256)),
+    "abracadabra": b"abracadabrasimsalabim",
+}
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["text"][:6] + ":" + c["query"] for c in CASES])
+def test_known_answers(oracle, case):
+    idx = oracle.Index.from_text(case["text"].encode())
+    if "error" in case:
+        with pytest.raises(oracle.ParseError) as e:
+            idx.search(case["query"])
+        assert case["error"] in str(e.value)
+    else:
+        assert idx.search(case["query"]).tolist() == case["tuples"]
+
+
+def test_suffix_array_matches_naive(oracle):
+    for name, t in FIXTURE_TEXTS.items():
+        tz = np.frombuffer(t + b"\0", dtype=np.uint8)
+        assert (oracle.suffix_array(tz) == naive_sa(tz)).all(), name
+    tz = np.concatenate([dna_text(3000, 7), [0]]).astype(np.uint8)
+    assert (oracle.suffix_array(tz) == naive_sa(tz)).all()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["rank_v", "rank_v5", "rrr63"])
+def test_bitrank_vs_reference(refmod, variant):
+    """test/rank_support_test.cpp:70-87 restated: rank(j) for every j, on crafted vectors."""
+    O = refmod
+    rng = np.random.default_rng(5)
+    for nbits in [0, 1, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 4096, 100000]:
+        for dens in (0.0, 0.03, 0.5, 0.97, 1.0):
+            nw = (nbits + 63) // 64
+            bits = (rng.random(nw * 64) < dens)
+            bits[nbits:] = False
+            words = np.packbits(bits.reshape(-1, 64)[:, ::-1], axis=1).view(">u8").ravel().astype(np.uint64) if nw else np.zeros(0, np.uint64)
+            idx = np.arange(nbits + 1, dtype=np.uint64) if nbits <= 5000 else \
+                np.unique(np.concatenate([rng.integers(0, nbits + 1, 3000), [0, nbits]])).astype(np.uint64)
+            want = O.ref_bitrank(words, nbits, variant, idx)
+            truth = np.concatenate([[0], np.cumsum(bits[:nbits])])[idx.astype(np.int64)]
+            assert (want == truth).all()
+            if variant == 2:
+                continue
+            wpad = np.concatenate([words, np.zeros(1, np.uint64)])
+            L = O.lib()
+            build, rank = (L.vlgo_rank_v_build, L.vlgo_rank_v) if variant == 0 else (L.vlgo_rank_v5_build, L.vlgo_rank_v5)
+            shift = 3 if variant == 0 else 5
+            blocks = np.zeros(2 * ((nw >> shift) + 1), dtype=np.uint64)
+            build(wpad.ctypes.data, nbits, blocks.ctypes.data)
+            got = np.array([rank(wpad.ctypes.data, blocks.ctypes.data, int(i)) for i in idx], dtype=np.uint64)
+            assert (got == want).all(), (nbits, dens)
+            if variant == 0:
+                assert (blocks == O.ref_rank_v_blocks(words, nbits)).all(), "rank_support_v layout"
+
+
+def _texts():
+    out = dict(FIXTURE_TEXTS)
+    out["dna2k"] = dna_text(2000, 1).tobytes()
+    out["dna_skew"] = dna_text(5000, 2, (0.7, 0.1, 0.1, 0.1)).tobytes()
+    out["zipf40"] = skewed_text(6000, 3).tobytes()
+    out["two_syms"] = (b"ab" * 50) + b"b" * 7
+    return out
+
+
+@pytest.mark.parametrize("name", list(_texts().keys()))
+def test_wavelet_tree_and_alphabet_vs_reference(refmod, name):
+    """wt_byte_test.cpp:116-177 (rank, inverse_select) + structure parity with the reference ctor."""
+    O = refmod
+    text = _texts()[name]
+    tz = np.frombuffer(text + b"\0", dtype=np.uint8)
+    sa = O.suffix_array(tz)
+    bwt = bwt_from_sa(tz, sa)
+    mine = O.Index.from_bwt(bwt, sa)
+    for variant in (0, 1, 2):
+        R = O.RefIndex(bwt, sa, variant)
+        c2c, Cc, sg = R.alphabet()
+        p = mine.parts()
+        assert sg == p["sigma"] and (c2c == p["char2comp"]).all() and (Cc == p["C"]).all()
+        assert R.bv_size() == p["bv_bits"]
+        assert (R.bv_words() == p["bv_words"]).all(), "WT bit-vector differs"
+        rn = R.nodes()
+        assert len(rn) == len(p["nodes"])
+        for v, (a, b) in enumerate(zip(rn, p["nodes"])):
+            leaf = int(b["child"][0]) == 0xFFFF
+            assert bool(a["leaf"]) == leaf
+            if leaf:
+                assert a["sym"] == int(b["bv_pos_rank"])
+            else:
+                assert a["bv_pos"] == int(b["bv_pos"]) and a["c0"] == int(b["child"][0]) and a["c1"] == int(b["child"][1])
+        n = len(tz)
+        rng = np.random.default_rng(11)
+        pos = np.arange(n + 1) if n <= 300 else np.unique(np.concatenate([rng.integers(0, n + 1, 400), [0, n]]))
+        syms = sorted(set(tz.tolist())) + [250 if 250 not in tz else 0]
+        for i in pos:
+            for c in syms[:12]:
+                assert mine.wt_rank(i, c) == R.wt_rank(i, c)
+            if i < n:
+                assert mine.inverse_select(i) == R.inverse_select(i)
+                assert mine.lf(i) == R.lf(i)
+                assert mine.sa(i) == R.sa(i) == int(sa[i])          # csa_byte_test.cpp:136-147
+        for idx in pos[: 200]:
+            j = int(idx) * p["bv_bits"] // (n + 1)
+            assert mine.bv_rank1(j) == R.bv_rank1(j)
+
+
+@pytest.mark.parametrize("name", ["abracadabra", "100a", "dna2k", "zipf40", "all_symbols"])
+def test_backward_search_and_locate_vs_bruteforce(oracle, name):
+    """csa_byte_test.cpp:59-84 (whole text, prefix, empty pattern) + locate == naive scan."""
+    text = _texts()[name]
+    idx = oracle.Index.from_text(text)
+    n = len(text) + 1
+    cnt, l, r = idx.backward_search(text)                      # whole text occurs once
+    assert cnt == 1 and idx.sa(l) == 0
+    cnt, l, r = idx.backward_search(b"")                       # empty pattern: whole interval
+    assert (cnt, l, r) == (n, 0, n - 1)
+    rng = np.random.default_rng(3)
+    pats = [text[:4]] + [text[s:s + m] for s, m in zip(rng.integers(0, max(1, len(text) - 8), 60), rng.integers(1, 8, 60))]
+    pats += [b"\xfe\xfe", b"zzzzq", text[-3:] + b"x"]
+    for p in pats:
+        want = naive_occurrences(text, p)
+        cnt, l, r = idx.backward_search(p)
+        assert cnt == len(want), p
+        assert sorted(idx.locate(p).tolist()) == want
+        if cnt:
+            assert idx.locate(p).tolist() == [idx.sa(i) for i in range(l, r + 1)]   # SA order
+
+
+def test_parser_dialects(oracle):
+    q = oracle.parse("ab.{2,5}?cde.{0,7}?f", 0)
+    subs, lo, hi, end = oracle.query_fields(q)
+    assert subs == [b"ab", b"cde", b"f"] and lo == [4, 3] and hi == [7, 10] and end == 1
+    q = oracle.parse("ab.{2,5}cde.{0,7}f", 1)                  # benchmark: gaps[0], |s0| everywhere
+    subs, lo, hi, end = oracle.query_fields(q)
+    assert subs == [b"ab", b"cde", b"f"] and lo == [4, 4] and hi == [7, 7] and end == 2
+    for bad, code in [("a.{1,2}b", 1), ("a.{3,2}?b", 2), ("a.{x,2}?b", 3), ("a.{1,2", 3), (".{1,2}?b", 4)]:
+        with pytest.raises(oracle.ParseError) as e:
+            oracle.parse(bad, 0)
+        assert e.value.code == code
+    subs, _, _, _ = oracle.query_fields(oracle.parse("a.{1,2}?b", 1))   # '?' belongs to s1 in the benchmark dialect
+    assert subs == [b"a", b"?b"]
+
+
+def test_join_matches_appendix_c(oracle):
+    rng = np.random.default_rng(17)
+    for trial in range(300):
+        k = int(rng.integers(1, 5))
+        lists = [np.unique(rng.integers(0, 400, int(rng.integers(0, 60)))).astype(np.uint64) for _ in range(k)]
+        lo = [int(rng.integers(1, 12)) for _ in range(k - 1)]
+        hi = [l + int(rng.integers(0, 40)) for l in lo]
+        end_len = int(rng.integers(1, 9))
+        m, tup = oracle.join(lists, lo, hi, end_len)
+        assert tup.tolist() == reference_semantics_join([l.tolist() for l in lists], lo, hi, end_len)
+
+
+def test_search_equals_naive_lists_plus_join(oracle):
+    text = dna_text(20000, 9).tobytes()
+    idx = oracle.Index.from_text(text)
+    rng = np.random.default_rng(23)
+    for trial in range(60):
+        k = int(rng.integers(1, 5))
+        subs = []
+        for _ in range(k):
+            s = int(rng.integers(0, len(text) - 6)); m = int(rng.integers(1, 5))
+            subs.append(text[s:s + m])
+        gaps = [(int(a), int(a) + int(b)) for a, b in zip(rng.integers(0, 30, k - 1), rng.integers(0, 60, k - 1))]
+        q = subs[0].decode() + "".join(".{%d,%d}?%s" % (a, b, s.decode()) for (a, b), s in zip(gaps, subs[1:]))
+        lists = [naive_occurrences(text, s) for s in subs]
+        lo = [a + len(subs[i]) for i, (a, b) in enumerate(gaps)]
+        hi = [b + len(subs[i]) for i, (a, b) in enumerate(gaps)]
+        want = reference_semantics_join(lists, lo, hi, len(subs[-1]))
+        assert idx.search(q).tolist() == want, q
+
+
+def test_from_parts_roundtrip(oracle):
+    text = skewed_text(4000, 5).tobytes()
+    a = oracle.Index.from_text(text)
+    b = oracle.Index.from_parts(a.parts())
+    for q in ["!.{0,9}?\"", "#\"", "!!.{1,30}?!.{0,5}?\""]:
+        assert a.search(q).tolist() == b.search(q).tolist()
+    assert (a.rank_blocks() == b.rank_blocks()).all()
