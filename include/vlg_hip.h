@@ -1,0 +1,237 @@
+/* include/vlg_hip.h -- C-ABI of the MI355X-native variable-length-gap (VLG) matcher.
+ *
+ * This is the drop-in boundary for the FM-index VLG hot path of olydis/vlg_matching
+ * (an sdsl-lite fork).  The reference has no FFI: the path sits behind C++ template concepts
+ * (SURVEY.md 8b).  Each entry point below names the reference interface it replaces
+ * (file:line relative to the reference root); INTEGRATION.md shows the C++ adapter a reference
+ * maintainer would add to route `index_*::search` / `sdsl::locate` through it.
+ *
+ * Conventions
+ *   - plain C, no exceptions: every call returns a vlg_status; vlg_last_error() gives the text.
+ *   - "h_" arguments are host pointers, "d_" arguments are device (HBM) pointers of the current
+ *     HIP device; the caller owns every buffer it passes in.
+ *   - positions/counts are uint64_t at the boundary, like sdsl's size_type; all arithmetic is
+ *     unsigned integer / bit manipulation (no floating point anywhere on the path).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - a vlg_index is immutable after creation; batched calls on different streams may share it.
+ *     A vlg_workspace / vlg_result belongs to one caller thread at a time.
+ *   - there is no CPU fallback: without a usable HIP device every compute call fails with
+ *     VLG_E_NO_DEVICE.
+ */
+#ifndef VLG_HIP_H
+#define VLG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    VLG_OK = 0,
+    VLG_E_INVALID = 1,       /* bad argument                                                   */
+    VLG_E_NO_DEVICE = 2,     /* no HIP device / HIP runtime error                              */
+    VLG_E_OOM = 3,           /* device or host allocation failed                               */
+    VLG_E_PARSE = 4,         /* gap syntax: the reference throws std::runtime_error
+                                (include/sdsl/vlg_index.hpp:92-99)                             */
+    VLG_E_ZERO_BYTE = 5,     /* text contains a 0 byte: std::logic_error in the reference
+                                (include/sdsl/construct.hpp:36-45)                             */
+    VLG_E_UNSUPPORTED = 6,   /* e.g. text longer than this build handles                       */
+    VLG_E_WORKSPACE = 7,     /* one query needs more workspace than the configured cap          */
+    VLG_E_INTERNAL = 8
+} vlg_status;
+
+typedef struct vlg_index vlg_index;          /* FM-index resident in HBM                       */
+typedef struct vlg_bitvector vlg_bitvector;  /* stand-alone rank-enabled bit-vector in HBM     */
+typedef struct vlg_queries vlg_queries;      /* a parsed query batch resident in HBM           */
+typedef struct vlg_result vlg_result;        /* results of one vlg_search_batch, in HBM        */
+typedef struct vlg_workspace vlg_workspace;  /* scratch HBM + stream + per-kernel statistics   */
+
+const char* vlg_last_error(void);            /* thread-local text of the last failure          */
+const char* vlg_version(void);
+vlg_status vlg_device_count(int* n);
+vlg_status vlg_set_device(int ordinal);
+
+/* ------------------------------------------------------------------------------------------
+ * Index parts in the REFERENCE's own layout (host memory) -- what a loaded
+ * sdsl::csa_wt<wt_huff<>,32,64> exposes (include/sdsl/csa_wt.hpp:120-152):
+ *   wavelet_tree.bv (wt_pc.hpp:185), the _byte_tree nodes (wt_helper.hpp:73-131, BFS order),
+ *   char2comp / C (csa_wt.hpp:139-142), sa_sample (csa_wt.hpp:150; csa_sampling_strategy.hpp:85-111).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t bv_pos;        /* inner node: first bit of the node in wavelet_tree.bv             */
+    uint64_t bv_pos_rank;   /* inner node: rank1(bv_pos); leaf: the symbol                      */
+    uint16_t parent;        /* 0xFFFF for the root                                             */
+    uint16_t child[2];      /* 0xFFFF,0xFFFF for a leaf                                        */
+} vlg_wt_node;
+
+typedef struct {
+    uint64_t n;                   /* csa.size() = |text| + 1 (sentinel)                         */
+    uint32_t sigma;               /* csa.sigma                                                 */
+    uint32_t sa_sample_dens;      /* t_dens, 32 in the reference default (csa_wt.hpp:61)        */
+    const uint8_t* char2comp;     /* [256]                                                     */
+    const uint64_t* C;            /* [sigma+1]                                                 */
+    const uint64_t* bv_words;     /* ceil(bv_bits/64) words, bit i = word[i>>6] >> (i&63)      */
+    uint64_t bv_bits;
+    const vlg_wt_node* nodes;     /* [n_nodes], node 0 = root                                  */
+    uint32_t n_nodes;             /* 2*sigma-1                                                 */
+    const uint64_t* sa_samples;   /* [ceil(n/dens)] unpacked: SA[0], SA[dens], ...              */
+    uint64_t n_samples;
+} vlg_index_parts;
+
+typedef struct {
+    uint64_t n;                   /* text length + 1                                           */
+    uint32_t sigma;
+    uint32_t sa_sample_dens;
+    uint32_t n_nodes;
+    uint32_t max_code_len;        /* deepest leaf of the Huffman-shaped tree                    */
+    uint64_t wt_bits;             /* sum of node sizes = n * (mean code length)                 */
+    uint64_t n_blocks;            /* 32-byte super-blocks in HBM                               */
+    uint64_t n_samples;
+    uint64_t hbm_bytes;           /* total device bytes of the index                           */
+    uint32_t pos_bytes;           /* 4 (n <= 2^32) or 8: width of positions inside kernels      */
+    uint32_t reserved;
+} vlg_index_info;
+
+/* Build on the device from raw text (no 0 byte; the sentinel is appended like
+ * sdsl::construct, include/sdsl/construct.hpp:47-52,112-159): suffix sort, BWT, Huffman-shaped
+ * wavelet tree (wt_pc.hpp:197-248), SA sampling -- all in HBM.  Replaces
+ * `index_*(collection&)` (benchmark/gapped-matching/include/index_sasearch.hpp:23-31) and
+ * `construct(idx, file, num_bytes)` (include/sdsl/vlg_index.hpp:375-392). */
+vlg_status vlg_index_build(const uint8_t* h_text, uint64_t n_text, uint32_t sa_sample_dens, vlg_index** out);
+/* Same, text already in HBM. */
+vlg_status vlg_index_build_device(const uint8_t* d_text, uint64_t n_text, uint32_t sa_sample_dens,
+                                  void* stream, vlg_index** out);
+/* Adopt an index built by the reference (host arrays in its layout) -- replaces
+ * `idx.load(istream)` (index_sasearch.hpp:41-45; csa_wt.hpp:395-407). */
+vlg_status vlg_index_from_parts(const vlg_index_parts* h_parts, vlg_index** out);
+/* Export to the reference layout (two-phase: pass NULL buffers in `out` to get sizes only). -- replaces
+ * `idx.serialize(ostream)` (index_sasearch.hpp:33-39).  Buffers in `out` are caller-allocated host arrays. */
+typedef struct {
+    uint8_t* char2comp;           /* [256]                                                     */
+    uint64_t* C;                  /* [257]                                                     */
+    uint64_t* bv_words;           /* [ceil(bv_bits/64)]                                        */
+    vlg_wt_node* nodes;           /* [n_nodes]                                                 */
+    uint64_t* sa_samples;         /* [n_samples]                                               */
+} vlg_index_parts_out;
+vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_parts* sizes, vlg_index_parts_out* out);
+vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* info);
+void vlg_index_destroy(vlg_index* idx);
+
+/* One contiguous device image of the read-only index, for replication across the GPUs of a node
+ * (SURVEY.md 8e): the owner exports it into caller-provided HBM, the caller moves it with RCCL
+ * (ncclBroadcast, or torch.distributed.broadcast on a uint8 tensor), every other rank attaches.
+ * The attached index borrows the blob: keep it alive until vlg_index_destroy. */
+vlg_status vlg_index_blob_bytes(const vlg_index* idx, uint64_t* bytes);
+vlg_status vlg_index_blob_export(const vlg_index* idx, void* d_blob, uint64_t bytes, void* stream);
+vlg_status vlg_index_attach_blob(const void* d_blob, uint64_t bytes, vlg_index** out);
+
+/* ------------------------------------------------------------------------------------------
+ * K1: batched bit-rank.  rank_support_v<1,1>::rank / rank_support_v5<1,1>::rank
+ * (include/sdsl/rank_support_v.hpp:114-124, rank_support_v5.hpp:116-134) on a plain bit_vector,
+ * re-laid out as 256-bit super-blocks {32-bit count, 224 data bits}.
+ * out[j] = number of 1 bits in bv[0, idx[j]),  0 <= idx[j] <= nbits.
+ * ---------------------------------------------------------------------------------------- */
+vlg_status vlg_bitvector_create(const uint64_t* h_words, uint64_t nbits, vlg_bitvector** out);
+vlg_status vlg_bitvector_rank_batch(const vlg_bitvector* bv, const uint64_t* d_idx, uint64_t* d_out,
+                                    uint64_t count, void* stream);
+uint64_t vlg_bitvector_hbm_bytes(const vlg_bitvector* bv);
+void vlg_bitvector_destroy(vlg_bitvector* bv);
+
+/* ------------------------------------------------------------------------------------------
+ * K2 / K3 primitives on the index (device-resident arguments).
+ * ---------------------------------------------------------------------------------------- */
+/* wt_pc::rank(i, c) (include/sdsl/wt_pc.hpp:350-373): out[j] = #c[j] in BWT[0, i[j]). */
+vlg_status vlg_wt_rank_batch(const vlg_index* idx, const uint64_t* d_i, const uint8_t* d_c, uint64_t* d_out,
+                             uint64_t count, void* stream);
+/* backward_search(csa, 0, n-1, pat.begin(), pat.end(), l, r)
+ * (include/sdsl/suffix_array_algorithm.hpp:305-326): pattern p = d_blob[d_off[p], d_off[p+1]).
+ * d_l/d_r receive the interval exactly as the reference leaves it; occurrences = r+1-l. */
+vlg_status vlg_backward_search_batch(const vlg_index* idx, const uint8_t* d_blob, const uint64_t* d_off,
+                                     uint64_t n_patterns, uint64_t* d_l, uint64_t* d_r, void* stream);
+/* csa[i] (include/sdsl/csa_wt.hpp:335-348) for arbitrary SA indices: out[j] = SA[d_i[j]]. */
+vlg_status vlg_sa_batch(const vlg_index* idx, const uint64_t* d_i, uint64_t* d_out, uint64_t count, void* stream);
+/* locate (include/sdsl/suffix_array_algorithm.hpp:604-619): for pattern p the occurrences
+ * csa[l[p]..r[p]] are written, in SA order (unsorted, like the reference), to
+ * d_out[d_out_off[p] ...]; d_out_off = exclusive prefix sum of (r+1-l), n_patterns+1 entries. */
+vlg_status vlg_locate_batch(const vlg_index* idx, const uint64_t* d_l, const uint64_t* d_r,
+                            const uint64_t* d_out_off, uint64_t n_patterns, uint64_t total,
+                            uint64_t* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Query batches.  Parsing mirrors the reference's two dialects:
+ *   VLG_DIALECT_LIBRARY   gapped_pattern_query(const std::string&)   include/sdsl/vlg_index.hpp:54-105
+ *   VLG_DIALECT_BENCHMARK gapped_pattern(const std::string&, true) + index_sasearch's gap mapping
+ *                         benchmark/gapped-matching/include/utils.hpp:25-70, index_sasearch.hpp:68-69,113
+ * ---------------------------------------------------------------------------------------- */
+#define VLG_DIALECT_LIBRARY 0
+#define VLG_DIALECT_BENCHMARK 1
+#define VLG_MAX_SUBPATTERNS 64
+
+/* Parse `n_queries` regexps (concatenated in h_text; query q = h_text[h_off[q], h_off[q+1])) and upload.
+ * h_status (optional, n_queries ints) receives VLG_OK / VLG_E_PARSE / VLG_E_INVALID per query; an
+ * unparsable query stays in the batch as an always-empty query (the reference driver skips such
+ * lines, utils.hpp:94-99).  Returns VLG_E_PARSE if any query failed and h_status is NULL. */
+vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_off, uint64_t n_queries, int dialect,
+                             int* h_status, vlg_queries** out);
+/* Already-parsed form: sub-pattern bytes + per-gap start-to-start bounds (lo,hi) + non-overlap length.
+ * Query q has sub-patterns [h_qsub[q], h_qsub[q+1]); sub-pattern s = h_blob[h_suboff[s], h_suboff[s+1]);
+ * h_lo/h_hi are indexed by sub-pattern (entry of a query's first sub-pattern is ignored). */
+vlg_status vlg_queries_create(const uint8_t* h_blob, const uint64_t* h_suboff, const uint64_t* h_qsub,
+                              const uint64_t* h_lo, const uint64_t* h_hi, const uint64_t* h_end_len,
+                              uint64_t n_queries, vlg_queries** out);
+uint64_t vlg_queries_count(const vlg_queries* q);
+uint64_t vlg_queries_subpatterns(const vlg_queries* q);
+/* h_k[q] = number of sub-patterns of query q (0 for a query that failed to parse). */
+vlg_status vlg_queries_k(const vlg_queries* q, uint32_t* h_k);
+void vlg_queries_destroy(vlg_queries* q);
+
+/* ------------------------------------------------------------------------------------------
+ * Workspace, fused search, results.
+ * ---------------------------------------------------------------------------------------- */
+/* max_hbm_bytes bounds the scratch used per chunk of queries (0 = default 8 GiB). */
+vlg_status vlg_workspace_create(uint64_t max_hbm_bytes, void* stream, vlg_workspace** out);
+void vlg_workspace_destroy(vlg_workspace* ws);
+
+/* The whole hot path for a batch, everything resident in HBM:
+ *   per sub-pattern backward_search -> locate -> sort ascending -> gap-bounded merge join
+ * = `idx.search(pat)` for every pattern (benchmark/gapped-matching/src/gm_search.cpp:91-121,
+ *   index_sasearch.hpp:58-118) and `sdsl::locate(idx, query)` (include/sdsl/vlg_index.hpp:395-401).
+ * Matches are the left-most, lazy, non-overlapping tuples of SURVEY.md Appendix C, bit-exact. */
+vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result** out);
+
+typedef struct {
+    uint64_t n_queries;
+    uint64_t n_matches;           /* = gm_search's num_results (gm_search.cpp:110-114)          */
+    uint64_t checksum;            /* = gm_search's checksum: sum of first positions mod 2^64    */
+    uint64_t n_tuple_values;      /* sum over matches of k(query)                              */
+    uint64_t located_occurrences; /* occurrences materialised by locate                        */
+    uint64_t lf_steps;            /* LF steps taken by locate (csa_wt.hpp:338-341)              */
+    uint64_t wt_levels_locate;    /* 32-byte super-block reads in locate                       */
+    uint64_t wt_levels_bsearch;   /* 32-byte super-block reads in backward search              */
+    uint64_t n_chunks;
+} vlg_result_summary;
+
+vlg_status vlg_result_summary_get(const vlg_result* r, vlg_result_summary* s);
+/* Copy to host.  counts[q] = matches of query q; offsets = exclusive prefix sum (n_queries+1);
+ * first_positions = gapped_search_result::positions of every query, concatenated (utils.hpp:73-80);
+ * tuples = every sub-pattern position of every match (vlg_iterator::operator[], vlg_index.hpp:337-340),
+ * query-major, k(q) values per match.  Any pointer may be NULL. */
+vlg_status vlg_result_fetch(const vlg_result* r, uint64_t* h_counts, uint64_t* h_offsets,
+                            uint64_t* h_first_positions, uint64_t* h_tuples);
+void vlg_result_destroy(vlg_result* r);
+
+/* Per-kernel accounting of the last calls on this workspace (HIP events on the workspace stream).
+ * Enabled with vlg_workspace_profile(ws, 1); reset by vlg_workspace_profile(ws, 1) again. */
+typedef struct {
+    char name[32];                /* "backward_search", "locate", "sort", "join", ...           */
+    uint64_t launches;
+    double total_ms;              /* sum of event-timed launch durations                       */
+    uint64_t algorithmic_bytes;   /* SURVEY.md 8(d) accounting, 0 if not defined for the kernel */
+} vlg_kernel_stat;
+vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
+vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLG_HIP_H */

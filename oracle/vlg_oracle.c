@@ -636,27 +636,34 @@ static int cmp_u64(const void* a, const void* b)
 }
 
 /* index_sasearch::search shape (index_sasearch.hpp:58-118) on the FM path of SURVEY 3.3:
- * per sub-pattern backward_search + locate, std::sort, then the join. */
+ * per sub-pattern backward_search; if any interval is empty the query has no match and nothing
+ * is located (vlg_index.hpp:315-316 returns at the first empty range); otherwise locate every
+ * list, std::sort it, then the join. */
 uint64_t vlgo_search(const vlgo_index* x, const vlgo_query* q, uint64_t* out, uint64_t cap, uint64_t* stats)
 {
     uint64_t* lists[VLGO_MAX_SUB];
-    uint64_t lens[VLGO_MAX_SUB];
+    uint64_t lens[VLGO_MAX_SUB], ls[VLGO_MAX_SUB];
     uint64_t st_occ = 0, st_lf = 0, st_lv = 0, st_rk = 0;
     uint32_t k = q->k;
-    int empty = 0;
-    for (uint32_t i = 0; i < VLGO_MAX_SUB; ++i) { lists[i] = NULL; lens[i] = 0; }
+    int empty = (k == 0);
+    for (uint32_t i = 0; i < VLGO_MAX_SUB; ++i) { lists[i] = NULL; lens[i] = 0; ls[i] = 0; }
     for (uint32_t i = 0; i < k; ++i) {
-        uint64_t l, r, occ = 0;
-        if (q->sub_len[i] < x->n) occ = bs_cnt(x, q->sub[i], q->sub_len[i], &l, &r, &st_rk);
+        uint64_t r, occ = 0;
+        if (q->sub_len[i] < x->n) occ = bs_cnt(x, q->sub[i], q->sub_len[i], &ls[i], &r, &st_rk);
         lens[i] = occ;
-        if (occ == 0) { empty = 1; break; }                       /* vlg_index.hpp:315-316 */
-        lists[i] = (uint64_t*)malloc(8 * occ);
-        for (uint64_t j = 0; j < occ; ++j) lists[i][j] = vlgo_sa(x, l + j, &st_lf, &st_lv);
-        st_occ += occ;
-        qsort(lists[i], occ, 8, cmp_u64);                         /* index_sasearch.hpp:80 */
+        if (occ == 0) empty = 1;
     }
     uint64_t res = 0;
-    if (!empty) res = vlgo_join(k, (const uint64_t* const*)lists, lens, q->lo, q->hi, q->end_len, out, cap);
+    if (!empty) {
+        for (uint32_t i = 0; i < k; ++i) {
+            uint64_t occ = lens[i];
+            lists[i] = (uint64_t*)malloc(8 * occ);
+            for (uint64_t j = 0; j < occ; ++j) lists[i][j] = vlgo_sa(x, ls[i] + j, &st_lf, &st_lv);
+            st_occ += occ;
+            qsort(lists[i], occ, 8, cmp_u64);                     /* index_sasearch.hpp:80 */
+        }
+        res = vlgo_join(k, (const uint64_t* const*)lists, lens, q->lo, q->hi, q->end_len, out, cap);
+    }
     for (uint32_t i = 0; i < k; ++i) free(lists[i]);
     if (stats) { stats[0] += st_occ; stats[1] += st_lf; stats[2] += st_lv; stats[3] += st_rk; }
     return res;

@@ -1,0 +1,264 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (include/vlg_hip.h), against the CPU oracle
+on the same seeded inputs and against the committed known answers.  Bit-exact everywhere (integer work)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from util import dna_text, skewed_text
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "vlg_known_answers.json")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def V():
+    import vlg_matching_amd as v
+    v.lib()                      # fails loudly if the HIP extension is missing
+    return v
+
+
+def dev_u64(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).cuda()
+
+
+def host_u64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def bits_to_words(bits):
+    nbits = len(bits)
+    nw = (nbits + 63) // 64
+    b = np.zeros(nw * 64, dtype=bool)
+    b[:nbits] = bits
+    return np.packbits(b.reshape(-1, 64)[:, ::-1], axis=1).view(">u8").ravel().astype(np.uint64) if nw else np.zeros(0, np.uint64)
+
+
+@pytest.mark.parametrize("nbits", [0, 1, 63, 64, 223, 224, 225, 447, 448, 4096, 100000, 1 << 20])
+def test_k1_bitvector_rank(torch_cuda, V, oracle, nbits):
+    """rank_support_test.cpp:70-87 restated: rank(j) for every j (sampled for big vectors)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(nbits + 1)
+    for dens in (0.0, 0.1, 0.5, 1.0):
+        bits = rng.random(nbits) < dens
+        words = bits_to_words(bits)
+        bv = V.BitVector(words, nbits)
+        idx = np.arange(nbits + 1, dtype=np.uint64) if nbits <= 5000 else \
+            np.unique(np.concatenate([rng.integers(0, nbits + 1, 20000), [0, nbits, 224, 223, nbits - 1]])).astype(np.uint64)
+        d_idx = dev_u64(torch, idx)
+        d_out = torch.zeros_like(d_idx)
+        bv.rank_device(d_idx.data_ptr(), d_out.data_ptr(), len(idx))
+        torch.cuda.synchronize()
+        got = host_u64(d_out)
+        L = oracle.lib()
+        wpad = np.concatenate([words, np.zeros(1, np.uint64)])
+        blocks = np.zeros(2 * ((len(words) >> 3) + 1), dtype=np.uint64)
+        L.vlgo_rank_v_build(wpad.ctypes.data, nbits, blocks.ctypes.data)
+        want = np.array([L.vlgo_rank_v(wpad.ctypes.data, blocks.ctypes.data, int(i)) for i in idx[:3000]], dtype=np.uint64)
+        assert (got[:3000] == want).all()
+        truth = np.concatenate([[0], np.cumsum(bits)])[idx.astype(np.int64)]
+        assert (got == truth).all()
+
+
+TEXTS = {
+    "abracadabra": lambda: b"abracadabrasimsalabim",
+    "one_byte": lambda: b"a",
+    "100a": lambda: b"a" * 100,
+    "all_symbols": lambda: bytes(range(1, 256)),
+    "dna_50k": lambda: dna_text(50000, 1).tobytes(),
+    "dna_skew": lambda: dna_text(30000, 2, (0.7, 0.1, 0.1, 0.1)).tobytes(),
+    "zipf40": lambda: skewed_text(40000, 3).tobytes(),
+}
+
+
+def assert_parts_equal(a, b, check_rank=True):
+    assert a["n"] == b["n"] and a["sigma"] == b["sigma"] and a["bv_bits"] == b["bv_bits"]
+    assert (np.asarray(a["char2comp"]) == np.asarray(b["char2comp"])).all()
+    assert (np.asarray(a["C"]) == np.asarray(b["C"])).all()
+    assert (np.asarray(a["bv_words"]) == np.asarray(b["bv_words"])).all(), "wavelet-tree bits differ"
+    assert (np.asarray(a["samples"]) == np.asarray(b["samples"])).all(), "SA samples differ"
+    na, nb = a["nodes"], b["nodes"]
+    assert len(na) == len(nb)
+    for f in ("bv_pos", "parent", "child") + (("bv_pos_rank",) if check_rank else ()):
+        assert (na[f] == nb[f]).all(), f
+
+
+@pytest.mark.parametrize("name", list(TEXTS))
+def test_from_parts_export_and_blob(torch_cuda, V, oracle, name):
+    torch = torch_cuda
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    parts = o.parts()
+    idx = V.VlgIndex.from_parts(parts)
+    assert_parts_equal(idx.export_parts(), parts)
+    nb = idx.blob_bytes()
+    blob = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    idx.blob_export(blob.data_ptr(), nb)
+    blob2 = blob.clone()                                  # as if it had been broadcast to another GPU
+    idx2 = V.VlgIndex.attach_blob(blob2.data_ptr(), nb, keep=blob2)
+    assert_parts_equal(idx2.export_parts(), parts)
+    assert idx2.info() == idx.info()
+
+
+@pytest.mark.parametrize("name", list(TEXTS) + ["empty"])
+def test_device_build_equals_oracle_build(V, oracle, name):
+    """SA (csa_byte_test.cpp:136-147 via samples), BWT -> identical Huffman WT bits, tree, C, samples."""
+    text = b"" if name == "empty" else TEXTS[name]()
+    idx = V.VlgIndex.build(text)
+    want = oracle.Index.from_text(text).parts()
+    assert_parts_equal(idx.export_parts(), want)
+
+
+def test_device_build_rejects_zero_byte(V):
+    with pytest.raises(V.VlgError) as e:
+        V.VlgIndex.build(b"ab\0cd")
+    assert e.value.status == 5
+
+
+def test_device_build_larger_dna(V, oracle):
+    text = dna_text(1 << 20, 77).tobytes()
+    idx = V.VlgIndex.build(text)
+    assert_parts_equal(idx.export_parts(), oracle.Index.from_text(text).parts())
+
+
+@pytest.mark.parametrize("name", ["abracadabra", "100a", "dna_50k", "zipf40", "all_symbols"])
+def test_k2_k3_primitives(torch_cuda, V, oracle, name):
+    torch = torch_cuda
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.from_parts(o.parts())
+    n = o.n
+    rng = np.random.default_rng(5)
+    L = V.lib()
+    # wt_pc::rank
+    m = 4000
+    pos = rng.integers(0, n + 1, m).astype(np.uint64)
+    syms = rng.choice(np.unique(np.concatenate([np.frombuffer(text, np.uint8), [0, 254]])), m).astype(np.uint8)
+    d_pos, d_sym = dev_u64(torch, pos), torch.from_numpy(syms).cuda()
+    d_out = torch.zeros_like(d_pos)
+    V.capi.check(L.vlg_wt_rank_batch(idx._h, d_pos.data_ptr(), d_sym.data_ptr(), d_out.data_ptr(), m, None))
+    torch.cuda.synchronize()
+    want = np.array([o.wt_rank(int(p), int(c)) for p, c in zip(pos, syms)], dtype=np.uint64)
+    assert (host_u64(d_out) == want).all()
+    # csa[i] for every i (small) or a sample
+    ii = np.arange(n, dtype=np.uint64) if n <= 60000 else rng.integers(0, n, 60000).astype(np.uint64)
+    d_i = dev_u64(torch, ii)
+    d_o = torch.zeros_like(d_i)
+    V.capi.check(L.vlg_sa_batch(idx._h, d_i.data_ptr(), d_o.data_ptr(), len(ii), None))
+    torch.cuda.synchronize()
+    sa = oracle.suffix_array(np.frombuffer(text + b"\0", np.uint8))
+    assert (host_u64(d_o) == sa[ii.astype(np.int64)]).all()
+    # backward_search + locate of a pattern batch
+    pats = [text[s:s + k] for s, k in zip(rng.integers(0, max(1, len(text) - 9), 300), rng.integers(1, 9, 300))]
+    pats += [b"\xfe\xfe", b"zq", text, text + b"x", text[:1]]
+    blob = np.frombuffer(b"".join(pats) + b"\0", np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in pats])]).astype(np.uint64)
+    d_blob, d_off = torch.from_numpy(blob.copy()).cuda(), dev_u64(torch, off)
+    d_l, d_r = torch.zeros(len(pats), dtype=torch.int64, device="cuda"), torch.zeros(len(pats), dtype=torch.int64, device="cuda")
+    V.capi.check(L.vlg_backward_search_batch(idx._h, d_blob.data_ptr(), d_off.data_ptr(), len(pats), d_l.data_ptr(), d_r.data_ptr(), None))
+    torch.cuda.synchronize()
+    l, r = host_u64(d_l), host_u64(d_r)
+    ref = [o.backward_search(p) for p in pats]
+    assert [(int(a), int(b)) for a, b in zip(l, r)] == [(x[1], x[2]) for x in ref]
+    occ = (r + np.uint64(1) - l).astype(np.uint64)
+    ooff = np.concatenate([[0], np.cumsum(occ)]).astype(np.uint64)
+    total = int(ooff[-1])
+    d_ooff = dev_u64(torch, ooff)
+    d_loc = torch.zeros(max(total, 1), dtype=torch.int64, device="cuda")
+    V.capi.check(L.vlg_locate_batch(idx._h, d_l.data_ptr(), d_r.data_ptr(), d_ooff.data_ptr(), len(pats), total, d_loc.data_ptr(), None))
+    torch.cuda.synchronize()
+    loc = host_u64(d_loc)
+    for j, p in enumerate(pats):
+        assert (loc[int(ooff[j]): int(ooff[j + 1])] == o.locate(p)).all(), p      # SA order, like the reference
+
+
+def test_known_answers_on_gpu(V):
+    cases = json.load(open(GOLD))["cases"]
+    for c in cases:
+        idx = V.VlgIndex.build(c["text"].encode())
+        if "error" in c:
+            with pytest.raises(V.VlgError) as e:
+                V.locate(idx, c["query"])
+            assert e.value.status == 4 and c["error"] in str(e.value)
+        else:
+            assert V.locate(idx, c["query"]).tolist() == c["tuples"], c
+            assert V.count(idx, c["query"]) == len(c["tuples"])
+
+
+def random_queries(text, rng, nq, kmax=5, mmax=5, gapmax=60, gaplo=30):
+    qs = []
+    for _ in range(nq):
+        k = int(rng.integers(1, kmax + 1))
+        subs = []
+        for _ in range(k):
+            s = int(rng.integers(0, len(text) - mmax - 1))
+            subs.append(text[s:s + int(rng.integers(1, mmax + 1))])
+        q = subs[0].decode("latin-1")
+        for sp in subs[1:]:
+            a = int(rng.integers(0, gaplo))
+            q += ".{%d,%d}?%s" % (a, a + int(rng.integers(0, gapmax)), sp.decode("latin-1"))
+        qs.append(q)
+    return qs
+
+
+@pytest.mark.parametrize("name,seed", [("dna_50k", 1), ("dna_skew", 2), ("zipf40", 3), ("100a", 4)])
+def test_search_batch_vs_oracle(V, oracle, name, seed):
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    rng = np.random.default_rng(seed)
+    qs = random_queries(text, rng, 400)
+    qs += ["\xfe.{0,5}?" + qs[0][:1], qs[1][:1] + ".{0,5}?\xfe"]            # empty first / last list
+    res = idx.search(qs)
+    total, chk, occ = 0, 0, np.zeros(4, dtype=np.uint64)
+    for i, q in enumerate(qs):
+        want = o.search(q, stats=occ)
+        got = res.tuples(i)
+        assert got.tolist() == want.tolist(), q
+        assert (res.positions(i) == want[:, 0]).all() if len(want) else len(res.positions(i)) == 0
+        total += len(want)
+        chk = (chk + int(want[:, 0].sum())) & (2 ** 64 - 1) if len(want) else chk
+    s = res.summary
+    assert s["n_matches"] == total and s["checksum"] == chk
+    assert s["located_occurrences"] == int(occ[0]) and s["lf_steps"] == int(occ[1])
+    assert s["wt_levels_locate"] == int(occ[2]) and s["wt_levels_bsearch"] == int(occ[3])
+
+
+def test_search_benchmark_dialect_and_bad_queries(V, oracle):
+    text = TEXTS["dna_50k"]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    qs = ["ACG.{0,50}TT.{0,50}GA", "A.{3,9}C", "TTT", "AC.{5,1}GT", "ACGT.{0,10}", "G.{0,4}?C"]
+    res = idx.search(qs, dialect=V.capi.DIALECT_BENCHMARK, strict=False)
+    for i, q in enumerate(qs):
+        try:
+            want = o.search(q, dialect=1)
+        except oracle.ParseError:
+            want = np.zeros((0, 1), np.uint64)
+        assert res.tuples(i).tolist() == want.tolist() or (len(want) == 0 and int(res.counts[i]) == 0), q
+
+
+def test_search_chunked_equals_unchunked(V):
+    """A tiny workspace forces many chunks; results must not change."""
+    text = TEXTS["dna_50k"]()
+    idx = V.VlgIndex.build(text)
+    qs = random_queries(text, np.random.default_rng(9), 300, kmax=3, mmax=3)
+    from vlg_matching_amd.index import Workspace
+    a = idx.search(qs)
+    b = idx.search(qs, workspace=Workspace(max_hbm_bytes=(64 << 20) + 44 * 40000))
+    assert b.summary["n_chunks"] > a.summary["n_chunks"]
+    for k in ("n_matches", "checksum", "n_tuple_values", "located_occurrences", "lf_steps", "wt_levels_locate"):
+        assert a.summary[k] == b.summary[k], k
+    fa, fb = a.fetch(), b.fetch()
+    for x, y in zip(fa, fb):
+        assert (x == y).all()

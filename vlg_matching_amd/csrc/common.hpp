@@ -1,0 +1,121 @@
+// Shared declarations of the MI355X VLG library (device layout, error plumbing).
+//
+// HBM layout of the index ("blob": ONE contiguous device allocation, 256-byte aligned sections):
+//
+//   [BlobHeader][blocks][nodes][C][paths][char2comp][samples][reference-layout nodes]
+//
+// blocks : the Huffman-shaped wavelet tree of the BWT, level-contiguous like the reference
+//          (BFS node order, include/sdsl/wt_helper.hpp:170-206) but re-cut into 256-bit
+//          super-blocks  { 7 x u32 data = 224 bits, u32 cnt }.  Every inner node starts on a
+//          block boundary and owns size/224 + 1 blocks; cnt = number of 1s of THIS NODE before the
+//          block (node-relative, so bv_pos_rank(v) of wt_pc.hpp:364 is folded away and the count
+//          fits 32 bits for n <= 2^32).  One rank = one aligned 32-byte read.
+// nodes  : DNode per tree node {first block, child[0], child[1]}; a child word with bit 31 set is a
+//          leaf and carries the alphabet rank (comp) of its symbol in the low bits.
+// C      : u64[sigma+1] cumulative counts (lib/csa_alphabet_strategy.cpp:25-55)
+// paths  : u64[256] m_path of wt_helper.hpp:219-240 (code bits, first edge in bit 0; length in 56..63)
+// samples: SA[0], SA[d], SA[2d], ... as u32 (n <= 2^32) or u64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/vlg_hip.h"
+
+namespace vlg {
+
+constexpr uint32_t kBlockBits = 224;
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint64_t kBlobMagic = 0x31424C4756ULL;  // "VGLB1"
+constexpr uint32_t kMaxNodes = 512;
+
+struct __attribute__((aligned(16))) DNode {
+    uint32_t base;      // first 32-byte block of the node (inner nodes only)
+    uint32_t child[2];  // node id, or kLeafFlag | comp
+    uint32_t size_lo;   // node size in bits (low 32 bits; informational)
+};
+
+struct __attribute__((aligned(32))) Block {
+    uint32_t w[7];
+    uint32_t cnt;
+};
+
+struct BlobHeader {
+    uint64_t magic;
+    uint64_t total_bytes;
+    uint64_t n;
+    uint64_t wt_bits;
+    uint64_t n_blocks;
+    uint64_t n_samples;
+    uint32_t sigma;
+    uint32_t dens;
+    uint32_t n_nodes;
+    uint32_t max_code_len;
+    uint32_t sample_bytes;
+    uint32_t pad0;
+    uint64_t off_blocks, off_nodes, off_C, off_paths, off_c2c, off_samples, off_refnodes;
+    uint64_t reserved[7];
+};
+
+// What kernels receive (by value).
+struct IndexView {
+    const Block* blocks;
+    const DNode* nodes;
+    const uint64_t* C;
+    const uint64_t* paths;
+    const uint8_t* char2comp;
+    const void* samples;
+    uint64_t n;
+    uint64_t n_samples;
+    uint32_t n_nodes;
+    uint32_t sigma;
+    uint32_t dens;
+    uint32_t sample_bytes;
+};
+
+void set_error(const std::string& msg);
+vlg_status fail(vlg_status st, const std::string& msg);
+
+#define VLG_HIP_TRY(expr)                                                                        \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return ::vlg::fail(_e == hipErrorOutOfMemory ? VLG_E_OOM : VLG_E_NO_DEVICE,          \
+                               std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+inline uint32_t bit_width64(uint64_t x) { return x ? 64u - (uint32_t)__builtin_clzll(x) : 0u; }
+
+// Host-side description of the tree, shared by from_parts and the device builder.
+struct HostTree {
+    uint32_t n_nodes = 0;
+    uint32_t sigma = 0;
+    uint32_t max_code_len = 0;
+    std::vector<vlg_wt_node> nodes;     // reference layout
+    std::vector<uint64_t> node_size;    // bits per inner node (0 for leaves)
+    std::vector<uint32_t> node_depth;
+    std::vector<uint64_t> paths;        // [256]
+    std::vector<uint16_t> c_to_leaf;    // [256]
+    std::vector<DNode> dnodes;          // device layout
+    uint64_t wt_bits = 0;
+    uint64_t n_blocks = 0;
+    uint8_t char2comp[256];
+    std::vector<uint64_t> C;            // [sigma+1]
+};
+
+// Huffman shape + BFS layout from symbol counts (restates wt_huff.hpp:91-117, wt_helper.hpp:170-241).
+vlg_status tree_from_counts(const uint64_t counts[256], HostTree& t);
+// Adopt reference nodes (from a loaded index).
+vlg_status tree_from_nodes(const vlg_wt_node* nodes, uint32_t n_nodes, uint64_t bv_bits, const uint8_t* char2comp,
+                           const uint64_t* C, uint32_t sigma, HostTree& t);
+
+}  // namespace vlg
+
+struct vlg_index {
+    void* d_blob = nullptr;
+    bool owns_blob = true;
+    vlg::BlobHeader hdr;
+    vlg::IndexView view;
+    vlg::HostTree tree;   // host copy (node table, C, ...) for export and planning
+};

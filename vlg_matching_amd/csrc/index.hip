@@ -1,0 +1,759 @@
+// Index objects in HBM: creation from reference-layout parts, export, blob replication, and the
+// on-device builder (suffix sort by prefix doubling -> BWT -> wavelet-tree super-blocks -> SA samples).
+#include <algorithm>
+#include <cstring>
+#include <string.h>
+#include "common.hpp"
+#include <rocprim/rocprim.hpp>
+
+using namespace vlg;
+
+namespace {
+
+struct InnerTable {          // inner nodes sorted by first block (= BFS order), for block->node lookup
+    uint32_t count;
+    uint32_t base[256];
+    uint64_t bv_pos[256];
+    uint64_t size[256];
+    uint32_t depth[256];
+    uint32_t node[256];
+};
+
+__device__ __forceinline__ uint32_t find_inner_by_block(const InnerTable& t, uint32_t blk)
+{
+    uint32_t lo = 0, hi = t.count;            // last k with base[k] <= blk
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (t.base[mid] <= blk) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// sdsl bit-vector words -> data words of the 256-bit super-blocks (pull: one thread per u32 word)
+__global__ void repack_kernel(const uint64_t* __restrict__ src, uint64_t src_words, Block* __restrict__ blocks,
+                              uint64_t n_blocks, const InnerTable* __restrict__ tab)
+{
+    __shared__ InnerTable t;
+    for (uint32_t i = threadIdx.x; i < sizeof(InnerTable) / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tab)[i];
+    __syncthreads();
+    uint64_t total = n_blocks * 8;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t blk = (uint32_t)(g >> 3), w = (uint32_t)(g & 7);
+        if (w == 7) continue;                                    // cnt word: second pass
+        uint32_t k = find_inner_by_block(t, blk);
+        uint64_t rel = (uint64_t)(blk - t.base[k]) * kBlockBits + 32u * w;   // node-relative bit
+        uint32_t val = 0;
+        if (rel < t.size[k]) {
+            uint64_t bit = t.bv_pos[k] + rel;
+            uint64_t wi = bit >> 6;
+            uint32_t s = (uint32_t)(bit & 63);
+            uint64_t lo = src[wi] >> s;
+            if (s > 32 && wi + 1 < src_words) lo |= src[wi + 1] << (64 - s);
+            val = (uint32_t)lo;
+            uint64_t left = t.size[k] - rel;
+            if (left < 32) val &= (1u << left) - 1u;
+        }
+        blocks[blk].w[w] = val;
+    }
+}
+
+struct BlockPop {
+    const Block* blocks;
+    __device__ uint64_t operator()(uint64_t b) const
+    {
+        const Block& B = blocks[b];
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) c += __popc(B.w[i]);
+        return c;
+    }
+};
+
+// cnt = ones of the node before the block = global exclusive scan - scan at the node's first block
+__global__ void fill_counts_kernel(Block* __restrict__ blocks, const uint64_t* __restrict__ scan, uint64_t n_blocks,
+                                   const InnerTable* __restrict__ tab)
+{
+    __shared__ InnerTable t;
+    for (uint32_t i = threadIdx.x; i < sizeof(InnerTable) / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tab)[i];
+    __syncthreads();
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t k = find_inner_by_block(t, (uint32_t)b);
+        blocks[b].cnt = (uint32_t)(scan[b] - scan[t.base[k]]);
+    }
+}
+
+// super-blocks -> sdsl bit-vector words (one thread per u64 output word; export only)
+__global__ void unpack_kernel(const Block* __restrict__ blocks, uint64_t* __restrict__ dst, uint64_t dst_words,
+                              uint64_t bv_bits, const InnerTable* __restrict__ tab)
+{
+    __shared__ InnerTable t;
+    for (uint32_t i = threadIdx.x; i < sizeof(InnerTable) / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tab)[i];
+    __syncthreads();
+    for (uint64_t W = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; W < dst_words; W += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t out = 0;
+        for (uint32_t j = 0; j < 64; ++j) {
+            uint64_t bit = W * 64 + j;
+            if (bit >= bv_bits) break;
+            uint32_t lo = 0, hi = t.count;                     // last k with bv_pos[k] <= bit
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (t.bv_pos[mid] <= bit) lo = mid; else hi = mid; }
+            uint64_t rel = bit - t.bv_pos[lo];
+            uint64_t blk = t.base[lo] + rel / kBlockBits;
+            uint32_t off = (uint32_t)(rel % kBlockBits);
+            out |= (uint64_t)((blocks[blk].w[off >> 5] >> (off & 31)) & 1u) << j;
+        }
+        dst[W] = out;
+    }
+}
+
+InnerTable make_inner_table(const HostTree& t)
+{
+    InnerTable tab;
+    memset(&tab, 0, sizeof tab);
+    for (uint32_t v = 0; v < t.n_nodes; ++v)
+        if (t.nodes[v].child[0] != 0xFFFF) {
+            uint32_t k = tab.count++;
+            tab.base[k] = t.dnodes[v].base;
+            tab.bv_pos[k] = t.nodes[v].bv_pos;
+            tab.size[k] = t.node_size[v];
+            tab.depth[k] = t.node_depth[v];
+            tab.node[k] = v;
+        }
+    return tab;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 256); }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+void bind_view(vlg_index* idx)
+{
+    uint8_t* b = reinterpret_cast<uint8_t*>(idx->d_blob);
+    const BlobHeader& h = idx->hdr;
+    idx->view.blocks = reinterpret_cast<const Block*>(b + h.off_blocks);
+    idx->view.nodes = reinterpret_cast<const DNode*>(b + h.off_nodes);
+    idx->view.C = reinterpret_cast<const uint64_t*>(b + h.off_C);
+    idx->view.paths = reinterpret_cast<const uint64_t*>(b + h.off_paths);
+    idx->view.char2comp = b + h.off_c2c;
+    idx->view.samples = b + h.off_samples;
+    idx->view.n = h.n;
+    idx->view.n_samples = h.n_samples;
+    idx->view.n_nodes = h.n_nodes;
+    idx->view.sigma = h.sigma;
+    idx->view.dens = h.dens;
+    idx->view.sample_bytes = h.sample_bytes;
+}
+
+// Plan the blob from the host tree, allocate it, upload the small tables. Blocks + samples stay to be filled.
+vlg_status alloc_blob(vlg_index* idx, uint64_t n, uint32_t dens, hipStream_t stream)
+{
+    HostTree& t = idx->tree;
+    BlobHeader& h = idx->hdr;
+    memset(&h, 0, sizeof h);
+    h.magic = kBlobMagic;
+    h.n = n;
+    h.wt_bits = t.wt_bits;
+    h.n_blocks = t.n_blocks;
+    h.sigma = t.sigma;
+    h.dens = dens;
+    h.n_nodes = t.n_nodes;
+    h.max_code_len = t.max_code_len;
+    h.n_samples = (n + dens - 1) / dens;
+    h.sample_bytes = (n <= 0x100000000ull) ? 4 : 8;
+    uint64_t off = align_up(sizeof(BlobHeader), 256);
+    h.off_blocks = off;  off = align_up(off + h.n_blocks * sizeof(Block), 256);
+    h.off_nodes = off;   off = align_up(off + (uint64_t)kMaxNodes * sizeof(DNode), 256);
+    h.off_C = off;       off = align_up(off + 257 * 8, 256);
+    h.off_paths = off;   off = align_up(off + 256 * 8, 256);
+    h.off_c2c = off;     off = align_up(off + 256, 256);
+    h.off_samples = off; off = align_up(off + h.n_samples * h.sample_bytes, 256);
+    h.off_refnodes = off; off = align_up(off + (uint64_t)kMaxNodes * sizeof(vlg_wt_node), 256);
+    h.total_bytes = off;
+    VLG_HIP_TRY(hipMalloc(&idx->d_blob, h.total_bytes));
+    idx->owns_blob = true;
+    uint8_t* b = reinterpret_cast<uint8_t*>(idx->d_blob);
+    VLG_HIP_TRY(hipMemcpyAsync(b, &h, sizeof h, hipMemcpyHostToDevice, stream));
+    VLG_HIP_TRY(hipMemsetAsync(b + h.off_nodes, 0, kMaxNodes * sizeof(DNode), stream));
+    if (t.n_nodes)
+        VLG_HIP_TRY(hipMemcpyAsync(b + h.off_nodes, t.dnodes.data(), t.n_nodes * sizeof(DNode), hipMemcpyHostToDevice, stream));
+    VLG_HIP_TRY(hipMemsetAsync(b + h.off_C, 0, 257 * 8, stream));
+    VLG_HIP_TRY(hipMemcpyAsync(b + h.off_C, t.C.data(), t.C.size() * 8, hipMemcpyHostToDevice, stream));
+    VLG_HIP_TRY(hipMemcpyAsync(b + h.off_paths, t.paths.data(), 256 * 8, hipMemcpyHostToDevice, stream));
+    VLG_HIP_TRY(hipMemcpyAsync(b + h.off_c2c, t.char2comp, 256, hipMemcpyHostToDevice, stream));
+    VLG_HIP_TRY(hipMemsetAsync(b + h.off_refnodes, 0, kMaxNodes * sizeof(vlg_wt_node), stream));
+    if (t.n_nodes)
+        VLG_HIP_TRY(hipMemcpyAsync(b + h.off_refnodes, t.nodes.data(), t.n_nodes * sizeof(vlg_wt_node), hipMemcpyHostToDevice, stream));
+    VLG_HIP_TRY(hipStreamSynchronize(stream));   // host sources above may go out of scope
+    bind_view(idx);
+    return VLG_OK;
+}
+
+// Second pass shared by from_parts and the builder: popcount scan -> node-relative cnt words.
+vlg_status fill_block_counts(vlg_index* idx, const InnerTable* d_tab, hipStream_t stream)
+{
+    uint64_t nb = idx->hdr.n_blocks;
+    if (!nb) return VLG_OK;
+    Block* blocks = const_cast<Block*>(idx->view.blocks);
+    DevBuf scan, temp;
+    VLG_HIP_TRY(scan.alloc(nb * 8));
+    auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), BlockPop{blocks});
+    size_t tb = 0;
+    VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, in, scan.as<uint64_t>(), (uint64_t)0, nb, rocprim::plus<uint64_t>(), stream));
+    VLG_HIP_TRY(temp.alloc(tb));
+    VLG_HIP_TRY(rocprim::exclusive_scan(temp.p, tb, in, scan.as<uint64_t>(), (uint64_t)0, nb, rocprim::plus<uint64_t>(), stream));
+    uint32_t grid = (uint32_t)std::min<uint64_t>((nb + 255) / 256, 8192);
+    hipLaunchKernelGGL(fill_counts_kernel, dim3(grid), dim3(256), 0, stream, blocks, scan.as<uint64_t>(), nb, d_tab);
+    VLG_HIP_TRY(hipGetLastError());
+    VLG_HIP_TRY(hipStreamSynchronize(stream));
+    return VLG_OK;
+}
+
+vlg_status check_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(VLG_E_NO_DEVICE, "no HIP device available (the VLG library has no CPU fallback)");
+    return VLG_OK;
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_device_count(int* n)
+{
+    if (!n) return fail(VLG_E_INVALID, "null argument");
+    *n = 0;
+    hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess) { *n = 0; return fail(VLG_E_NO_DEVICE, hipGetErrorString(e)); }
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_set_device(int ordinal)
+{
+    VLG_HIP_TRY(hipSetDevice(ordinal));
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_index_from_parts(const vlg_index_parts* p, vlg_index** out)
+{
+    if (!p || !out) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    if (vlg_status st = check_device()) return st;
+    if (p->n == 0 || !p->char2comp || !p->C || !p->nodes || (p->bv_bits && !p->bv_words) || !p->sa_samples)
+        return fail(VLG_E_INVALID, "incomplete index parts");
+    if (p->sa_sample_dens == 0) return fail(VLG_E_INVALID, "sa_sample_dens must be > 0");
+    if (p->n > (1ull << 36)) return fail(VLG_E_UNSUPPORTED, "text longer than 2^36");
+    if (p->n_samples != (p->n + p->sa_sample_dens - 1) / p->sa_sample_dens)
+        return fail(VLG_E_INVALID, "n_samples must be ceil(n/dens)");
+    vlg_index* idx = new vlg_index();
+    vlg_status st = tree_from_nodes(p->nodes, p->n_nodes, p->bv_bits, p->char2comp, p->C, p->sigma, idx->tree);
+    if (st) { delete idx; return st; }
+    hipStream_t stream = nullptr;
+    st = alloc_blob(idx, p->n, p->sa_sample_dens, stream);
+    if (st) { vlg_index_destroy(idx); return st; }
+    auto run = [&]() -> vlg_status {
+        const BlobHeader& h = idx->hdr;
+        uint8_t* b = reinterpret_cast<uint8_t*>(idx->d_blob);
+        // samples
+        if (h.sample_bytes == 4) {
+            std::vector<uint32_t> s32(h.n_samples);
+            for (uint64_t i = 0; i < h.n_samples; ++i) s32[i] = (uint32_t)p->sa_samples[i];
+            VLG_HIP_TRY(hipMemcpy(b + h.off_samples, s32.data(), h.n_samples * 4, hipMemcpyHostToDevice));
+        } else {
+            VLG_HIP_TRY(hipMemcpy(b + h.off_samples, p->sa_samples, h.n_samples * 8, hipMemcpyHostToDevice));
+        }
+        if (h.n_blocks) {
+            InnerTable tab = make_inner_table(idx->tree);
+            DevBuf d_tab, d_src;
+            VLG_HIP_TRY(d_tab.alloc(sizeof tab));
+            VLG_HIP_TRY(hipMemcpy(d_tab.p, &tab, sizeof tab, hipMemcpyHostToDevice));
+            uint64_t words = (p->bv_bits + 63) / 64;
+            VLG_HIP_TRY(d_src.alloc(words * 8 + 8));
+            VLG_HIP_TRY(hipMemcpy(d_src.p, p->bv_words, words * 8, hipMemcpyHostToDevice));
+            Block* blocks = const_cast<Block*>(idx->view.blocks);
+            uint32_t grid = (uint32_t)std::min<uint64_t>((h.n_blocks * 8 + 255) / 256, 16384);
+            hipLaunchKernelGGL(repack_kernel, dim3(grid), dim3(256), 0, stream, d_src.as<uint64_t>(), words, blocks,
+                               h.n_blocks, d_tab.as<InnerTable>());
+            VLG_HIP_TRY(hipGetLastError());
+            if (vlg_status s2 = fill_block_counts(idx, d_tab.as<InnerTable>(), stream)) return s2;
+        }
+        VLG_HIP_TRY(hipDeviceSynchronize());
+        return VLG_OK;
+    };
+    st = run();
+    if (st) { vlg_index_destroy(idx); return st; }
+    *out = idx;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_parts* sizes, vlg_index_parts_out* out)
+{
+    if (!idx || !sizes) return fail(VLG_E_INVALID, "null argument");
+    const BlobHeader& h = idx->hdr;
+    memset(sizes, 0, sizeof *sizes);
+    sizes->n = h.n;
+    sizes->sigma = h.sigma;
+    sizes->sa_sample_dens = h.dens;
+    sizes->bv_bits = h.wt_bits;
+    sizes->n_nodes = h.n_nodes;
+    sizes->n_samples = h.n_samples;
+    if (!out) return VLG_OK;
+    const HostTree& t = idx->tree;
+    if (out->char2comp) memcpy(out->char2comp, t.char2comp, 256);
+    if (out->C) { memset(out->C, 0, 257 * 8); memcpy(out->C, t.C.data(), t.C.size() * 8); }
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(idx->d_blob);
+    uint64_t words = (h.wt_bits + 63) / 64;
+    std::vector<uint64_t> bv(words);
+    if (words && (out->bv_words || out->nodes)) {
+        InnerTable tab = make_inner_table(t);
+        DevBuf d_tab, d_dst;
+        VLG_HIP_TRY(d_tab.alloc(sizeof tab));
+        VLG_HIP_TRY(hipMemcpy(d_tab.p, &tab, sizeof tab, hipMemcpyHostToDevice));
+        VLG_HIP_TRY(d_dst.alloc(words * 8));
+        uint32_t grid = (uint32_t)std::min<uint64_t>((words + 255) / 256, 16384);
+        hipLaunchKernelGGL(unpack_kernel, dim3(grid), dim3(256), 0, nullptr, idx->view.blocks, d_dst.as<uint64_t>(), words,
+                           h.wt_bits, d_tab.as<InnerTable>());
+        VLG_HIP_TRY(hipGetLastError());
+        VLG_HIP_TRY(hipMemcpy(bv.data(), d_dst.p, words * 8, hipMemcpyDeviceToHost));
+        if (out->bv_words) memcpy(out->bv_words, bv.data(), words * 8);
+    }
+    if (out->nodes) {
+        // bv_pos_rank of inner nodes = rank1(bv_pos) over the concatenated bit-vector (wt_helper.hpp:243-250)
+        std::vector<vlg_wt_node> nodes = t.nodes;
+        std::vector<uint32_t> order;
+        for (uint32_t v = 0; v < t.n_nodes; ++v) if (nodes[v].child[0] != 0xFFFF) order.push_back(v);
+        uint64_t cum = 0, pos = 0;
+        for (uint32_t v : order) {                       // inner nodes are in increasing bv_pos order
+            uint64_t target = nodes[v].bv_pos;
+            while (pos < target) {
+                uint64_t w = pos >> 6, o = pos & 63;
+                uint64_t take = std::min<uint64_t>(64 - o, target - pos);
+                uint64_t m = take == 64 ? ~0ull : (((1ull << take) - 1) << o);
+                cum += (uint64_t)__builtin_popcountll(bv[w] & m);
+                pos += take;
+            }
+            nodes[v].bv_pos_rank = cum;
+        }
+        memcpy(out->nodes, nodes.data(), nodes.size() * sizeof(vlg_wt_node));
+    }
+    if (out->sa_samples) {
+        if (h.sample_bytes == 4) {
+            std::vector<uint32_t> s32(h.n_samples);
+            VLG_HIP_TRY(hipMemcpy(s32.data(), b + h.off_samples, h.n_samples * 4, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < h.n_samples; ++i) out->sa_samples[i] = s32[i];
+        } else {
+            VLG_HIP_TRY(hipMemcpy(out->sa_samples, b + h.off_samples, h.n_samples * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* info)
+{
+    if (!idx || !info) return fail(VLG_E_INVALID, "null argument");
+    const BlobHeader& h = idx->hdr;
+    info->n = h.n;
+    info->sigma = h.sigma;
+    info->sa_sample_dens = h.dens;
+    info->n_nodes = h.n_nodes;
+    info->max_code_len = h.max_code_len;
+    info->wt_bits = h.wt_bits;
+    info->n_blocks = h.n_blocks;
+    info->n_samples = h.n_samples;
+    info->hbm_bytes = h.total_bytes;
+    info->pos_bytes = h.sample_bytes;
+    info->reserved = 0;
+    return VLG_OK;
+}
+
+extern "C" void vlg_index_destroy(vlg_index* idx)
+{
+    if (!idx) return;
+    if (idx->d_blob && idx->owns_blob) (void)hipFree(idx->d_blob);
+    delete idx;
+}
+
+extern "C" vlg_status vlg_index_blob_bytes(const vlg_index* idx, uint64_t* bytes)
+{
+    if (!idx || !bytes) return fail(VLG_E_INVALID, "null argument");
+    *bytes = idx->hdr.total_bytes;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_index_blob_export(const vlg_index* idx, void* d_blob, uint64_t bytes, void* stream)
+{
+    if (!idx || !d_blob) return fail(VLG_E_INVALID, "null argument");
+    if (bytes < idx->hdr.total_bytes) return fail(VLG_E_INVALID, "blob buffer too small");
+    VLG_HIP_TRY(hipMemcpyAsync(d_blob, idx->d_blob, idx->hdr.total_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    VLG_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_index_attach_blob(const void* d_blob, uint64_t bytes, vlg_index** out)
+{
+    if (!d_blob || !out) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    if (bytes < sizeof(BlobHeader)) return fail(VLG_E_INVALID, "blob too small");
+    vlg_index* idx = new vlg_index();
+    auto run = [&]() -> vlg_status {
+        VLG_HIP_TRY(hipMemcpy(&idx->hdr, d_blob, sizeof(BlobHeader), hipMemcpyDeviceToHost));
+        const BlobHeader& h = idx->hdr;
+        if (h.magic != kBlobMagic || h.total_bytes > bytes || h.n_nodes > kMaxNodes || h.sigma > 256)
+            return fail(VLG_E_INVALID, "not a VLG index blob");
+        idx->d_blob = const_cast<void*>(d_blob);
+        idx->owns_blob = false;
+        bind_view(idx);
+        // rebuild the host-side tree copy from the tables stored in the blob
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(d_blob);
+        std::vector<uint64_t> Cc(h.sigma + 1, 0);
+        std::vector<vlg_wt_node> nodes(h.n_nodes ? h.n_nodes : 1);
+        uint8_t c2c[256];
+        VLG_HIP_TRY(hipMemcpy(Cc.data(), b + h.off_C, (h.sigma + 1) * 8, hipMemcpyDeviceToHost));
+        VLG_HIP_TRY(hipMemcpy(c2c, b + h.off_c2c, 256, hipMemcpyDeviceToHost));
+        if (h.n_nodes) VLG_HIP_TRY(hipMemcpy(nodes.data(), b + h.off_refnodes, h.n_nodes * sizeof(vlg_wt_node), hipMemcpyDeviceToHost));
+        HostTree t2;
+        vlg_status st = tree_from_nodes(nodes.data(), h.n_nodes, h.wt_bits, c2c, Cc.data(), h.sigma, t2);
+        if (st) return st;
+        idx->tree = t2;
+        return VLG_OK;
+    };
+    vlg_status st = run();
+    if (st) { delete idx; return st; }
+    *out = idx;
+    return VLG_OK;
+}
+
+// =============================================================================================
+// On-device builder.
+// =============================================================================================
+namespace {
+
+__global__ void count_zero_kernel(const uint8_t* __restrict__ text, uint64_t n_text, unsigned long long* __restrict__ zeros)
+{
+    unsigned long long local = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_text; i += (uint64_t)gridDim.x * blockDim.x)
+        local += text[i] == 0;
+    if (local) atomicAdd(zeros, local);
+}
+
+// T' = text + 0 sentinel (construct.hpp:47-52); key = first 8 bytes of suffix i, big-endian.
+__global__ void sa_init_keys(const uint8_t* __restrict__ text, uint64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t k = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t p = i + j;
+            uint64_t c = (p + 1 < n) ? text[p] : 0;      // position n-1 is the sentinel
+            k = (k << 8) | c;
+        }
+        keys[i] = k;
+        vals[i] = (uint32_t)i;
+    }
+}
+
+// head[j] = j if sorted key j starts a new group else 0;  *n_groups += #group heads
+__global__ void sa_group_heads(const uint64_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ head,
+                               unsigned long long* __restrict__ n_groups)
+{
+    unsigned long long local = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        bool h = (j == 0) || keys[j] != keys[j - 1];
+        head[j] = h ? (uint32_t)j : 0u;
+        local += h;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_groups, local);
+}
+
+__global__ void sa_scatter_rank(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ head, uint64_t n,
+                                uint32_t* __restrict__ rank_of)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
+        rank_of[sa[j]] = head[j];
+}
+
+__global__ void sa_next_keys(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ rank_of, uint64_t n, uint64_t h,
+                             uint32_t shift, uint64_t* __restrict__ keys)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s = sa[j];
+        uint64_t r1 = rank_of[s];
+        uint64_t r2 = (s + h < n) ? (uint64_t)rank_of[s + h] + 1 : 0;
+        keys[j] = (r1 << shift) | r2;
+    }
+}
+
+// bwt[j] = T'[SA[j]-1] (construct_bwt.hpp:71-75); also the symbol histogram
+__global__ void bwt_kernel(const uint8_t* __restrict__ text, const uint32_t* __restrict__ sa, uint64_t n,
+                           uint8_t* __restrict__ bwt, unsigned long long* __restrict__ hist)
+{
+    __shared__ unsigned int h[256];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t s = sa[j];
+        uint8_t c = s ? text[s - 1] : 0;
+        bwt[j] = c;
+        atomicAdd(&h[c], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+__global__ void sample_kernel(const uint32_t* __restrict__ sa, uint64_t n_samples, uint32_t dens, void* __restrict__ out,
+                              uint32_t sample_bytes)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_samples; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = sa[j * dens];                          // csa_sampling_strategy.hpp:92-98
+        if (sample_bytes == 4) reinterpret_cast<uint32_t*>(out)[j] = v;
+        else reinterpret_cast<uint64_t*>(out)[j] = v;
+    }
+}
+
+struct LevelTables {                 // per-symbol lookup for one depth of the wavelet tree
+    uint16_t key_next[256];          // node id of the ancestor at depth d+1 if the code is longer, else 511 (dead)
+    uint8_t bit[256];                // code bit at depth d
+    uint32_t inner_of[256];          // index into InnerTable of the depth-d ancestor (valid when alive at d)
+};
+
+// keys for the stable partition that produces the arrangement of depth d+1 from depth d
+__global__ void wt_keys_kernel(const uint8_t* __restrict__ syms, uint64_t count, const LevelTables* __restrict__ lt,
+                               uint16_t* __restrict__ keys)
+{
+    __shared__ uint16_t kn[256];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) kn[i] = lt->key_next[i];
+    __syncthreads();
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x)
+        keys[j] = kn[syms[j]];
+}
+
+// Emit the data words of every block of every inner node at depth d from the depth-d arrangement
+// (symbols grouped by node in BFS order, BWT order inside a node).  One thread per u32 data word.
+__global__ void wt_emit_kernel(const uint8_t* __restrict__ syms, Block* __restrict__ blocks, const InnerTable* __restrict__ tab,
+                               const LevelTables* __restrict__ lt, uint32_t first_inner, uint32_t n_inner_at_depth,
+                               uint64_t first_block, uint64_t n_blocks_at_depth, const uint64_t* __restrict__ arr_start)
+{
+    __shared__ InnerTable t;
+    __shared__ uint8_t bit[256];
+    for (uint32_t i = threadIdx.x; i < sizeof(InnerTable) / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tab)[i];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) bit[i] = lt->bit[i];
+    __syncthreads();
+    (void)n_inner_at_depth;
+    uint64_t total = n_blocks_at_depth * 8;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t blk = (uint32_t)(first_block + (g >> 3)), w = (uint32_t)(g & 7);
+        if (w == 7) continue;
+        uint32_t k = find_inner_by_block(t, blk);
+        uint64_t rel = (uint64_t)(blk - t.base[k]) * kBlockBits + 32u * w;
+        uint32_t val = 0;
+        if (rel < t.size[k]) {
+            uint64_t left = t.size[k] - rel;
+            uint32_t m = left < 32 ? (uint32_t)left : 32u;
+            const uint8_t* s = syms + arr_start[k - first_inner] + rel;
+            for (uint32_t j = 0; j < m; ++j) val |= (uint32_t)bit[s[j]] << j;
+        }
+        blocks[blk].w[w] = val;
+    }
+}
+
+template <class K, class V>
+vlg_status sort_pairs(DevBuf& temp, size_t& temp_cap, K* kin, K* kout, V* vin, V* vout, uint64_t n, unsigned b0, unsigned b1,
+                      hipStream_t stream)
+{
+    size_t tb = 0;
+    VLG_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, n, b0, b1, stream));
+    if (tb > temp_cap) {
+        if (temp.p) { (void)hipFree(temp.p); temp.p = nullptr; }
+        VLG_HIP_TRY(temp.alloc(tb));
+        temp_cap = tb;
+    }
+    VLG_HIP_TRY(rocprim::radix_sort_pairs(temp.p, tb, kin, kout, vin, vout, n, b0, b1, stream));
+    return VLG_OK;
+}
+
+inline uint32_t grid_for(uint64_t n) { return (uint32_t)std::min<uint64_t>((n + 255) / 256, 16384); }
+
+vlg_status build_on_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens, hipStream_t stream, vlg_index** out)
+{
+    const uint64_t n = n_text + 1;
+    if (n > 0xFFFFFFF0ull) return fail(VLG_E_UNSUPPORTED, "device builder handles texts shorter than 2^32-16 bytes in this version");
+    vlg_index* idx = new vlg_index();
+    auto run = [&]() -> vlg_status {
+        DevBuf keys_a, keys_b, sa_a, sa_b, rank_of, head, temp, counter, bwt;
+        size_t temp_cap = 0;
+        VLG_HIP_TRY(keys_a.alloc(n * 8));
+        VLG_HIP_TRY(keys_b.alloc(n * 8));
+        VLG_HIP_TRY(sa_a.alloc(n * 4));
+        VLG_HIP_TRY(sa_b.alloc(n * 4));
+        VLG_HIP_TRY(rank_of.alloc(n * 4));
+        VLG_HIP_TRY(head.alloc(n * 4));
+        VLG_HIP_TRY(counter.alloc(8 + 256 * 8));
+        unsigned long long* d_groups = counter.as<unsigned long long>();
+        unsigned long long* d_hist = d_groups + 1;
+        const uint32_t g = grid_for(n);
+        {   // a zero byte in the text is a std::logic_error in the reference (construct.hpp:36-45)
+            VLG_HIP_TRY(hipMemsetAsync(d_groups, 0, 8, stream));
+            hipLaunchKernelGGL(count_zero_kernel, dim3(std::min<uint32_t>(g, 4096)), dim3(256), 0, stream, d_text, n_text, d_groups);
+            unsigned long long zeros = 0;
+            VLG_HIP_TRY(hipMemcpyAsync(&zeros, d_groups, 8, hipMemcpyDeviceToHost, stream));
+            VLG_HIP_TRY(hipStreamSynchronize(stream));
+            if (zeros) return fail(VLG_E_ZERO_BYTE, "text contains a zero byte (sdsl::construct throws std::logic_error)");
+        }
+        // --- suffix array by prefix doubling (8 characters first, then h = 8, 16, ...) ------------
+        hipLaunchKernelGGL(sa_init_keys, dim3(g), dim3(256), 0, stream, d_text, n, keys_a.as<uint64_t>(), sa_a.as<uint32_t>());
+        VLG_HIP_TRY(hipGetLastError());
+        if (vlg_status st = sort_pairs(temp, temp_cap, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), sa_a.as<uint32_t>(),
+                                       sa_b.as<uint32_t>(), n, 0, 64, stream)) return st;
+        uint64_t* keys_sorted = keys_b.as<uint64_t>();
+        uint64_t* keys_other = keys_a.as<uint64_t>();
+        uint32_t* sa_cur = sa_b.as<uint32_t>();
+        uint32_t* sa_other = sa_a.as<uint32_t>();
+        const uint32_t shift = bit_width64(n);            // r2 <= n needs bit_width(n) bits
+        for (uint64_t h = 8;; h <<= 1) {
+            VLG_HIP_TRY(hipMemsetAsync(d_groups, 0, 8, stream));
+            hipLaunchKernelGGL(sa_group_heads, dim3(g), dim3(256), 0, stream, keys_sorted, n, head.as<uint32_t>(), d_groups);
+            VLG_HIP_TRY(hipGetLastError());
+            unsigned long long groups = 0;
+            VLG_HIP_TRY(hipMemcpyAsync(&groups, d_groups, 8, hipMemcpyDeviceToHost, stream));
+            VLG_HIP_TRY(hipStreamSynchronize(stream));
+            if (groups == n) break;
+            if (h > 2 * n) return fail(VLG_E_INTERNAL, "suffix sort did not converge");
+            size_t tb = 0;
+            VLG_HIP_TRY(rocprim::inclusive_scan(nullptr, tb, head.as<uint32_t>(), head.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), stream));
+            if (tb > temp_cap) { if (temp.p) { (void)hipFree(temp.p); temp.p = nullptr; } VLG_HIP_TRY(temp.alloc(tb)); temp_cap = tb; }
+            VLG_HIP_TRY(rocprim::inclusive_scan(temp.p, tb, head.as<uint32_t>(), head.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), stream));
+            hipLaunchKernelGGL(sa_scatter_rank, dim3(g), dim3(256), 0, stream, sa_cur, head.as<uint32_t>(), n, rank_of.as<uint32_t>());
+            hipLaunchKernelGGL(sa_next_keys, dim3(g), dim3(256), 0, stream, sa_cur, rank_of.as<uint32_t>(), n, h, shift, keys_other);
+            VLG_HIP_TRY(hipGetLastError());
+            if (vlg_status st = sort_pairs(temp, temp_cap, keys_other, keys_sorted, sa_cur, sa_other, n, 0, 2 * shift, stream)) return st;
+            std::swap(sa_cur, sa_other);                   // keys_sorted now holds the sorted keys again
+        }
+        // free the big sort buffers we no longer need
+        (void)hipFree(keys_a.p); keys_a.p = nullptr;
+        (void)hipFree(keys_b.p); keys_b.p = nullptr;
+        (void)hipFree(rank_of.p); rank_of.p = nullptr;
+        (void)hipFree(head.p); head.p = nullptr;
+        // --- BWT + alphabet ------------------------------------------------------------------------
+        VLG_HIP_TRY(bwt.alloc(n));
+        VLG_HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * 8, stream));
+        hipLaunchKernelGGL(bwt_kernel, dim3(std::min<uint32_t>(g, 4096)), dim3(256), 0, stream, d_text, sa_cur, n, bwt.as<uint8_t>(), d_hist);
+        VLG_HIP_TRY(hipGetLastError());
+        uint64_t counts[256];
+        VLG_HIP_TRY(hipMemcpyAsync(counts, d_hist, sizeof counts, hipMemcpyDeviceToHost, stream));
+        VLG_HIP_TRY(hipStreamSynchronize(stream));
+        if (counts[0] != 1) return fail(VLG_E_ZERO_BYTE, "text contains a zero byte (sdsl::construct throws std::logic_error)");
+        if (vlg_status st = tree_from_counts(counts, idx->tree)) return st;
+        if (vlg_status st = alloc_blob(idx, n, dens, stream)) return st;
+        const BlobHeader& hd = idx->hdr;
+        uint8_t* blob = reinterpret_cast<uint8_t*>(idx->d_blob);
+        // --- SA samples ----------------------------------------------------------------------------
+        hipLaunchKernelGGL(sample_kernel, dim3(grid_for(hd.n_samples)), dim3(256), 0, stream, sa_cur, hd.n_samples, dens,
+                           blob + hd.off_samples, hd.sample_bytes);
+        VLG_HIP_TRY(hipGetLastError());
+        VLG_HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(sa_a.p); sa_a.p = nullptr;
+        (void)hipFree(sa_b.p); sa_b.p = nullptr;
+        // --- wavelet tree, one depth at a time -------------------------------------------------------
+        const HostTree& t = idx->tree;
+        if (hd.n_blocks) {
+            InnerTable tab = make_inner_table(t);
+            DevBuf d_tab, d_lt, d_arr, syms_b, keys16_a, keys16_b;
+            VLG_HIP_TRY(d_tab.alloc(sizeof tab));
+            VLG_HIP_TRY(hipMemcpy(d_tab.p, &tab, sizeof tab, hipMemcpyHostToDevice));
+            VLG_HIP_TRY(d_lt.alloc(sizeof(LevelTables)));
+            VLG_HIP_TRY(d_arr.alloc(256 * 8));
+            VLG_HIP_TRY(syms_b.alloc(n));
+            VLG_HIP_TRY(keys16_a.alloc(n * 2));
+            VLG_HIP_TRY(keys16_b.alloc(n * 2));
+            uint8_t* cur = bwt.as<uint8_t>();
+            uint8_t* other = syms_b.as<uint8_t>();
+            uint64_t alive = n;                              // symbols whose code is longer than d
+            Block* blocks = const_cast<Block*>(idx->view.blocks);
+            for (uint32_t d = 0; d < t.max_code_len; ++d) {
+                // inner nodes of this depth are consecutive in BFS order
+                uint32_t first_inner = 0, n_inner = 0;
+                for (uint32_t k = 0; k < tab.count; ++k)
+                    if (tab.depth[k] == d) { if (!n_inner) first_inner = k; ++n_inner; }
+                if (!n_inner) break;
+                LevelTables lt;
+                memset(&lt, 0, sizeof lt);
+                uint64_t alive_next = 0;
+                for (uint32_t c = 0; c < 256; ++c) {
+                    lt.key_next[c] = 511;
+                    if (t.c_to_leaf[c] == 0xFFFF) continue;
+                    uint32_t len = (uint32_t)(t.paths[c] >> 56);
+                    if (len <= d) continue;
+                    lt.bit[c] = (uint8_t)((t.paths[c] >> d) & 1);
+                    if (len > d + 1) {
+                        uint32_t v = 0;
+                        for (uint32_t l = 0; l <= d; ++l) v = t.nodes[v].child[(t.paths[c] >> l) & 1];
+                        lt.key_next[c] = (uint16_t)v;
+                        uint32_t cc = t.char2comp[c];
+                        alive_next += t.C[cc + 1] - t.C[cc];
+                    }
+                }
+                std::vector<uint64_t> arr_start(n_inner);
+                uint64_t acc = 0, first_block = tab.base[first_inner], last_block = 0;
+                for (uint32_t k = 0; k < n_inner; ++k) {
+                    arr_start[k] = acc;
+                    acc += tab.size[first_inner + k];
+                    last_block = (uint64_t)tab.base[first_inner + k] + tab.size[first_inner + k] / kBlockBits + 1;
+                }
+                if (acc != alive) return fail(VLG_E_INTERNAL, "wavelet tree level size mismatch");
+                VLG_HIP_TRY(hipMemcpyAsync(d_lt.p, &lt, sizeof lt, hipMemcpyHostToDevice, stream));
+                VLG_HIP_TRY(hipMemcpyAsync(d_arr.p, arr_start.data(), n_inner * 8, hipMemcpyHostToDevice, stream));
+                uint64_t nb = last_block - first_block;
+                hipLaunchKernelGGL(wt_emit_kernel, dim3(grid_for(nb * 8)), dim3(256), 0, stream, cur, blocks, d_tab.as<InnerTable>(),
+                                   d_lt.as<LevelTables>(), first_inner, n_inner, first_block, nb, d_arr.as<uint64_t>());
+                VLG_HIP_TRY(hipGetLastError());
+                if (alive_next) {
+                    hipLaunchKernelGGL(wt_keys_kernel, dim3(grid_for(alive)), dim3(256), 0, stream, cur, alive, d_lt.as<LevelTables>(),
+                                       keys16_a.as<uint16_t>());
+                    VLG_HIP_TRY(hipGetLastError());
+                    if (vlg_status st = sort_pairs(temp, temp_cap, keys16_a.as<uint16_t>(), keys16_b.as<uint16_t>(), cur, other,
+                                                   alive, 0, 9, stream)) return st;
+                    std::swap(cur, other);
+                }
+                VLG_HIP_TRY(hipStreamSynchronize(stream));   // lt / arr_start are reused next iteration
+                alive = alive_next;
+                if (!alive) break;
+            }
+            if (vlg_status st = fill_block_counts(idx, d_tab.as<InnerTable>(), stream)) return st;
+        }
+        VLG_HIP_TRY(hipStreamSynchronize(stream));
+        return VLG_OK;
+    };
+    vlg_status st = run();
+    if (st) { vlg_index_destroy(idx); return st; }
+    *out = idx;
+    return VLG_OK;
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_index_build_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens, void* stream, vlg_index** out)
+{
+    if (!out || (n_text && !d_text)) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    if (vlg_status st = check_device()) return st;
+    if (dens == 0) dens = 32;
+    return build_on_device(d_text, n_text, dens, (hipStream_t)stream, out);
+}
+
+extern "C" vlg_status vlg_index_build(const uint8_t* h_text, uint64_t n_text, uint32_t dens, vlg_index** out)
+{
+    if (!out || (n_text && !h_text)) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    if (vlg_status st = check_device()) return st;
+    DevBuf d;
+    VLG_HIP_TRY(d.alloc(n_text + 16));
+    if (n_text) VLG_HIP_TRY(hipMemcpy(d.p, h_text, n_text, hipMemcpyHostToDevice));
+    return vlg_index_build_device(d.as<uint8_t>(), n_text, dens, nullptr, out);
+}

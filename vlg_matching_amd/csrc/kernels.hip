@@ -1,0 +1,448 @@
+// K1 batched bit-rank, K2 wavelet-tree rank / backward search, K3 locate (LF iteration).
+#include <algorithm>
+#include <cstring>
+#include <string.h>
+#include "common.hpp"
+#include "device_rank.hpp"
+#include "kernels.hpp"
+
+using namespace vlg;
+
+// =============================================================================================
+// K1: rank_support_v<1,1>::rank on a plain bit-vector (include/sdsl/rank_support_v.hpp:114-124)
+// =============================================================================================
+struct vlg_bitvector {
+    Block* d_blocks = nullptr;
+    uint64_t nbits = 0;
+    uint64_t n_blocks = 0;
+};
+
+namespace {
+
+// host words -> blocks. One thread per block: 7 data words + running count comes from a scan.
+__global__ void bv_pack_kernel(const uint64_t* __restrict__ src, uint64_t src_words, uint64_t nbits, Block* __restrict__ blocks,
+                               uint64_t n_blocks, uint32_t* __restrict__ pops)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t pc = 0;
+        Block B;
+#pragma unroll
+        for (uint32_t w = 0; w < 7; ++w) {
+            uint64_t bit = b * kBlockBits + 32u * w;
+            uint32_t val = 0;
+            if (bit < nbits) {
+                uint64_t wi = bit >> 6;
+                uint32_t s = (uint32_t)(bit & 63);
+                uint64_t lo = src[wi] >> s;
+                if (s > 32 && wi + 1 < src_words) lo |= src[wi + 1] << (64 - s);
+                val = (uint32_t)lo;
+                uint64_t left = nbits - bit;
+                if (left < 32) val &= (1u << left) - 1u;
+            }
+            B.w[w] = val;
+            pc += __popc(val);
+        }
+        B.cnt = 0;
+        blocks[b] = B;
+        pops[b] = pc;
+    }
+}
+
+// single-workgroup-per-tile scan is plenty for a creation-time pass: serial over tiles of 1024 blocks
+__global__ void bv_count_kernel(Block* __restrict__ blocks, const uint32_t* __restrict__ pops, uint64_t n_blocks)
+{
+    // one workgroup, chunked inclusive scan with a running carry
+    __shared__ uint32_t s[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n_blocks; base += 1024) {
+        uint64_t i = base + threadIdx.x;
+        uint32_t v = i < n_blocks ? pops[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            uint32_t t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) blocks[i].cnt = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) bitrank_kernel(const Block* __restrict__ blocks, const uint64_t* __restrict__ idx,
+                                                       uint64_t* __restrict__ out, uint64_t count)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x)
+        out[j] = node_rank1(blocks, 0, idx[j]);
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_bitvector_create(const uint64_t* h_words, uint64_t nbits, vlg_bitvector** out)
+{
+    if (!out || (nbits && !h_words)) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VLG_E_NO_DEVICE, "no HIP device available");
+    if (nbits >= (1ull << 32)) return fail(VLG_E_UNSUPPORTED, "stand-alone bit-vectors are limited to 2^32-1 bits (32-bit block counts)");
+    vlg_bitvector* bv = new vlg_bitvector();
+    bv->nbits = nbits;
+    bv->n_blocks = nbits / kBlockBits + 1;
+    uint64_t words = (nbits + 63) / 64;
+    uint64_t* d_src = nullptr;
+    uint32_t* d_pops = nullptr;
+    auto run = [&]() -> vlg_status {
+        VLG_HIP_TRY(hipMalloc((void**)&bv->d_blocks, bv->n_blocks * sizeof(Block)));
+        VLG_HIP_TRY(hipMalloc((void**)&d_src, words * 8 + 8));
+        VLG_HIP_TRY(hipMalloc((void**)&d_pops, bv->n_blocks * 4));
+        if (words) VLG_HIP_TRY(hipMemcpy(d_src, h_words, words * 8, hipMemcpyHostToDevice));
+        uint32_t grid = (uint32_t)std::min<uint64_t>((bv->n_blocks + 255) / 256, 8192);
+        hipLaunchKernelGGL(bv_pack_kernel, dim3(grid), dim3(256), 0, nullptr, d_src, words, nbits, bv->d_blocks, bv->n_blocks, d_pops);
+        hipLaunchKernelGGL(bv_count_kernel, dim3(1), dim3(1024), 0, nullptr, bv->d_blocks, d_pops, bv->n_blocks);
+        VLG_HIP_TRY(hipGetLastError());
+        VLG_HIP_TRY(hipDeviceSynchronize());
+        return VLG_OK;
+    };
+    vlg_status st = run();
+    if (d_src) (void)hipFree(d_src);
+    if (d_pops) (void)hipFree(d_pops);
+    if (st) { vlg_bitvector_destroy(bv); return st; }
+    *out = bv;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_bitvector_rank_batch(const vlg_bitvector* bv, const uint64_t* d_idx, uint64_t* d_out, uint64_t count, void* stream)
+{
+    if (!bv || (count && (!d_idx || !d_out))) return fail(VLG_E_INVALID, "null argument");
+    if (!count) return VLG_OK;
+    uint32_t grid = (uint32_t)std::min<uint64_t>((count + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(bitrank_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bv->d_blocks, d_idx, d_out, count);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+
+extern "C" uint64_t vlg_bitvector_hbm_bytes(const vlg_bitvector* bv) { return bv ? bv->n_blocks * sizeof(Block) : 0; }
+
+extern "C" void vlg_bitvector_destroy(vlg_bitvector* bv)
+{
+    if (!bv) return;
+    if (bv->d_blocks) (void)hipFree(bv->d_blocks);
+    delete bv;
+}
+
+// =============================================================================================
+// K2: wt_pc::rank (include/sdsl/wt_pc.hpp:350-373) and backward_search
+//     (include/sdsl/suffix_array_algorithm.hpp:250-278, 305-326)
+// =============================================================================================
+namespace vlg {
+
+// #c in BWT[0,i): walk the code of c from the root; one super-block read per level.
+__device__ __forceinline__ uint64_t wt_rank_dev(const IndexView& iv, const TreeLds& s, uint64_t path, uint64_t i, uint32_t& levels)
+{
+    uint32_t len = (uint32_t)(path >> 56);
+    if (len == 0) return (iv.sigma == 1) ? i : 0;       // sigma==1: wt_pc.hpp:355-357 (the only symbol has an empty code)
+    uint64_t res = i;
+    uint32_t v = 0;
+    for (uint32_t l = 0; l < len && res; ++l, path >>= 1) {       // "and result": wt_pc.hpp:361
+        uint32_t bit = (uint32_t)(path & 1);
+        uint64_t r1 = node_rank1(iv.blocks, s.nodes[v].base, res);
+        ++levels;
+        res = bit ? r1 : res - r1;
+        v = s.nodes[v].child[bit] & ~kLeafFlag;
+    }
+    return res;
+}
+
+}  // namespace vlg
+
+namespace {
+
+__global__ void __launch_bounds__(256) wt_rank_kernel(IndexView iv, const uint64_t* __restrict__ pos, const uint8_t* __restrict__ sym,
+                                                      uint64_t* __restrict__ out, uint64_t count)
+{
+    __shared__ TreeLds s;
+    stage_tree(s, iv);
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint8_t c = sym[j];
+        uint64_t path = iv.paths[c];
+        uint32_t lv = 0;
+        bool present = (c == 0) || iv.char2comp[c] != 0;          // c_to_leaf valid  (wt_pc.hpp:352-354)
+        out[j] = present ? wt_rank_dev(iv, s, path, pos[j], lv) : 0;
+    }
+}
+
+// one lane per pattern; the two ranks of a step are independent loads
+__global__ void __launch_bounds__(256) backward_search_kernel(IndexView iv, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
+                                                              uint64_t n_pat, uint64_t* __restrict__ out_l, uint64_t* __restrict__ out_r,
+                                                              unsigned long long* __restrict__ stat_levels)
+{
+    __shared__ TreeLds s;
+    stage_tree(s, iv);
+    uint32_t levels = 0;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pat; p += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t b = off[p], e = off[p + 1];
+        uint64_t l = 0, r = iv.n - 1;
+        while (b < e && r + 1 - l > 0) {                          // suffix_array_algorithm.hpp:319
+            --e;
+            uint8_t c = blob[e];
+            uint32_t cc = iv.char2comp[c];
+            if (cc == 0 && c > 0) { l = 1; r = 0; }               // :263-265
+            else {
+                uint64_t c_begin = s.C[cc];
+                if (l == 0 && r + 1 == iv.n) { l = c_begin; r = s.C[cc + 1] - 1; }      // :268-270
+                else {
+                    uint64_t path = iv.paths[c];
+                    uint64_t nl = c_begin + wt_rank_dev(iv, s, path, l, levels);          // :272
+                    uint64_t nr = c_begin + wt_rank_dev(iv, s, path, r + 1, levels) - 1;  // :273
+                    l = nl; r = nr;
+                }
+            }
+        }
+        out_l[p] = l;
+        out_r[p] = r;
+    }
+    if (stat_levels) {
+        unsigned long long t = levels;
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+        if ((threadIdx.x & 63) == 0 && t) atomicAdd(stat_levels, t);
+    }
+}
+
+// =============================================================================================
+// K3: csa[i] = LF iteration to the next sampled SA index (include/sdsl/csa_wt.hpp:335-348,
+//     LF = C[c] + inverse_select(i): suffix_array_helper.hpp:336-349, wt_pc.hpp:385-402).
+//
+// io[t] holds the SA index on entry and the text position on exit (in place).
+// Work is dealt to lanes, not to waves: a wave owns a contiguous slice of io[] and every lane that
+// finishes an occurrence immediately pulls the next one of the slice (ballot + prefix popcount), so
+// all 64 lanes issue one 32-byte super-block read per iteration whatever the (geometric) number
+// of LF steps and whatever the code lengths.
+// =============================================================================================
+template <typename pos_t>
+__global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __restrict__ io, uint64_t total, uint32_t per_wave,
+                                                     unsigned long long* __restrict__ stats /* [2]: lf steps, levels */)
+{
+    __shared__ TreeLds s;
+    stage_tree(s, iv);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint64_t next = wave * per_wave;                       // wave-uniform cursor into the slice
+    const uint64_t slice_end = next + per_wave < total ? next + per_wave : total;
+    const uint32_t dens = iv.dens;
+    const bool pow2 = (dens & (dens - 1)) == 0;
+    const uint32_t dmask = dens - 1;
+    const uint32_t dshift = 31 - __clz(dens);
+    const pos_t* samples = reinterpret_cast<const pos_t*>(iv.samples);
+
+    uint64_t t = 0;          // slot being worked on
+    uint64_t i = 0;          // SA index at the root, node-relative index below it
+    uint32_t v = 0, off = 0;
+    bool active = false, need = true;
+    uint32_t n_lf = 0, n_lv = 0;
+    for (;;) {
+        // ---- refill ---------------------------------------------------------------------------
+        unsigned long long m = __ballot(need);
+        if (m) {
+            uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
+            if (need) {
+                uint64_t cand = next + before;
+                if (cand < slice_end) { t = cand; i = io[cand]; v = 0; off = 0; active = true; }
+                else active = false;
+                need = false;
+            }
+            next += __popcll(m);
+        }
+        if (!__any(active)) break;
+        if (active) {
+            bool sampled = pow2 ? ((i & dmask) == 0) : (i % dens == 0);
+            if (v == 0 && sampled) {                       // csa_sampling_strategy.hpp:102-111
+                uint64_t q = pow2 ? (i >> dshift) : (i / dens);
+                uint64_t r = (uint64_t)samples[q] + off;
+                if (r >= iv.n) r -= iv.n;                  // csa_wt.hpp:343-347
+                io[t] = (pos_t)r;
+                need = true;
+                active = false;
+            } else if (iv.sigma == 1) {                    // degenerate: only the sentinel exists
+                i = 0; ++off;
+            } else {
+                // one level of inverse_select: the bit and the rank come from the same block
+                const DNode nd = s.nodes[v];
+                uint32_t blk, o;
+                split224(i, blk, o);
+                BlockRegs R = load_block(iv.blocks, nd.base + blk);
+                uint32_t bit = block_bit(R, o);
+                uint64_t r1 = block_rank(R, o);
+                ++n_lv;
+                uint64_t ni = bit ? r1 : i - r1;
+                uint32_t ch = nd.child[bit];
+                if (ch & kLeafFlag) {                      // reached the symbol: LF = C[c] + rank
+                    i = s.C[ch & ~kLeafFlag] + ni;
+                    v = 0;
+                    ++off;
+                    ++n_lf;
+                } else {
+                    i = ni;
+                    v = ch;
+                }
+            }
+        }
+    }
+    if (stats) {
+        unsigned long long a = n_lf, b = n_lv;
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+        if (lane == 0) { if (a) atomicAdd(&stats[0], a); if (b) atomicAdd(&stats[1], b); }
+    }
+}
+
+// io[off[p] + j] = l[p] + j : the SA indices of every occurrence (input of locate_kernel), plus seg[]
+template <typename pos_t>
+__global__ void expand_kernel(const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t total,
+                              pos_t* __restrict__ io, uint32_t* __restrict__ seg)
+{
+    // tile of 256 consecutive slots per workgroup iteration; first lane finds the segment by binary search
+    __shared__ uint64_t s_first;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256; base < total; base += (uint64_t)gridDim.x * 256) {
+        if (threadIdx.x == 0) {
+            uint64_t lo = 0, hi = n_pat;                   // last p with out_off[p] <= base
+            while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (out_off[mid] <= base) lo = mid; else hi = mid; }
+            s_first = lo;
+        }
+        __syncthreads();
+        uint64_t t = base + threadIdx.x;
+        if (t < total) {
+            uint64_t p = s_first;
+            while (out_off[p + 1] <= t) ++p;               // empty segments are skipped too
+            io[t] = (pos_t)(l[p] + (t - out_off[p]));
+            if (seg) seg[t] = (uint32_t)p;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename pos_t>
+__global__ void widen_kernel(const pos_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t count)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) out[j] = in[j];
+}
+template <typename pos_t>
+__global__ void narrow_kernel(const uint64_t* __restrict__ in, pos_t* __restrict__ out, uint64_t count)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) out[j] = (pos_t)in[j];
+}
+
+inline uint32_t grid_for(uint64_t n, uint32_t cap = 16384) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, cap)); }
+
+}  // namespace
+
+namespace vlg {
+
+vlg_status launch_backward_search(const IndexView& iv, const uint8_t* d_blob, const uint64_t* d_off, uint64_t n_pat, uint64_t* d_l,
+                                  uint64_t* d_r, unsigned long long* d_stat_levels, hipStream_t stream)
+{
+    if (!n_pat) return VLG_OK;
+    hipLaunchKernelGGL(backward_search_kernel, dim3(grid_for(n_pat, 4096)), dim3(256), 0, stream, iv, d_blob, d_off, n_pat, d_l, d_r,
+                       d_stat_levels);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+
+template <typename pos_t>
+vlg_status launch_expand(const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total, pos_t* d_io, uint32_t* d_seg,
+                         hipStream_t stream)
+{
+    if (!total) return VLG_OK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(expand_kernel<pos_t>), dim3(grid_for(total, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
+                       total, d_io, d_seg);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+template vlg_status launch_expand<uint32_t>(const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint32_t*, uint32_t*, hipStream_t);
+template vlg_status launch_expand<uint64_t>(const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint64_t*, uint32_t*, hipStream_t);
+
+// Slices: enough waves to fill 256 CUs x 32 waves several times over, but slices long enough that the
+// drain tail (the slowest occurrence of a slice) stays a small fraction of the slice.
+template <typename pos_t>
+vlg_status launch_locate(const IndexView& iv, pos_t* d_io, uint64_t total, unsigned long long* d_stats, hipStream_t stream)
+{
+    if (!total) return VLG_OK;
+    const uint64_t target_waves = 256ull * 32 * 4;
+    uint64_t per_wave = (total + target_waves - 1) / target_waves;
+    per_wave = std::max<uint64_t>(per_wave, 64 * 16);
+    per_wave = std::min<uint64_t>(per_wave, 1u << 20);
+    uint64_t waves = (total + per_wave - 1) / per_wave;
+    uint64_t wgs = (waves + 3) / 4;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t>), dim3((uint32_t)wgs), dim3(256), 0, stream, iv, d_io, total,
+                       (uint32_t)per_wave, d_stats);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+template vlg_status launch_locate<uint32_t>(const IndexView&, uint32_t*, uint64_t, unsigned long long*, hipStream_t);
+template vlg_status launch_locate<uint64_t>(const IndexView&, uint64_t*, uint64_t, unsigned long long*, hipStream_t);
+
+}  // namespace vlg
+
+extern "C" vlg_status vlg_wt_rank_batch(const vlg_index* idx, const uint64_t* d_i, const uint8_t* d_c, uint64_t* d_out, uint64_t count,
+                                        void* stream)
+{
+    if (!idx || (count && (!d_i || !d_c || !d_out))) return fail(VLG_E_INVALID, "null argument");
+    if (!count) return VLG_OK;
+    hipLaunchKernelGGL(wt_rank_kernel, dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream, idx->view, d_i, d_c, d_out, count);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_backward_search_batch(const vlg_index* idx, const uint8_t* d_blob, const uint64_t* d_off, uint64_t n_patterns,
+                                                uint64_t* d_l, uint64_t* d_r, void* stream)
+{
+    if (!idx || (n_patterns && (!d_off || !d_l || !d_r))) return fail(VLG_E_INVALID, "null argument");
+    return launch_backward_search(idx->view, d_blob, d_off, n_patterns, d_l, d_r, nullptr, (hipStream_t)stream);
+}
+
+extern "C" vlg_status vlg_sa_batch(const vlg_index* idx, const uint64_t* d_i, uint64_t* d_out, uint64_t count, void* stream)
+{
+    if (!idx || (count && (!d_i || !d_out))) return fail(VLG_E_INVALID, "null argument");
+    if (!count) return VLG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (idx->hdr.sample_bytes == 8) {
+        if (d_out != d_i) VLG_HIP_TRY(hipMemcpyAsync(d_out, d_i, count * 8, hipMemcpyDeviceToDevice, st));
+        return launch_locate<uint64_t>(idx->view, d_out, count, nullptr, st);
+    }
+    uint32_t* tmp = nullptr;
+    VLG_HIP_TRY(hipMalloc((void**)&tmp, count * 4));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(narrow_kernel<uint32_t>), dim3(grid_for(count)), dim3(256), 0, st, d_i, tmp, count);
+    vlg_status s2 = launch_locate<uint32_t>(idx->view, tmp, count, nullptr, st);
+    if (!s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(widen_kernel<uint32_t>), dim3(grid_for(count)), dim3(256), 0, st, tmp, d_out, count);
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (s2) return s2;
+    VLG_HIP_TRY(e);
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_locate_batch(const vlg_index* idx, const uint64_t* d_l, const uint64_t* d_r, const uint64_t* d_out_off,
+                                       uint64_t n_patterns, uint64_t total, uint64_t* d_out, void* stream)
+{
+    (void)d_r;
+    if (!idx || (n_patterns && (!d_l || !d_out_off)) || (total && !d_out)) return fail(VLG_E_INVALID, "null argument");
+    if (!total) return VLG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (idx->hdr.sample_bytes == 8) {
+        if (vlg_status s = launch_expand<uint64_t>(d_l, d_out_off, n_patterns, total, d_out, nullptr, st)) return s;
+        return launch_locate<uint64_t>(idx->view, d_out, total, nullptr, st);
+    }
+    uint32_t* tmp = nullptr;
+    VLG_HIP_TRY(hipMalloc((void**)&tmp, total * 4));
+    vlg_status s2 = launch_expand<uint32_t>(d_l, d_out_off, n_patterns, total, tmp, nullptr, st);
+    if (!s2) s2 = launch_locate<uint32_t>(idx->view, tmp, total, nullptr, st);
+    if (!s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(widen_kernel<uint32_t>), dim3(grid_for(total)), dim3(256), 0, st, tmp, d_out, total);
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (s2) return s2;
+    VLG_HIP_TRY(e);
+    return VLG_OK;
+}

@@ -1,0 +1,796 @@
+// Query batches, workspace, the fused search (backward search -> locate -> sort -> join) and results.
+//
+// Join (K5).  The reference's merge join (benchmark/gapped-matching/include/index_sasearch.hpp:85-116;
+// semantics of vlg_iterator, include/sdsl/vlg_index.hpp:227-291) advances k monotone pointers one step
+// at a time.  Every step only ever raises one pointer to the least value a gap constraint forces, so a
+// match is the component-wise LEAST tuple (p_0 >= a, p_1, ..., p_{k-1}) that satisfies all constraints
+// lo_i <= L_i[p_i] - L_{i-1}[p_{i-1}] <= hi_i, and the next search restarts at the first p_0 with
+// L_0[p_0] >= L_{k-1}[p_{k-1}] + end_len.  That fixed-point view is data parallel:
+//   back to front, every element of list i learns whether a feasible chain to the last list starts at
+//   it, which element of list i+1 it links to (the first feasible one inside its window) and where the
+//   chain ends ("link pass", one binary search per element);  a reverse min-scan gives "nearest feasible
+//   element at or after j";  a per-query wavefront then hops along list 0 (window of 64 jump targets per
+//   load) emitting the non-overlapping matches in order;  a gather pass writes the tuples.
+#include <algorithm>
+#include <cstring>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "common.hpp"
+#include "kernels.hpp"
+#include <rocprim/rocprim.hpp>
+
+using namespace vlg;
+
+// =============================================================================================
+// Query batches
+// =============================================================================================
+struct vlg_queries {
+    uint64_t nq = 0, nsub = 0;
+    std::vector<uint64_t> qsub;      // [nq+1]
+    std::vector<uint64_t> suboff;    // [nsub+1]
+    std::vector<uint8_t> blob;
+    std::vector<uint64_t> lo, hi;    // [nsub]
+    std::vector<uint64_t> end_len;   // [nq]
+    uint32_t kmax = 0;
+    uint8_t* d_blob = nullptr;
+    uint64_t* d_suboff = nullptr;
+};
+
+namespace {
+
+// std::stoull on [s,e): optional blanks, optional sign, digits; trailing characters ignored
+bool parse_u64(const char* s, const char* e, uint64_t& out)
+{
+    while (s < e && (*s == ' ' || (*s >= 9 && *s <= 13))) ++s;
+    bool neg = false;
+    if (s < e && (*s == '+' || *s == '-')) { neg = *s == '-'; ++s; }
+    if (s >= e || *s < '0' || *s > '9') return false;
+    uint64_t v = 0;
+    while (s < e && *s >= '0' && *s <= '9') {
+        uint64_t d = (uint64_t)(*s - '0');
+        if (v > (0xFFFFFFFFFFFFFFFFull - d) / 10) return false;
+        v = v * 10 + d;
+        ++s;
+    }
+    out = neg ? (uint64_t)(0 - v) : v;
+    return true;
+}
+
+struct Parsed {
+    std::vector<std::pair<uint64_t, uint64_t>> sub;   // (offset, length) into the query text
+    std::vector<uint64_t> lo, hi;                     // per sub-pattern (entry 0 unused)
+    uint64_t end_len = 0;
+};
+
+// gapped_pattern_query (include/sdsl/vlg_index.hpp:54-105) / gapped_pattern (benchmark utils.hpp:25-70)
+vlg_status parse_one(const char* re, uint64_t len, int dialect, Parsed& out, std::string& why)
+{
+    std::vector<uint64_t> raw_lo(1, 0), raw_hi(1, 0);
+    uint64_t start = 0;
+    for (;;) {
+        uint64_t gp = std::string::npos;
+        for (uint64_t i = start; i + 1 < len; ++i) if (re[i] == '.' && re[i + 1] == '{') { gp = i; break; }
+        if (gp == std::string::npos) break;
+        if (out.sub.size() + 1 >= VLG_MAX_SUBPATTERNS) { why = "too many sub-patterns"; return VLG_E_INVALID; }
+        uint64_t ge = std::string::npos, comma = std::string::npos;
+        for (uint64_t i = gp; i < len; ++i) if (re[i] == '}') { ge = i; break; }
+        if (ge == std::string::npos) { why = "invalid gap description"; return VLG_E_PARSE; }
+        for (uint64_t i = gp; i <= ge; ++i) if (re[i] == ',') { comma = i; break; }
+        uint64_t a = 0, b = 0;
+        if (comma == std::string::npos || !parse_u64(re + gp + 2, re + comma, a) || !parse_u64(re + comma + 1, re + ge, b)) {
+            why = "invalid gap description";
+            return VLG_E_PARSE;
+        }
+        if (a > b) { why = "invalid gap description: min-gap > max-gap"; return VLG_E_PARSE; }           // vlg_index.hpp:92-94
+        out.sub.emplace_back(start, gp - start);
+        raw_lo.push_back(a);
+        raw_hi.push_back(b);
+        if (dialect == VLG_DIALECT_LIBRARY) {
+            if (ge + 1 == len || re[ge + 1] != '?') {                                                   // vlg_index.hpp:97-99
+                why = "invalid gap description: expected '?' (lazy semantics)";
+                return VLG_E_PARSE;
+            }
+            start = ge + 2;
+        } else {
+            start = ge + 1;
+        }
+    }
+    out.sub.emplace_back(start, len - start);
+    for (auto& s : out.sub) if (s.second == 0) { why = "empty sub-pattern"; return VLG_E_INVALID; }
+    size_t k = out.sub.size();
+    out.lo.assign(k, 0);
+    out.hi.assign(k, 0);
+    if (dialect == VLG_DIALECT_LIBRARY) {
+        for (size_t i = 1; i < k; ++i) {                                                                // vlg_index.hpp:95
+            out.lo[i] = raw_lo[i] + out.sub[i - 1].second;
+            out.hi[i] = raw_hi[i] + out.sub[i - 1].second;
+            if (out.hi[i] < raw_hi[i]) out.hi[i] = ~0ull;
+            if (out.lo[i] < raw_lo[i]) out.lo[i] = ~0ull;
+        }
+        out.end_len = out.sub[k - 1].second;                                                            // vlg_index.hpp:262,306
+    } else {
+        for (size_t i = 1; i < k; ++i) {                                                                // index_sasearch.hpp:68-69
+            out.lo[i] = raw_lo[1] + out.sub[0].second;
+            out.hi[i] = raw_hi[1] + out.sub[0].second;
+            if (out.hi[i] < raw_hi[1]) out.hi[i] = ~0ull;
+            if (out.lo[i] < raw_lo[1]) out.lo[i] = ~0ull;
+        }
+        out.end_len = out.sub[0].second;                                                                // index_sasearch.hpp:113
+    }
+    return VLG_OK;
+}
+
+vlg_status upload_queries(vlg_queries* q)
+{
+    q->kmax = 0;
+    for (uint64_t i = 0; i < q->nq; ++i) q->kmax = std::max<uint32_t>(q->kmax, (uint32_t)(q->qsub[i + 1] - q->qsub[i]));
+    VLG_HIP_TRY(hipMalloc((void**)&q->d_blob, q->blob.size() + 16));
+    VLG_HIP_TRY(hipMalloc((void**)&q->d_suboff, (q->nsub + 1) * 8));
+    if (!q->blob.empty()) VLG_HIP_TRY(hipMemcpy(q->d_blob, q->blob.data(), q->blob.size(), hipMemcpyHostToDevice));
+    VLG_HIP_TRY(hipMemcpy(q->d_suboff, q->suboff.data(), (q->nsub + 1) * 8, hipMemcpyHostToDevice));
+    return VLG_OK;
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_off, uint64_t n_queries, int dialect, int* h_status,
+                                        vlg_queries** out)
+{
+    if (!out || (n_queries && (!h_text || !h_off))) return fail(VLG_E_INVALID, "null argument");
+    if (dialect != VLG_DIALECT_LIBRARY && dialect != VLG_DIALECT_BENCHMARK) return fail(VLG_E_INVALID, "unknown dialect");
+    *out = nullptr;
+    vlg_queries* q = new vlg_queries();
+    q->nq = n_queries;
+    q->qsub.assign(1, 0);
+    q->suboff.assign(1, 0);
+    vlg_status first_err = VLG_OK;
+    std::string first_why;
+    for (uint64_t i = 0; i < n_queries; ++i) {
+        Parsed p;
+        std::string why;
+        const char* re = h_text + h_off[i];
+        vlg_status st = parse_one(re, h_off[i + 1] - h_off[i], dialect, p, why);
+        if (h_status) h_status[i] = st;
+        if (st) {
+            if (!first_err) { first_err = st; first_why = "query " + std::to_string(i) + ": " + why; }
+        } else {
+            for (size_t s = 0; s < p.sub.size(); ++s) {
+                q->blob.insert(q->blob.end(), re + p.sub[s].first, re + p.sub[s].first + p.sub[s].second);
+                q->suboff.push_back(q->blob.size());
+                q->lo.push_back(p.lo[s]);
+                q->hi.push_back(p.hi[s]);
+            }
+        }
+        q->qsub.push_back(q->suboff.size() - 1);     // a failed query keeps zero sub-patterns
+        q->end_len.push_back(st ? 0 : p.end_len);
+    }
+    q->nsub = q->suboff.size() - 1;
+    if (first_err && !h_status) { delete q; return fail(first_err, first_why); }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete q; return fail(VLG_E_NO_DEVICE, "no HIP device available"); }
+    if (vlg_status st = upload_queries(q)) { vlg_queries_destroy(q); return st; }
+    *out = q;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_queries_create(const uint8_t* h_blob, const uint64_t* h_suboff, const uint64_t* h_qsub, const uint64_t* h_lo,
+                                         const uint64_t* h_hi, const uint64_t* h_end_len, uint64_t n_queries, vlg_queries** out)
+{
+    if (!out || (n_queries && (!h_suboff || !h_qsub || !h_lo || !h_hi || !h_end_len))) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    vlg_queries* q = new vlg_queries();
+    q->nq = n_queries;
+    q->nsub = n_queries ? h_qsub[n_queries] : 0;
+    q->qsub.assign(h_qsub, h_qsub + n_queries + 1);
+    if (!n_queries) q->qsub.assign(1, 0);
+    q->suboff.assign(1, 0);
+    if (q->nsub) q->suboff.assign(h_suboff, h_suboff + q->nsub + 1);
+    for (uint64_t i = 0; i < n_queries; ++i)
+        if (q->qsub[i + 1] < q->qsub[i] || q->qsub[i + 1] - q->qsub[i] > VLG_MAX_SUBPATTERNS) { delete q; return fail(VLG_E_INVALID, "bad query offsets"); }
+    for (uint64_t s = 0; s < q->nsub; ++s)
+        if (q->suboff[s + 1] <= q->suboff[s]) { delete q; return fail(VLG_E_INVALID, "empty sub-pattern"); }
+    if (q->nsub && !h_blob) { delete q; return fail(VLG_E_INVALID, "null argument"); }
+    if (q->nsub) q->blob.assign(h_blob, h_blob + q->suboff[q->nsub]);
+    q->lo.assign(h_lo, h_lo + q->nsub);
+    q->hi.assign(h_hi, h_hi + q->nsub);
+    q->end_len.assign(h_end_len, h_end_len + n_queries);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete q; return fail(VLG_E_NO_DEVICE, "no HIP device available"); }
+    if (vlg_status st = upload_queries(q)) { vlg_queries_destroy(q); return st; }
+    *out = q;
+    return VLG_OK;
+}
+
+extern "C" uint64_t vlg_queries_count(const vlg_queries* q) { return q ? q->nq : 0; }
+extern "C" uint64_t vlg_queries_subpatterns(const vlg_queries* q) { return q ? q->nsub : 0; }
+extern "C" vlg_status vlg_queries_k(const vlg_queries* q, uint32_t* h_k)
+{
+    if (!q || (q->nq && !h_k)) return fail(VLG_E_INVALID, "null argument");
+    for (uint64_t i = 0; i < q->nq; ++i) h_k[i] = (uint32_t)(q->qsub[i + 1] - q->qsub[i]);
+    return VLG_OK;
+}
+extern "C" void vlg_queries_destroy(vlg_queries* q)
+{
+    if (!q) return;
+    if (q->d_blob) (void)hipFree(q->d_blob);
+    if (q->d_suboff) (void)hipFree(q->d_suboff);
+    delete q;
+}
+
+// =============================================================================================
+// Workspace
+// =============================================================================================
+enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_SORT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_COUNT };
+static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "sort", "join_link", "join_scan", "join_chain", "gather"};
+
+struct vlg_workspace {
+    hipStream_t stream = nullptr;
+    uint64_t cap_bytes = 0;
+    uint8_t* arena = nullptr;
+    uint64_t arena_bytes = 0;
+    bool profile = false;
+    vlg_kernel_stat stats[KS_COUNT];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KS_COUNT];
+    std::vector<hipEvent_t> free_events;
+};
+
+namespace {
+
+hipEvent_t ws_event(vlg_workspace* ws)
+{
+    if (!ws->free_events.empty()) { hipEvent_t e = ws->free_events.back(); ws->free_events.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct Timed {      // RAII: HIP events around one launch (or one library call) on the workspace stream
+    vlg_workspace* ws; int k; hipEvent_t a = nullptr, b = nullptr;
+    Timed(vlg_workspace* w, int kernel, uint64_t alg_bytes) : ws(w), k(kernel)
+    {
+        ws->stats[k].launches++;
+        ws->stats[k].algorithmic_bytes += alg_bytes;
+        if (ws->profile) { a = ws_event(ws); b = ws_event(ws); if (a) (void)hipEventRecord(a, ws->stream); }
+    }
+    ~Timed() { if (a && b) { (void)hipEventRecord(b, ws->stream); ws->pending[k].emplace_back(a, b); } }
+};
+
+void ws_collect(vlg_workspace* ws)
+{
+    for (int k = 0; k < KS_COUNT; ++k) {
+        for (auto& pr : ws->pending[k]) {
+            float ms = 0;
+            (void)hipEventSynchronize(pr.second);
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) ws->stats[k].total_ms += ms;
+            ws->free_events.push_back(pr.first);
+            ws->free_events.push_back(pr.second);
+        }
+        ws->pending[k].clear();
+    }
+}
+
+void ws_reset_stats(vlg_workspace* ws)
+{
+    ws_collect(ws);
+    for (int k = 0; k < KS_COUNT; ++k) {
+        memset(&ws->stats[k], 0, sizeof(vlg_kernel_stat));
+        strncpy(ws->stats[k].name, kKernelNames[k], sizeof(ws->stats[k].name) - 1);
+    }
+}
+
+vlg_status ws_reserve(vlg_workspace* ws, uint64_t bytes)
+{
+    if (bytes <= ws->arena_bytes) return VLG_OK;
+    if (ws->arena) { (void)hipFree(ws->arena); ws->arena = nullptr; ws->arena_bytes = 0; }
+    VLG_HIP_TRY(hipMalloc((void**)&ws->arena, bytes));
+    ws->arena_bytes = bytes;
+    return VLG_OK;
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_workspace_create(uint64_t max_hbm_bytes, void* stream, vlg_workspace** out)
+{
+    if (!out) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VLG_E_NO_DEVICE, "no HIP device available");
+    vlg_workspace* ws = new vlg_workspace();
+    ws->stream = (hipStream_t)stream;
+    ws->cap_bytes = max_hbm_bytes ? max_hbm_bytes : (8ull << 30);
+    ws_reset_stats(ws);
+    *out = ws;
+    return VLG_OK;
+}
+
+extern "C" void vlg_workspace_destroy(vlg_workspace* ws)
+{
+    if (!ws) return;
+    ws_collect(ws);
+    for (hipEvent_t e : ws->free_events) (void)hipEventDestroy(e);
+    if (ws->arena) (void)hipFree(ws->arena);
+    delete ws;
+}
+
+extern "C" vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable)
+{
+    if (!ws) return fail(VLG_E_INVALID, "null argument");
+    ws_reset_stats(ws);
+    ws->profile = enable != 0;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n)
+{
+    if (!ws || !n) return fail(VLG_E_INVALID, "null argument");
+    ws_collect(ws);
+    *n = KS_COUNT;
+    for (uint32_t k = 0; k < KS_COUNT && k < cap && out; ++k) out[k] = ws->stats[k];
+    return VLG_OK;
+}
+
+// =============================================================================================
+// Results
+// =============================================================================================
+struct ResultPiece {
+    uint64_t q0 = 0, q1 = 0;       // query range of the chunk
+    uint64_t matches = 0, tuple_vals = 0;
+    uint64_t* d_first = nullptr;   // [matches]
+    uint64_t* d_tuples = nullptr;  // [tuple_vals]
+};
+
+struct vlg_result {
+    vlg_result_summary sum;
+    std::vector<uint64_t> counts;          // host: per query
+    std::vector<uint32_t> k;               // host: sub-patterns per query
+    std::vector<ResultPiece> pieces;
+};
+
+extern "C" void vlg_result_destroy(vlg_result* r)
+{
+    if (!r) return;
+    for (auto& p : r->pieces) {
+        if (p.d_first) (void)hipFree(p.d_first);
+        if (p.d_tuples) (void)hipFree(p.d_tuples);
+    }
+    delete r;
+}
+
+extern "C" vlg_status vlg_result_summary_get(const vlg_result* r, vlg_result_summary* s)
+{
+    if (!r || !s) return fail(VLG_E_INVALID, "null argument");
+    *s = r->sum;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_result_fetch(const vlg_result* r, uint64_t* h_counts, uint64_t* h_offsets, uint64_t* h_first, uint64_t* h_tuples)
+{
+    if (!r) return fail(VLG_E_INVALID, "null argument");
+    uint64_t nq = r->counts.size();
+    if (h_counts && nq) memcpy(h_counts, r->counts.data(), nq * 8);
+    if (h_offsets) {
+        uint64_t acc = 0;
+        for (uint64_t q = 0; q < nq; ++q) { h_offsets[q] = acc; acc += r->counts[q]; }
+        h_offsets[nq] = acc;
+    }
+    uint64_t fo = 0, to = 0;
+    for (const auto& p : r->pieces) {
+        if (h_first && p.matches) VLG_HIP_TRY(hipMemcpy(h_first + fo, p.d_first, p.matches * 8, hipMemcpyDeviceToHost));
+        if (h_tuples && p.tuple_vals) VLG_HIP_TRY(hipMemcpy(h_tuples + to, p.d_tuples, p.tuple_vals * 8, hipMemcpyDeviceToHost));
+        fo += p.matches;
+        to += p.tuple_vals;
+    }
+    return VLG_OK;
+}
+
+// =============================================================================================
+// Join kernels
+// =============================================================================================
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct SegMeta {            // one per sub-pattern of the chunk (device array)
+    uint32_t begin, end;    // slots of its occurrence list in the chunk arrays
+    uint32_t dist;          // sub-patterns after it in its query (0 = last)
+    uint32_t level;         // index inside the query (0 = first)
+    uint64_t lo, hi;        // gap bounds between the previous sub-pattern and this one
+};
+
+struct QueryMeta {          // one per query of the chunk
+    uint32_t seg0;          // first segment (level 0); kNone if the query is dead
+    uint32_t k;
+    uint64_t end_len;
+    uint64_t out_first;     // offsets into the chunk's result arrays (filled before gather)
+    uint64_t out_tuple;
+};
+
+__device__ __forceinline__ uint64_t sat_add(uint64_t a, uint64_t b) { uint64_t c = a + b; return c < a ? ~0ull : c; }
+
+template <typename pos_t>
+__device__ __forceinline__ uint32_t lower_bound_dev(const pos_t* __restrict__ P, uint32_t a, uint32_t b, uint64_t key)
+{
+    while (a < b) {
+        uint32_t mid = a + ((b - a) >> 1);
+        if ((uint64_t)P[mid] < key) a = mid + 1; else b = mid;
+    }
+    return a;
+}
+
+// distance-0 elements: always feasible, chain ends at themselves
+template <typename pos_t>
+__global__ void join_init_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
+                                 uint32_t seg_base, uint64_t total, uint32_t* __restrict__ feas, pos_t* __restrict__ endp,
+                                 uint32_t* __restrict__ link)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+        const SegMeta m = sm[seg[e] - seg_base];
+        if (m.dist == 0) { feas[e] = (uint32_t)e; endp[e] = P[e]; }
+        else feas[e] = kNone;          // not known yet
+        link[e] = kNone;
+    }
+}
+
+// link pass for the elements with `dist` sub-patterns after them
+template <typename pos_t>
+__global__ void join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
+                                 uint32_t seg_base, uint64_t total, uint32_t dist, const uint32_t* __restrict__ nf_in,
+                                 uint32_t* __restrict__ feas_out, pos_t* __restrict__ endp, uint32_t* __restrict__ link)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t s = seg[e] - seg_base;
+        const SegMeta m = sm[s];
+        if (m.dist != dist) continue;
+        const SegMeta nx = sm[s + 1];
+        uint64_t x = P[e];
+        uint64_t tlo = sat_add(x, nx.lo), thi = sat_add(x, nx.hi);
+        uint32_t j = lower_bound_dev(P, nx.begin, nx.end, tlo);
+        if (j < nx.end && dist > 1) j = nf_in[j];            // nearest feasible at or after j (may leave the segment)
+        bool ok = j < nx.end && (uint64_t)P[j] <= thi;
+        if (ok) { link[e] = j; endp[e] = endp[j]; feas_out[e] = (uint32_t)e; }
+        else { feas_out[e] = kNone; }
+    }
+}
+
+// jump[e] for level-0 elements: first feasible element of list 0 at or after end(e)+end_len
+template <typename pos_t>
+__global__ void join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
+                                 const QueryMeta* __restrict__ qm, const uint32_t* __restrict__ seg_query, uint32_t seg_base,
+                                 uint64_t total, const uint32_t* __restrict__ nf, const pos_t* __restrict__ endp,
+                                 uint32_t* __restrict__ jump)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t s = seg[e] - seg_base;
+        const SegMeta m = sm[s];
+        if (m.level != 0) continue;
+        uint32_t out = m.end;
+        if (nf[e] == (uint32_t)e) {                           // feasible start
+            uint64_t lim = sat_add((uint64_t)endp[e], qm[seg_query[s]].end_len);
+            uint32_t j = lower_bound_dev(P, (uint32_t)e + 1, m.end, lim);
+            if (j < m.end) { j = nf[j]; }
+            out = j < m.end ? j : m.end;
+        }
+        jump[e] = out;
+    }
+}
+
+// One wavefront per query: hop along list 0.  A window of 64 consecutive jump targets is fetched with
+// one coalesced load; hops that stay inside the window are resolved through cross-lane reads.
+__global__ void __launch_bounds__(256) join_chain_kernel(const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint32_t nq,
+                                                         const uint32_t* __restrict__ nf, const uint32_t* __restrict__ jump,
+                                                         uint32_t* __restrict__ mlist, unsigned long long* __restrict__ counts)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (q >= nq) return;
+    const QueryMeta Q = qm[q];
+    unsigned long long n_match = 0;
+    if (Q.seg0 != kNone) {
+        const SegMeta m = sm[Q.seg0];
+        uint32_t cur = m.begin < m.end ? nf[m.begin] : m.end;
+        if (cur > m.end) cur = m.end;
+        while (cur < m.end) {                                   // wave-uniform loop
+            uint32_t idx = cur + lane;
+            uint32_t jv = idx < m.end ? jump[idx] : m.end;      // window [cur, cur+64)
+            uint32_t wbase = cur;
+            uint32_t pend = 0;                                  // match held by this lane for a coalesced store
+            uint32_t npend = 0;
+            for (;;) {                                          // every lane runs the same scalar walk
+                if (lane == npend) pend = cur;
+                ++npend;
+                uint32_t nxt = __shfl(jv, (int)(cur - wbase));
+                cur = nxt;
+                if (cur >= m.end || cur - wbase >= 64 || npend == 64) break;
+            }
+            if (lane < npend) mlist[m.begin + n_match + lane] = pend;
+            n_match += npend;
+        }
+    }
+    if (lane == 0) counts[q] = n_match;
+}
+
+// tuples of every match: walk the links from the level-0 element
+template <typename pos_t>
+__global__ void join_gather_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
+                                   const QueryMeta* __restrict__ qm, const uint32_t* __restrict__ seg_query, uint32_t seg_base,
+                                   uint64_t total, const uint32_t* __restrict__ link, const uint32_t* __restrict__ mlist,
+                                   const unsigned long long* __restrict__ counts, uint64_t* __restrict__ out_first,
+                                   uint64_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
+{
+    unsigned long long local = 0;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t s = seg[e] - seg_base;
+        const SegMeta m = sm[s];
+        if (m.level != 0) continue;
+        uint32_t qi = seg_query[s];
+        uint64_t t = e - m.begin;
+        if (t >= counts[qi]) continue;
+        const QueryMeta Q = qm[qi];
+        uint32_t el = mlist[e];
+        uint64_t first = P[el];
+        out_first[Q.out_first + t] = first;
+        local += first;
+        uint64_t* tp = out_tuples + Q.out_tuple + t * Q.k;
+        for (uint32_t i = 0; i < Q.k; ++i) {
+            tp[i] = P[el];
+            el = link[el];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(checksum, local);
+}
+
+inline uint32_t grid_for(uint64_t n, uint32_t cap = 16384) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, cap)); }
+
+struct Arena {
+    uint8_t* base; uint64_t size; uint64_t used = 0;
+    template <class T> T* take(uint64_t count)
+    {
+        uint64_t bytes = align_up(count * sizeof(T), 256);
+        if (used + bytes > size) return nullptr;
+        T* p = reinterpret_cast<T*>(base + used);
+        used += bytes;
+        return p;
+    }
+};
+
+template <typename pos_t>
+vlg_status run_chunk(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result* res, uint64_t q0, uint64_t q1,
+                     const std::vector<uint64_t>& occ /* per sub, 0 for dead queries */, const uint64_t* d_l, uint64_t T,
+                     unsigned long long* d_stats /* [0]=lf,[1]=levels,[2]=checksum */)
+{
+    hipStream_t st = ws->stream;
+    const uint64_t s0 = q->qsub[q0], s1 = q->qsub[q1];
+    const uint32_t nseg = (uint32_t)(s1 - s0), nq = (uint32_t)(q1 - q0);
+    ResultPiece piece;
+    piece.q0 = q0; piece.q1 = q1;
+    if (T == 0 || nseg == 0) { res->pieces.push_back(piece); return VLG_OK; }
+    // ---- host-side metadata of the chunk ---------------------------------------------------------
+    std::vector<SegMeta> sm(nseg + 1);
+    std::vector<QueryMeta> qm(nq);
+    std::vector<uint32_t> seg_query(nseg);
+    std::vector<uint64_t> off64(nseg + 1);
+    uint32_t kmax = 0;
+    uint64_t acc = 0;
+    for (uint64_t qi = q0; qi < q1; ++qi) {
+        uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
+        QueryMeta& Q = qm[qi - q0];
+        Q.k = k; Q.end_len = q->end_len[qi]; Q.out_first = Q.out_tuple = 0;
+        bool live = k > 0 && occ[q->qsub[qi]] > 0;
+        Q.seg0 = live ? (uint32_t)(q->qsub[qi] - s0) : kNone;
+        if (live) kmax = std::max(kmax, k);
+        for (uint32_t i = 0; i < k; ++i) {
+            uint64_t s = q->qsub[qi] + i;
+            SegMeta& m = sm[s - s0];
+            m.begin = (uint32_t)acc;
+            off64[s - s0] = acc;
+            acc += occ[s];
+            m.end = (uint32_t)acc;
+            m.level = i; m.dist = k - 1 - i;
+            m.lo = q->lo[s]; m.hi = q->hi[s];
+            seg_query[s - s0] = (uint32_t)(qi - q0);
+        }
+    }
+    off64[nseg] = acc;
+    sm[nseg] = SegMeta{(uint32_t)acc, (uint32_t)acc, 0, 0, 0, 0};
+    if (acc != T) return fail(VLG_E_INTERNAL, "chunk size mismatch");
+    // ---- carve the arena ---------------------------------------------------------------------------
+    size_t sort_tmp = 0, scan_tmp = 0;
+    {
+        pos_t* np = nullptr; uint32_t* nu = nullptr;
+        unsigned bits = bit_width64(idx->hdr.n);
+        VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, np, np, (unsigned)T, nseg, nu, nu, 0, bits, st));
+        auto rin = rocprim::make_reverse_iterator(nu);
+        VLG_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_tmp, rin, rin, T, rocprim::minimum<uint32_t>(), st));
+    }
+    uint64_t need = 0;
+    auto add = [&](uint64_t bytes) { need += align_up(bytes, 256); };
+    add(T * sizeof(pos_t)); add(T * sizeof(pos_t)); add(T * 4); add(T * 4); add(T * sizeof(pos_t)); add(T * 4); add(T * 4); add(T * 4); add(T * 4);
+    add((nseg + 1) * sizeof(SegMeta)); add(nq * sizeof(QueryMeta)); add(nseg * 4); add((nseg + 1) * 8); add((nseg + 1) * 4);
+    add(nq * 8); add(std::max(sort_tmp, scan_tmp));
+    if (vlg_status s = ws_reserve(ws, need)) return s;
+    Arena A{ws->arena, ws->arena_bytes};
+    pos_t* P0 = A.take<pos_t>(T);
+    pos_t* P = A.take<pos_t>(T);
+    uint32_t* seg = A.take<uint32_t>(T);
+    uint32_t* link = A.take<uint32_t>(T);
+    pos_t* endp = A.take<pos_t>(T);
+    uint32_t* nf = A.take<uint32_t>(T);
+    uint32_t* feas = A.take<uint32_t>(T);
+    uint32_t* jump = A.take<uint32_t>(T);
+    uint32_t* mlist = A.take<uint32_t>(T);
+    SegMeta* d_sm = A.take<SegMeta>(nseg + 1);
+    QueryMeta* d_qm = A.take<QueryMeta>(nq);
+    uint32_t* d_segq = A.take<uint32_t>(nseg);
+    uint64_t* d_off64 = A.take<uint64_t>(nseg + 1);
+    uint32_t* d_off32 = A.take<uint32_t>(nseg + 1);
+    unsigned long long* d_counts = A.take<unsigned long long>(nq);
+    void* d_tmp = A.take<uint8_t>(std::max(sort_tmp, scan_tmp));
+    if (!d_tmp) return fail(VLG_E_INTERNAL, "arena carve failed");
+    std::vector<uint32_t> off32(nseg + 1);
+    for (uint32_t i = 0; i <= nseg; ++i) off32[i] = (uint32_t)off64[i];
+    VLG_HIP_TRY(hipMemcpyAsync(d_sm, sm.data(), (nseg + 1) * sizeof(SegMeta), hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_segq, seg_query.data(), nseg * 4, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_off64, off64.data(), (nseg + 1) * 8, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_off32, off32.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
+    // ---- locate -------------------------------------------------------------------------------------
+    {
+        Timed t(ws, KS_EXPAND, 0);
+        // NB: segment ids are global sub-pattern ids minus nothing: expand writes p relative to d_l + s0
+        if (vlg_status s = launch_expand<pos_t>(d_l + s0, d_off64, nseg, T, P0, seg, st)) return s;
+    }
+    {
+        Timed t(ws, KS_LOCATE, 0);
+        if (vlg_status s = launch_locate<pos_t>(idx->view, P0, T, d_stats, st)) return s;
+    }
+    // ---- sort every occurrence list ascending (std::sort, index_sasearch.hpp:80) --------------------
+    {
+        Timed t(ws, KS_SORT, 2ull * T * sizeof(pos_t));
+        unsigned bits = bit_width64(idx->hdr.n);
+        size_t tb = sort_tmp;
+        VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(d_tmp, tb, P0, P, (unsigned)T, nseg, d_off32, d_off32 + 1, 0, bits, st));
+    }
+    // ---- join ---------------------------------------------------------------------------------------
+    const uint32_t g = grid_for(T);
+    {
+        Timed t(ws, KS_JOIN_LINK, 0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_init_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, 0u, T, feas, endp, link);
+    }
+    for (uint32_t dist = 1; dist < kmax; ++dist) {
+        {
+            Timed t(ws, KS_JOIN_LINK, 0);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, 0u, T, dist, nf, feas, endp, link);
+        }
+        {
+            Timed t(ws, KS_JOIN_SCAN, 8ull * T);
+            // nf[j] = nearest element at or after j whose chain is known to be feasible
+            VLG_HIP_TRY(hipMemcpyAsync(nf, feas, T * 4, hipMemcpyDeviceToDevice, st));
+            auto rin = rocprim::make_reverse_iterator(nf + T);
+            size_t tb = scan_tmp;
+            VLG_HIP_TRY(rocprim::inclusive_scan(d_tmp, tb, rin, rin, T, rocprim::minimum<uint32_t>(), st));
+        }
+    }
+    if (kmax <= 1) VLG_HIP_TRY(hipMemcpyAsync(nf, feas, T * 4, hipMemcpyDeviceToDevice, st));   // single sub-patterns: identity
+    {
+        Timed t(ws, KS_JOIN_CHAIN, 0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, d_qm, d_segq, 0u, T, nf, endp, jump);
+        hipLaunchKernelGGL(join_chain_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, d_sm, d_qm, nq, nf, jump, mlist, d_counts);
+    }
+    VLG_HIP_TRY(hipGetLastError());
+    // ---- sizes of the result, then gather -------------------------------------------------------------
+    std::vector<unsigned long long> counts(nq);
+    VLG_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, nq * 8, hipMemcpyDeviceToHost, st));
+    VLG_HIP_TRY(hipStreamSynchronize(st));
+    uint64_t M = 0, TV = 0;
+    for (uint32_t i = 0; i < nq; ++i) {
+        qm[i].out_first = M; qm[i].out_tuple = TV;
+        M += counts[i]; TV += counts[i] * qm[i].k;
+        res->counts[q0 + i] = counts[i];
+    }
+    piece.matches = M; piece.tuple_vals = TV;
+    if (M) {
+        VLG_HIP_TRY(hipMalloc((void**)&piece.d_first, M * 8));
+        VLG_HIP_TRY(hipMalloc((void**)&piece.d_tuples, TV * 8));
+        res->pieces.push_back(piece);
+        VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
+        Timed t(ws, KS_GATHER, 8ull * (M + TV));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, d_qm, d_segq, 0u, T, link, mlist,
+                           d_counts, piece.d_first, piece.d_tuples, d_stats + 2);
+        VLG_HIP_TRY(hipGetLastError());
+    } else {
+        res->pieces.push_back(piece);
+    }
+    VLG_HIP_TRY(hipStreamSynchronize(st));     // qm / counts host buffers are read by the async copies above
+    res->sum.n_matches += M;
+    res->sum.n_tuple_values += TV;
+    res->sum.located_occurrences += T;
+    res->sum.n_chunks++;
+    return VLG_OK;
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result** out)
+{
+    if (!idx || !q || !ws || !out) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    hipStream_t st = ws->stream;
+    vlg_result* res = new vlg_result();
+    memset(&res->sum, 0, sizeof res->sum);
+    res->sum.n_queries = q->nq;
+    res->counts.assign(q->nq, 0);
+    res->k.resize(q->nq);
+    for (uint64_t i = 0; i < q->nq; ++i) res->k[i] = (uint32_t)(q->qsub[i + 1] - q->qsub[i]);
+    uint64_t* d_l = nullptr;
+    uint64_t* d_r = nullptr;
+    unsigned long long* d_stats = nullptr;
+    auto run = [&]() -> vlg_status {
+        const uint64_t nsub = q->nsub;
+        VLG_HIP_TRY(hipMalloc((void**)&d_l, (nsub + 1) * 8));
+        VLG_HIP_TRY(hipMalloc((void**)&d_r, (nsub + 1) * 8));
+        VLG_HIP_TRY(hipMalloc((void**)&d_stats, 4 * 8));
+        VLG_HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * 8, st));
+        // ---- K2: every sub-pattern's SA interval ------------------------------------------------------
+        {
+            Timed t(ws, KS_BSEARCH, 0);
+            if (vlg_status s = launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_l, d_r, d_stats + 3, st)) return s;
+        }
+        std::vector<uint64_t> l(nsub), r(nsub), occ(nsub, 0);
+        if (nsub) {
+            VLG_HIP_TRY(hipMemcpyAsync(l.data(), d_l, nsub * 8, hipMemcpyDeviceToHost, st));
+            VLG_HIP_TRY(hipMemcpyAsync(r.data(), d_r, nsub * 8, hipMemcpyDeviceToHost, st));
+        }
+        VLG_HIP_TRY(hipStreamSynchronize(st));
+        // a query with an empty sub-pattern list has no match: none of its lists is materialised
+        // (vlg_index.hpp:315-316 returns at the first empty range)
+        for (uint64_t qi = 0; qi < q->nq; ++qi) {
+            bool live = q->qsub[qi + 1] > q->qsub[qi];
+            for (uint64_t s = q->qsub[qi]; s < q->qsub[qi + 1] && live; ++s) live = (r[s] + 1 - l[s]) > 0;
+            if (live) for (uint64_t s = q->qsub[qi]; s < q->qsub[qi + 1]; ++s) occ[s] = r[s] + 1 - l[s];
+        }
+        // ---- chunks of whole queries that fit the workspace -----------------------------------------
+        const uint64_t pos_bytes = idx->hdr.sample_bytes;
+        const uint64_t per_occ = 3 * pos_bytes + 6 * 4 + 8;          // arrays of run_chunk + sort temp slack
+        const uint64_t fixed = 64ull << 20;
+        uint64_t cap_occ = ws->cap_bytes > fixed ? (ws->cap_bytes - fixed) / per_occ : 0;
+        cap_occ = std::min<uint64_t>(cap_occ, 0xFFFFFF00ull);
+        uint64_t q0 = 0;
+        while (q0 < q->nq) {
+            uint64_t T = 0, q1 = q0;
+            while (q1 < q->nq) {
+                uint64_t t = 0;
+                for (uint64_t s = q->qsub[q1]; s < q->qsub[q1 + 1]; ++s) t += occ[s];
+                if (t > cap_occ)
+                    return fail(VLG_E_WORKSPACE, "query " + std::to_string(q1) + " needs " + std::to_string(t) +
+                                                     " occurrence slots; workspace cap allows " + std::to_string(cap_occ));
+                if (T + t > cap_occ || (q1 - q0) >= (1u << 24)) break;
+                T += t;
+                ++q1;
+            }
+            vlg_status s = (pos_bytes == 4) ? run_chunk<uint32_t>(idx, q, ws, res, q0, q1, occ, d_l, T, d_stats)
+                                            : run_chunk<uint64_t>(idx, q, ws, res, q0, q1, occ, d_l, T, d_stats);
+            if (s) return s;
+            q0 = q1;
+        }
+        unsigned long long hs[4];
+        VLG_HIP_TRY(hipMemcpyAsync(hs, d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipStreamSynchronize(st));
+        res->sum.lf_steps = hs[0];
+        res->sum.wt_levels_locate = hs[1];
+        res->sum.checksum = hs[2];
+        res->sum.wt_levels_bsearch = hs[3];
+        // algorithmic bytes: 32 B per super-block read (+ one sample per occurrence)
+        ws->stats[KS_LOCATE].algorithmic_bytes += 32ull * hs[1] + pos_bytes * res->sum.located_occurrences;
+        ws->stats[KS_BSEARCH].algorithmic_bytes += 32ull * hs[3];
+        return VLG_OK;
+    };
+    vlg_status stt = run();
+    if (d_l) (void)hipFree(d_l);
+    if (d_r) (void)hipFree(d_r);
+    if (d_stats) (void)hipFree(d_stats);
+    if (stt) { vlg_result_destroy(res); return stt; }
+    *out = res;
+    return VLG_OK;
+}

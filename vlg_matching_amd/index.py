@@ -1,0 +1,280 @@
+"""Host-side mirror of the reference interface for the VLG hot path.
+
+  VlgIndex          ~ sdsl::vlg_index<> / the benchmark index concept (construct, serialize/load via parts, search)
+  count / locate    ~ sdsl::count / sdsl::locate (include/sdsl/vlg_index.hpp:395-411)
+  VlgIndex.search   ~ index_*::search for a batch of gapped_pattern (benchmark/gapped-matching/src/gm_search.cpp:91-121)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import VlgError, check, lib
+
+NODE_DTYPE = np.dtype([("bv_pos", "<u8"), ("bv_pos_rank", "<u8"), ("parent", "<u2"), ("child", "<u2", (2,))], align=True)
+assert NODE_DTYPE.itemsize == C.sizeof(capi.WtNode)
+
+
+def _u8(a):
+    if isinstance(a, (bytes, bytearray)):
+        return np.frombuffer(bytes(a), dtype=np.uint8)
+    if isinstance(a, str):
+        return np.frombuffer(a.encode("latin-1"), dtype=np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class SearchResult:
+    """Per-query match counts, first positions (gapped_search_result::positions) and full tuples."""
+
+    def __init__(self, handle, ks):
+        self._h = handle
+        self._ks = ks
+        s = capi.ResultSummary()
+        check(lib().vlg_result_summary_get(handle, C.byref(s)))
+        self.summary = {k: int(getattr(s, k)) for k, _ in capi.ResultSummary._fields_}
+        self._fetched = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vlg_result_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def fetch(self):
+        if self._fetched is None:
+            nq = self.summary["n_queries"]
+            counts = np.zeros(max(nq, 1), dtype=np.uint64)
+            offsets = np.zeros(nq + 1, dtype=np.uint64)
+            first = np.zeros(max(self.summary["n_matches"], 1), dtype=np.uint64)
+            tuples = np.zeros(max(self.summary["n_tuple_values"], 1), dtype=np.uint64)
+            check(lib().vlg_result_fetch(self._h, counts.ctypes.data, offsets.ctypes.data, first.ctypes.data, tuples.ctypes.data))
+            self._fetched = (counts[:nq], offsets, first[: self.summary["n_matches"]], tuples[: self.summary["n_tuple_values"]])
+        return self._fetched
+
+    @property
+    def counts(self):
+        return self.fetch()[0]
+
+    def positions(self, q):
+        _, off, first, _ = self.fetch()
+        return first[int(off[q]): int(off[q + 1])]
+
+    def tuples(self, q):
+        counts, _, _, tup = self.fetch()
+        ks = np.asarray(self._ks, dtype=np.uint64)
+        toff = np.concatenate([[0], np.cumsum(counts * ks)]).astype(np.int64)
+        k = int(ks[q])
+        return tup[toff[q]: toff[q + 1]].reshape(-1, max(k, 1)) if k else np.zeros((0, 0), np.uint64)
+
+
+class Workspace:
+    def __init__(self, max_hbm_bytes=0, stream=None):
+        h = C.c_void_p()
+        check(lib().vlg_workspace_create(int(max_hbm_bytes), stream, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vlg_workspace_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def profile(self, enable=True):
+        check(lib().vlg_workspace_profile(self._h, 1 if enable else 0))
+
+    def kernel_stats(self):
+        arr = (capi.KernelStat * 16)()
+        n = C.c_uint32()
+        check(lib().vlg_workspace_kernel_stats(self._h, arr, 16, C.byref(n)))
+        return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),
+                                           algorithmic_bytes=int(arr[i].algorithmic_bytes)) for i in range(n.value)}
+
+
+class Queries:
+    """A parsed query batch resident in HBM."""
+
+    def __init__(self, regexps, dialect=capi.DIALECT_LIBRARY, strict=True):
+        raws = [r.encode("latin-1") if isinstance(r, str) else bytes(r) for r in regexps]
+        off = np.zeros(len(raws) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in raws])
+        text = b"".join(raws)
+        h = C.c_void_p()
+        status = np.zeros(max(len(raws), 1), dtype=np.int32)
+        check(lib().vlg_queries_parse(text, off.ctypes.data, len(raws), dialect, None if strict else status.ctypes.data, C.byref(h)))
+        self._h = h
+        self.status = status[: len(raws)]
+        self.n = len(raws)
+
+    @classmethod
+    def from_arrays(cls, subpatterns, lo, hi, end_len):
+        """subpatterns: list (per query) of lists of bytes; lo/hi: per query lists of k-1 start-to-start bounds."""
+        self = cls.__new__(cls)
+        blob, suboff, qsub, flo, fhi = [], [0], [0], [], []
+        for subs, l, h in zip(subpatterns, lo, hi):
+            for i, s in enumerate(subs):
+                blob.append(bytes(s))
+                suboff.append(suboff[-1] + len(s))
+                flo.append(0 if i == 0 else int(l[i - 1]))
+                fhi.append(0 if i == 0 else int(h[i - 1]))
+            qsub.append(len(suboff) - 1)
+        b = np.frombuffer(b"".join(blob) + b"\0", dtype=np.uint8)
+        a = [np.asarray(x, dtype=np.uint64) for x in (suboff, qsub, flo + [0], fhi + [0], list(end_len) + [0])]
+        hq = C.c_void_p()
+        check(lib().vlg_queries_create(b.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                                       a[4].ctypes.data, len(subpatterns), C.byref(hq)))
+        self._h = hq
+        self.n = len(subpatterns)
+        self.status = np.zeros(self.n, dtype=np.int32)
+        return self
+
+    @property
+    def ks(self):
+        """sub-patterns per query (0 for a query that failed to parse)"""
+        if getattr(self, "_ks", None) is None:
+            k = np.zeros(max(self.n, 1), dtype=np.uint32)
+            check(lib().vlg_queries_k(self._h, k.ctypes.data))
+            self._ks = k[: self.n]
+        return self._ks
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vlg_queries_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class VlgIndex:
+    """FM-index (csa_wt<wt_huff<>>-equivalent) resident in HBM."""
+
+    def __init__(self, handle, keep=None):
+        self._h = handle
+        self._keep = keep          # e.g. the torch tensor backing an attached blob
+        self._ws = None
+
+    # -- construction ---------------------------------------------------------------------------
+    @classmethod
+    def build(cls, text, dens=32):
+        """sdsl::construct equivalent, on the device (suffix sort, BWT, wavelet tree, sampling)."""
+        t = _u8(text)
+        h = C.c_void_p()
+        check(lib().vlg_index_build(t.ctypes.data if len(t) else None, len(t), dens, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def build_device(cls, d_text_ptr, n_text, dens=32, stream=None):
+        h = C.c_void_p()
+        check(lib().vlg_index_build_device(d_text_ptr, n_text, dens, stream, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_parts(cls, p):
+        """Adopt an index in the reference's own layout (dict as produced by export_parts())."""
+        nodes = np.ascontiguousarray(p["nodes"])
+        c2c = np.ascontiguousarray(p["char2comp"], dtype=np.uint8)
+        Cc = np.ascontiguousarray(p["C"], dtype=np.uint64)
+        bv = np.ascontiguousarray(p["bv_words"], dtype=np.uint64)
+        smp = np.ascontiguousarray(p["samples"], dtype=np.uint64)
+        parts = capi.IndexParts(int(p["n"]), int(p["sigma"]), int(p.get("dens", 32)), c2c.ctypes.data, Cc.ctypes.data,
+                                bv.ctypes.data if len(bv) else None, int(p["bv_bits"]), nodes.ctypes.data, len(nodes),
+                                smp.ctypes.data, len(smp))
+        h = C.c_void_p()
+        check(lib().vlg_index_from_parts(C.byref(parts), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def attach_blob(cls, d_ptr, nbytes, keep=None):
+        h = C.c_void_p()
+        check(lib().vlg_index_attach_blob(d_ptr, nbytes, C.byref(h)))
+        return cls(h, keep)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vlg_index_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- introspection ----------------------------------------------------------------------------
+    def info(self):
+        i = capi.IndexInfo()
+        check(lib().vlg_index_get_info(self._h, C.byref(i)))
+        return {k: int(getattr(i, k)) for k, _ in capi.IndexInfo._fields_ if k != "reserved"}
+
+    def export_parts(self):
+        sz = capi.IndexParts()
+        check(lib().vlg_index_export_parts(self._h, C.byref(sz), None))
+        c2c = np.zeros(256, np.uint8)
+        Cc = np.zeros(257, np.uint64)
+        bv = np.zeros(max((sz.bv_bits + 63) // 64, 1), np.uint64)
+        nodes = np.zeros(max(sz.n_nodes, 1), dtype=NODE_DTYPE)
+        smp = np.zeros(max(sz.n_samples, 1), np.uint64)
+        out = capi.IndexPartsOut(c2c.ctypes.data, Cc.ctypes.data, bv.ctypes.data, nodes.ctypes.data, smp.ctypes.data)
+        check(lib().vlg_index_export_parts(self._h, C.byref(sz), C.byref(out)))
+        return {"n": int(sz.n), "sigma": int(sz.sigma), "dens": int(sz.sa_sample_dens), "char2comp": c2c,
+                "C": Cc[: sz.sigma + 1], "bv_bits": int(sz.bv_bits), "bv_words": bv[: (sz.bv_bits + 63) // 64],
+                "nodes": nodes[: sz.n_nodes], "samples": smp[: sz.n_samples]}
+
+    def blob_bytes(self):
+        b = C.c_uint64()
+        check(lib().vlg_index_blob_bytes(self._h, C.byref(b)))
+        return int(b.value)
+
+    def blob_export(self, d_ptr, nbytes, stream=None):
+        check(lib().vlg_index_blob_export(self._h, d_ptr, nbytes, stream))
+
+    # -- search -----------------------------------------------------------------------------------
+    def workspace(self, max_hbm_bytes=0):
+        if self._ws is None:
+            self._ws = Workspace(max_hbm_bytes)
+        return self._ws
+
+    def search(self, queries, dialect=capi.DIALECT_LIBRARY, workspace=None, strict=True):
+        """Batched `idx.search(pat)`: queries is a list of regexps or a Queries object."""
+        q = queries if isinstance(queries, Queries) else Queries(queries, dialect, strict)
+        ws = workspace or self.workspace()
+        h = C.c_void_p()
+        check(lib().vlg_search_batch(self._h, q._h, ws._h, C.byref(h)))
+        return SearchResult(h, q.ks)
+
+
+def locate(idx, query):
+    """sdsl::locate(idx, query): tuples [matches, k] of sub-pattern start positions (library dialect)."""
+    r = idx.search([query])
+    return r.tuples(0)
+
+
+def count(idx, query):
+    """sdsl::count(idx, query)."""
+    return int(idx.search([query]).counts[0])
+
+
+class BitVector:
+    """rank_support_v-equivalent on a plain bit-vector, resident in HBM (K1)."""
+
+    def __init__(self, words, nbits):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib().vlg_bitvector_create(w.ctypes.data if len(w) else None, int(nbits), C.byref(h)))
+        self._h = h
+        self.nbits = int(nbits)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vlg_bitvector_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def rank_device(self, d_idx_ptr, d_out_ptr, count, stream=None):
+        check(lib().vlg_bitvector_rank_batch(self._h, d_idx_ptr, d_out_ptr, count, stream))
+
+    def hbm_bytes(self):
+        return int(lib().vlg_bitvector_hbm_bytes(self._h))
