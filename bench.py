@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- VLG queries/s + located occurrences/s of the MI355X hot path (BASELINE.json metric).
+
+A "step" is one pass of the whole hot path (backward search -> locate -> sort -> gap join) over one batch
+of synthetic queries, index and query batch already resident in HBM.  At N=1 the workload is SURVEY.md 8(d)
+config C3 (1 GiB english-like text, 100k 3-sub-pattern queries, gap <= 1000).  With N GPUs the read-only
+index is built on rank 0 and broadcast over RCCL, every rank runs its own batch (weak scaling, no data-path
+collective); the timed region is bracketed by barrier + synchronize and the max over ranks is reported.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--scale 1.0]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=450000, budget_s=25.0):
+    """The CPU oracle (restatement of the reference path, reference data layout) timed on this host, one thread,
+    on a bounded seeded sample of the same query batch."""
+    from oracle import oracle as O
+    parts = idx.export_parts()
+    o = O.Index.from_parts(parts)
+    rng = np.random.default_rng(12345)
+    order = rng.permutation(len(queries))
+    stats = np.zeros(4, dtype=np.uint64)
+    done, dt, remaining = 0, 0.0, budget_occ
+    for qi in order:
+        subs, _, _, _ = O.query_fields(O.parse(queries[qi]))
+        occs = [o.backward_search(sp)[0] for sp in subs]
+        need = 0 if min(occs) == 0 else sum(occs)
+        if need > remaining:                      # keeps the sample bounded: heavy queries cost minutes on one core
+            continue
+        t0 = time.perf_counter()
+        o.search(queries[qi], stats=stats)
+        dt += time.perf_counter() - t0
+        done += 1
+        remaining -= need
+        if dt > budget_s or remaining < 1000 or done >= 2000:
+            break
+    occ_rate = float(stats[0]) / dt if dt > 0 else 0.0
+    # a sample's queries/s depends on which heavy queries it happened to draw; the stable figure is located
+    # occurrences/s, converted with the exact mean occurrences per query of the full batch
+    qps = occ_rate / occ_per_query_mean if occ_per_query_mean > 0 else 0.0
+    return {"value": qps, "unit": "queries/s", "cores": 1, "kind": "port",
+            "located_occ_per_sec": occ_rate, "sample_queries": done, "sample_seconds": dt,
+            "sample_located_occ": int(stats[0]), "sample_lf_steps": int(stats[1]),
+            "sample": "%d queries of the same batch, drawn in random order (seed 12345) while their occurrence lists fit a "
+                      "%d-occurrence budget; %.1f s on one core; queries/s = sample occurrences/s / mean occurrences "
+                      "per query of the full batch (%.0f)" % (done, budget_occ, dt, occ_per_query_mean)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink text and batch (development only)")
+    ap.add_argument("--workspace-gb", type=float, default=48.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+
+    import vlg_matching_amd as V
+    from vlg_matching_amd import workload
+    from vlg_matching_amd.index import Queries, Workspace
+    V.capi.check(V.lib().vlg_set_device(local_rank))
+
+    cfg = workload.config(args.config, args.scale)
+    t_gen = t_build = 0.0
+    # ---- index: built on rank 0, replicated over RCCL (one broadcast of the contiguous HBM image) ----------
+    text = None
+    if rank == 0:
+        t0 = time.perf_counter()
+        text = workload.gen_text(cfg["kind"], cfg["n"], cfg["seed"])
+        t_gen = time.perf_counter() - t0
+        log("text %s n=%d generated in %.1f s" % (cfg["kind"], cfg["n"], t_gen))
+        d_text = torch.from_numpy(text).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx = V.VlgIndex.build_device(d_text.data_ptr(), len(text))
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t0
+        del d_text
+        torch.cuda.empty_cache()
+        log("index built on device in %.2f s: %s" % (t_build, idx.info()))
+    if world > 1:
+        nb = torch.tensor([idx.blob_bytes() if rank == 0 else 0], dtype=torch.int64, device="cuda")
+        dist.broadcast(nb, 0)
+        blob = torch.empty(int(nb.item()), dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idx.blob_export(blob.data_ptr(), blob.numel())
+        t0 = time.perf_counter()
+        dist.broadcast(blob, 0)
+        torch.cuda.synchronize()
+        log("rank %d: index image %.1f MB broadcast in %.3f s" % (rank, blob.numel() / 1e6, time.perf_counter() - t0))
+        if rank != 0:
+            idx = V.VlgIndex.attach_blob(blob.data_ptr(), blob.numel(), keep=blob)
+    info = idx.info()
+
+    # ---- query batches: one per rank (weak scaling), generated where the text is ---------------------------
+    if rank == 0:
+        batches = [workload.gen_queries(text, cfg["nq"], cfg["k"], cfg["m"], cfg["gap"], cfg["qseed"] + 1000 * r)
+                   for r in range(world)]
+    else:
+        batches = None
+    if world > 1:
+        mine = [None]
+        dist.scatter_object_list(mine, batches if rank == 0 else None, src=0)
+        queries = mine[0]
+    else:
+        queries = batches[0]
+    del text
+    q = Queries(queries)                      # parsed + uploaded: resident in HBM before the timed region
+    ws = Workspace(int(args.workspace_gb * (1 << 30)))
+
+    def step():
+        return idx.search(q, workspace=ws)
+
+    for _ in range(args.warmup):
+        step()
+    ws.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    s = res.summary
+    tot = torch.tensor([s["n_queries"], s["located_occurrences"], s["n_matches"], s["logical_occurrences"]],
+                       dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    n_queries, n_occ, n_matches, n_logical = int(tot[0]), int(tot[1]), int(tot[2]), int(tot[3])
+    kstats = ws.kernel_stats()
+
+    if rank == 0:
+        loc = kstats["locate"]
+        launches = max(loc["launches"], 1)
+        per_launch_ms = loc["total_ms"] / launches
+        alg_bytes_per_launch = loc["algorithmic_bytes"] / launches
+        achieved = alg_bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        out = {
+            "metric": "vlg_queries_per_sec",
+            "value": n_queries * args.steps / dt,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32" if info["pos_bytes"] == 4 else "u64",
+            "data": "synthetic",
+            "config": {"workload": "%s%s: %s text n=%d (seed %d), %d queries/GPU x k=%d, m=%d, gap .{%d,%d}?, t_dens=32"
+                                   % (args.config, "" if args.scale == 1.0 else " x%g" % args.scale, cfg["kind"], cfg["n"],
+                                      cfg["seed"], cfg["nq"], cfg["k"], cfg["m"], cfg["gap"][0], cfg["gap"][1]),
+                       "sigma": info["sigma"], "mean_code_len_bits": info["wt_bits"] / info["n"],
+                       "index_hbm_bytes": info["hbm_bytes"]},
+            "located_occ_per_sec": n_occ * args.steps / dt,
+            "located_occ_per_step": n_occ,
+            "logical_occ_per_sec": n_logical * args.steps / dt,
+            "logical_occ_per_step": n_logical,
+            "matches_per_step": n_matches,
+            "checksum_rank0": s["checksum"],
+            "lf_steps_per_occ": s["lf_steps"] / max(s["located_occurrences"], 1),
+            "wt_levels_per_lf": s["wt_levels_locate"] / max(s["lf_steps"], 1),
+            "chunks_per_step": s["n_chunks"],
+            "index_build_s": t_build, "text_gen_s": t_gen,
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kstats.items()},
+            "kernels_ms_sum_per_step": sum(v["total_ms"] for v in kstats.values()) / args.steps,
+            "roofline": {"bound": "hbm", "kernel": "locate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": per_launch_ms,
+                         "launches": loc["launches"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(idx, queries, n_logical / max(n_queries, 1))
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

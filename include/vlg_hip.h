@@ -204,11 +204,14 @@ typedef struct {
     uint64_t n_matches;           /* = gm_search's num_results (gm_search.cpp:110-114)          */
     uint64_t checksum;            /* = gm_search's checksum: sum of first positions mod 2^64    */
     uint64_t n_tuple_values;      /* sum over matches of k(query)                              */
-    uint64_t located_occurrences; /* occurrences materialised by locate                        */
+    uint64_t located_occurrences; /* occurrences materialised by locate (each distinct SA interval of the
+                                     batch is located once and shared by the queries that use it)     */
     uint64_t lf_steps;            /* LF steps taken by locate (csa_wt.hpp:338-341)              */
     uint64_t wt_levels_locate;    /* 32-byte super-block reads in locate                       */
     uint64_t wt_levels_bsearch;   /* 32-byte super-block reads in backward search              */
     uint64_t n_chunks;
+    uint64_t logical_occurrences; /* sum of the list lengths the joins consumed (what the reference
+                                     would locate query by query)                                 */
 } vlg_result_summary;
 
 vlg_status vlg_result_summary_get(const vlg_result* r, vlg_result_summary* s);
@@ -229,6 +232,9 @@ typedef struct {
     uint64_t algorithmic_bytes;   /* SURVEY.md 8(d) accounting, 0 if not defined for the kernel */
 } vlg_kernel_stat;
 vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
+/* Options: "dedup" (default 1): share one located+sorted list between all sub-patterns of a batch that
+ * have the same SA interval; 0 = locate every sub-pattern of every query separately like the reference. */
+vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* name, int64_t value);
 vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n);
 
 #ifdef __cplusplus

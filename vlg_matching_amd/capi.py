@@ -39,7 +39,8 @@ class IndexInfo(C.Structure):
 
 class ResultSummary(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_queries", "n_matches", "checksum", "n_tuple_values", "located_occurrences",
-                                           "lf_steps", "wt_levels_locate", "wt_levels_bsearch", "n_chunks")]
+                                           "lf_steps", "wt_levels_locate", "wt_levels_bsearch", "n_chunks",
+                                           "logical_occurrences")]
 
 
 class KernelStat(C.Structure):
@@ -83,6 +84,7 @@ SYMBOLS = [
     ("vlg_result_fetch", _I, [_P, _P, _P, _P, _P]),
     ("vlg_result_destroy", None, [_P]),
     ("vlg_workspace_profile", _I, [_P, _I]),
+    ("vlg_workspace_set_option", _I, [_P, C.c_char_p, C.c_int64]),
     ("vlg_workspace_kernel_stats", _I, [_P, C.POINTER(KernelStat), C.c_uint32, C.POINTER(C.c_uint32)]),
 ]
 

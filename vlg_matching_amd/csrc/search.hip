@@ -230,6 +230,7 @@ struct vlg_workspace {
     uint8_t* arena = nullptr;
     uint64_t arena_bytes = 0;
     bool profile = false;
+    bool dedup = true;
     vlg_kernel_stat stats[KS_COUNT];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KS_COUNT];
     std::vector<hipEvent_t> free_events;
@@ -321,6 +322,13 @@ extern "C" vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable)
     return VLG_OK;
 }
 
+extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* name, int64_t value)
+{
+    if (!ws || !name) return fail(VLG_E_INVALID, "null argument");
+    if (!strcmp(name, "dedup")) { ws->dedup = value != 0; return VLG_OK; }
+    return fail(VLG_E_INVALID, std::string("unknown workspace option ") + name);
+}
+
 extern "C" vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n)
 {
     if (!ws || !n) return fail(VLG_E_INVALID, "null argument");
@@ -391,8 +399,12 @@ namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
+// Occurrence lists are PHYSICAL: one sorted list per distinct SA interval of the batch, shared by every
+// query that uses the sub-pattern.  Join state (link / end / feasibility ...) is LOGICAL: one slot per
+// element of every (query, level) whose level is not the query's last one (the last list is only searched).
 struct SegMeta {            // one per sub-pattern of the chunk (device array)
-    uint32_t begin, end;    // slots of its occurrence list in the chunk arrays
+    uint32_t begin, end;    // logical slots (begin == end for the last level of a k>=2 query)
+    uint32_t pbegin, pend;  // physical list inside P
     uint32_t dist;          // sub-patterns after it in its query (0 = last)
     uint32_t level;         // index inside the query (0 = first)
     uint64_t lo, hi;        // gap bounds between the previous sub-pattern and this one
@@ -407,6 +419,7 @@ struct QueryMeta {          // one per query of the chunk
 };
 
 __device__ __forceinline__ uint64_t sat_add(uint64_t a, uint64_t b) { uint64_t c = a + b; return c < a ? ~0ull : c; }
+__device__ __forceinline__ uint32_t phys_of(const SegMeta& m, uint32_t e) { return m.pbegin + (e - m.begin); }
 
 template <typename pos_t>
 __device__ __forceinline__ uint32_t lower_bound_dev(const pos_t* __restrict__ P, uint32_t a, uint32_t b, uint64_t key)
@@ -418,15 +431,36 @@ __device__ __forceinline__ uint32_t lower_bound_dev(const pos_t* __restrict__ P,
     return a;
 }
 
-// distance-0 elements: always feasible, chain ends at themselves
+// seg[t] = segment owning logical slot t (tile of 256 slots, one binary search per tile)
+__global__ void seg_ids_kernel(const uint32_t* __restrict__ seg_begin /* [nseg+1], non-decreasing */, uint32_t nseg, uint64_t total,
+                               uint32_t* __restrict__ seg)
+{
+    __shared__ uint32_t s_first;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256; base < total; base += (uint64_t)gridDim.x * 256) {
+        if (threadIdx.x == 0) {
+            uint32_t lo = 0, hi = nseg;                    // last p with seg_begin[p] <= base
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (seg_begin[mid] <= base) lo = mid; else hi = mid; }
+            s_first = lo;
+        }
+        __syncthreads();
+        uint64_t t = base + threadIdx.x;
+        if (t < total) {
+            uint32_t p = s_first;
+            while (seg_begin[p + 1] <= t) ++p;             // skips empty segments
+            seg[t] = p;
+        }
+        __syncthreads();
+    }
+}
+
+// single-sub-pattern queries: every element is a feasible chain that ends at itself
 template <typename pos_t>
 __global__ void join_init_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
-                                 uint32_t seg_base, uint64_t total, uint32_t* __restrict__ feas, pos_t* __restrict__ endp,
-                                 uint32_t* __restrict__ link)
+                                 uint64_t total, uint32_t* __restrict__ feas, pos_t* __restrict__ endp, uint32_t* __restrict__ link)
 {
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
-        const SegMeta m = sm[seg[e] - seg_base];
-        if (m.dist == 0) { feas[e] = (uint32_t)e; endp[e] = P[e]; }
+        const SegMeta m = sm[seg[e]];
+        if (m.dist == 0) { feas[e] = (uint32_t)e; endp[e] = P[phys_of(m, (uint32_t)e)]; }
         else feas[e] = kNone;          // not known yet
         link[e] = kNone;
     }
@@ -435,41 +469,47 @@ __global__ void join_init_kernel(const pos_t* __restrict__ P, const uint32_t* __
 // link pass for the elements with `dist` sub-patterns after them
 template <typename pos_t>
 __global__ void join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
-                                 uint32_t seg_base, uint64_t total, uint32_t dist, const uint32_t* __restrict__ nf_in,
-                                 uint32_t* __restrict__ feas_out, pos_t* __restrict__ endp, uint32_t* __restrict__ link)
+                                 uint64_t total, uint32_t dist, const uint32_t* __restrict__ nf_in, uint32_t* __restrict__ feas_out,
+                                 pos_t* __restrict__ endp, uint32_t* __restrict__ link)
 {
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t s = seg[e] - seg_base;
+        uint32_t s = seg[e];
         const SegMeta m = sm[s];
         if (m.dist != dist) continue;
         const SegMeta nx = sm[s + 1];
-        uint64_t x = P[e];
+        uint64_t x = P[phys_of(m, (uint32_t)e)];
         uint64_t tlo = sat_add(x, nx.lo), thi = sat_add(x, nx.hi);
-        uint32_t j = lower_bound_dev(P, nx.begin, nx.end, tlo);
-        if (j < nx.end && dist > 1) j = nf_in[j];            // nearest feasible at or after j (may leave the segment)
-        bool ok = j < nx.end && (uint64_t)P[j] <= thi;
-        if (ok) { link[e] = j; endp[e] = endp[j]; feas_out[e] = (uint32_t)e; }
-        else { feas_out[e] = kNone; }
+        uint32_t j = lower_bound_dev(P, nx.pbegin, nx.pend, tlo);     // physical index in the next list
+        bool ok = false;
+        if (dist == 1) {                                              // next list is the last one: every element is feasible
+            ok = j < nx.pend && (uint64_t)P[j] <= thi;
+            if (ok) { link[e] = j; endp[e] = P[j]; }
+        } else if (j < nx.pend) {
+            uint32_t ej = nf_in[nx.begin + (j - nx.pbegin)];          // nearest feasible logical element at or after it
+            if (ej < nx.end && (uint64_t)P[phys_of(nx, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+        }
+        feas_out[e] = ok ? (uint32_t)e : kNone;
     }
 }
 
 // jump[e] for level-0 elements: first feasible element of list 0 at or after end(e)+end_len
 template <typename pos_t>
 __global__ void join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
-                                 const QueryMeta* __restrict__ qm, const uint32_t* __restrict__ seg_query, uint32_t seg_base,
-                                 uint64_t total, const uint32_t* __restrict__ nf, const pos_t* __restrict__ endp,
-                                 uint32_t* __restrict__ jump)
+                                 const QueryMeta* __restrict__ qm, const uint32_t* __restrict__ seg_query, uint64_t total,
+                                 const uint32_t* __restrict__ nf, const pos_t* __restrict__ endp, uint32_t* __restrict__ jump)
 {
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t s = seg[e] - seg_base;
+        uint32_t s = seg[e];
         const SegMeta m = sm[s];
         if (m.level != 0) continue;
         uint32_t out = m.end;
         if (nf[e] == (uint32_t)e) {                           // feasible start
             uint64_t lim = sat_add((uint64_t)endp[e], qm[seg_query[s]].end_len);
-            uint32_t j = lower_bound_dev(P, (uint32_t)e + 1, m.end, lim);
-            if (j < m.end) { j = nf[j]; }
-            out = j < m.end ? j : m.end;
+            uint32_t jp = lower_bound_dev(P, phys_of(m, (uint32_t)e) + 1, m.pend, lim);
+            if (jp < m.pend) {
+                uint32_t ej = nf[m.begin + (jp - m.pbegin)];
+                out = ej < m.end ? ej : m.end;
+            }
         }
         jump[e] = out;
     }
@@ -513,28 +553,31 @@ __global__ void __launch_bounds__(256) join_chain_kernel(const SegMeta* __restri
 // tuples of every match: walk the links from the level-0 element
 template <typename pos_t>
 __global__ void join_gather_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
-                                   const QueryMeta* __restrict__ qm, const uint32_t* __restrict__ seg_query, uint32_t seg_base,
-                                   uint64_t total, const uint32_t* __restrict__ link, const uint32_t* __restrict__ mlist,
+                                   const QueryMeta* __restrict__ qm, const uint32_t* __restrict__ seg_query, uint64_t total,
+                                   const uint32_t* __restrict__ link, const uint32_t* __restrict__ mlist,
                                    const unsigned long long* __restrict__ counts, uint64_t* __restrict__ out_first,
                                    uint64_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
 {
     unsigned long long local = 0;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t s = seg[e] - seg_base;
+        uint32_t s = seg[e];
         const SegMeta m = sm[s];
         if (m.level != 0) continue;
         uint32_t qi = seg_query[s];
         uint64_t t = e - m.begin;
         if (t >= counts[qi]) continue;
         const QueryMeta Q = qm[qi];
-        uint32_t el = mlist[e];
-        uint64_t first = P[el];
+        uint32_t el = mlist[e];                                // logical element of level 0
+        uint64_t first = P[phys_of(m, el)];
         out_first[Q.out_first + t] = first;
         local += first;
         uint64_t* tp = out_tuples + Q.out_tuple + t * Q.k;
-        for (uint32_t i = 0; i < Q.k; ++i) {
-            tp[i] = P[el];
-            el = link[el];
+        tp[0] = first;
+        uint32_t cur = link[el];
+        for (uint32_t i = 1; i < Q.k; ++i) {
+            const SegMeta mi = sm[s + i];
+            if (mi.dist == 0) { tp[i] = P[cur]; }              // link of a dist-1 element is a physical index
+            else { tp[i] = P[phys_of(mi, cur)]; cur = link[cur]; }
         }
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
@@ -555,64 +598,118 @@ struct Arena {
     }
 };
 
+struct Plan {                       // host view of the batch after backward search
+    std::vector<uint64_t> occ;      // per sub-pattern, 0 for dead queries
+    std::vector<uint32_t> did;      // per sub-pattern: distinct-interval id (valid when occ > 0)
+    std::vector<uint64_t> dl, docc; // per distinct interval: left border, size
+};
+
+constexpr uint64_t kJoinBytesPerSlot = 7 * 4 + 8;     // seg, link, nf, feas, jump, mlist, endp(<=8)
+
+// ---- physical pass: locate + sort every distinct interval used by queries [Q0,Q1) -------------------
 template <typename pos_t>
-vlg_status run_chunk(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result* res, uint64_t q0, uint64_t q1,
-                     const std::vector<uint64_t>& occ /* per sub, 0 for dead queries */, const uint64_t* d_l, uint64_t T,
-                     unsigned long long* d_stats /* [0]=lf,[1]=levels,[2]=checksum */)
+vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* res, const std::vector<uint32_t>& dlist /* distinct ids */,
+                          const Plan& pl, Arena& A, pos_t*& P_out, std::vector<uint32_t>& poff /* per distinct id -> offset (size dl) */,
+                          uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats)
 {
+    hipStream_t st = ws->stream;
+    const uint32_t nd = (uint32_t)dlist.size();
+    std::vector<uint64_t> off64(nd + 1), lh(nd);
+    std::vector<uint32_t> off32(nd + 1);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < nd; ++i) {
+        off64[i] = acc; off32[i] = (uint32_t)acc; lh[i] = pl.dl[dlist[i]];
+        poff[dlist[i]] = (uint32_t)acc;
+        acc += pl.docc[dlist[i]];
+    }
+    off64[nd] = acc; off32[nd] = (uint32_t)acc;
+    Tphys = acc;
+    P_out = nullptr;
+    if (!acc) return VLG_OK;
+    const unsigned bits = bit_width64(idx->hdr.n);
+    pos_t* Pa = A.take<pos_t>(acc);
+    pos_t* Pb = A.take<pos_t>(acc);
+    uint64_t* d_off64 = A.take<uint64_t>(nd + 1);
+    uint32_t* d_off32 = A.take<uint32_t>(nd + 1);
+    uint64_t* d_lh = A.take<uint64_t>(nd);
+    void* d_tmp = A.take<uint8_t>(sort_tmp + 256);
+    if (!d_tmp) return fail(VLG_E_INTERNAL, "arena carve failed (physical)");
+    VLG_HIP_TRY(hipMemcpyAsync(d_off64, off64.data(), (nd + 1) * 8, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_off32, off32.data(), (nd + 1) * 4, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_lh, lh.data(), nd * 8, hipMemcpyHostToDevice, st));
+    {
+        Timed t(ws, KS_EXPAND, 0);
+        if (vlg_status s = launch_expand<pos_t>(d_lh, d_off64, nd, acc, Pa, nullptr, st)) return s;
+    }
+    {
+        Timed t(ws, KS_LOCATE, 0);
+        if (vlg_status s = launch_locate<pos_t>(idx->view, Pa, acc, d_stats, st)) return s;
+    }
+    {   // sort every occurrence list ascending (std::sort, index_sasearch.hpp:80)
+        Timed t(ws, KS_SORT, 2ull * acc * sizeof(pos_t));
+        size_t tb = sort_tmp;
+        VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(d_tmp, tb, Pa, Pb, (unsigned)acc, nd, d_off32, d_off32 + 1, 0, bits, st));
+    }
+    VLG_HIP_TRY(hipStreamSynchronize(st));        // host staging vectors go out of scope
+    P_out = Pb;
+    res->sum.located_occurrences += acc;
+    return VLG_OK;
+}
+
+// ---- join of the queries [q0,q1) against the physical lists -------------------------------------------
+template <typename pos_t>
+vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result* res, uint64_t q0, uint64_t q1,
+                          const Plan& pl, const std::vector<uint32_t>& poff, const pos_t* P, Arena A /* by value: scratch past P */,
+                          unsigned long long* d_stats)
+{
+    (void)idx;
     hipStream_t st = ws->stream;
     const uint64_t s0 = q->qsub[q0], s1 = q->qsub[q1];
     const uint32_t nseg = (uint32_t)(s1 - s0), nq = (uint32_t)(q1 - q0);
     ResultPiece piece;
     piece.q0 = q0; piece.q1 = q1;
-    if (T == 0 || nseg == 0) { res->pieces.push_back(piece); return VLG_OK; }
     // ---- host-side metadata of the chunk ---------------------------------------------------------
     std::vector<SegMeta> sm(nseg + 1);
     std::vector<QueryMeta> qm(nq);
-    std::vector<uint32_t> seg_query(nseg);
-    std::vector<uint64_t> off64(nseg + 1);
+    std::vector<uint32_t> seg_query(nseg + 1, 0), seg_begin(nseg + 2, 0);
     uint32_t kmax = 0;
     uint64_t acc = 0;
     for (uint64_t qi = q0; qi < q1; ++qi) {
         uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
         QueryMeta& Q = qm[qi - q0];
         Q.k = k; Q.end_len = q->end_len[qi]; Q.out_first = Q.out_tuple = 0;
-        bool live = k > 0 && occ[q->qsub[qi]] > 0;
+        bool live = k > 0 && pl.occ[q->qsub[qi]] > 0;
         Q.seg0 = live ? (uint32_t)(q->qsub[qi] - s0) : kNone;
         if (live) kmax = std::max(kmax, k);
         for (uint32_t i = 0; i < k; ++i) {
             uint64_t s = q->qsub[qi] + i;
             SegMeta& m = sm[s - s0];
-            m.begin = (uint32_t)acc;
-            off64[s - s0] = acc;
-            acc += occ[s];
-            m.end = (uint32_t)acc;
             m.level = i; m.dist = k - 1 - i;
             m.lo = q->lo[s]; m.hi = q->hi[s];
+            m.pbegin = m.pend = 0;
+            seg_begin[s - s0] = (uint32_t)acc;
+            m.begin = (uint32_t)acc;
+            if (live) {
+                m.pbegin = poff[pl.did[s]];
+                m.pend = m.pbegin + (uint32_t)pl.occ[s];
+                if (m.dist > 0 || k == 1) acc += pl.occ[s];      // the last list of a k>=2 query needs no join state
+            }
+            m.end = (uint32_t)acc;
             seg_query[s - s0] = (uint32_t)(qi - q0);
         }
     }
-    off64[nseg] = acc;
-    sm[nseg] = SegMeta{(uint32_t)acc, (uint32_t)acc, 0, 0, 0, 0};
-    if (acc != T) return fail(VLG_E_INTERNAL, "chunk size mismatch");
+    const uint64_t T = acc;
+    seg_begin[nseg] = (uint32_t)acc;
+    seg_begin[nseg + 1] = 0xFFFFFFFFu;
+    sm[nseg] = SegMeta{(uint32_t)acc, (uint32_t)acc, 0, 0, 0, 0, 0, 0};
+    if (T == 0 || nseg == 0) { res->pieces.push_back(piece); return VLG_OK; }
     // ---- carve the arena ---------------------------------------------------------------------------
-    size_t sort_tmp = 0, scan_tmp = 0;
+    size_t scan_tmp = 0;
     {
-        pos_t* np = nullptr; uint32_t* nu = nullptr;
-        unsigned bits = bit_width64(idx->hdr.n);
-        VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, np, np, (unsigned)T, nseg, nu, nu, 0, bits, st));
+        uint32_t* nu = nullptr;
         auto rin = rocprim::make_reverse_iterator(nu);
         VLG_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_tmp, rin, rin, T, rocprim::minimum<uint32_t>(), st));
     }
-    uint64_t need = 0;
-    auto add = [&](uint64_t bytes) { need += align_up(bytes, 256); };
-    add(T * sizeof(pos_t)); add(T * sizeof(pos_t)); add(T * 4); add(T * 4); add(T * sizeof(pos_t)); add(T * 4); add(T * 4); add(T * 4); add(T * 4);
-    add((nseg + 1) * sizeof(SegMeta)); add(nq * sizeof(QueryMeta)); add(nseg * 4); add((nseg + 1) * 8); add((nseg + 1) * 4);
-    add(nq * 8); add(std::max(sort_tmp, scan_tmp));
-    if (vlg_status s = ws_reserve(ws, need)) return s;
-    Arena A{ws->arena, ws->arena_bytes};
-    pos_t* P0 = A.take<pos_t>(T);
-    pos_t* P = A.take<pos_t>(T);
     uint32_t* seg = A.take<uint32_t>(T);
     uint32_t* link = A.take<uint32_t>(T);
     pos_t* endp = A.take<pos_t>(T);
@@ -622,46 +719,25 @@ vlg_status run_chunk(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
     uint32_t* mlist = A.take<uint32_t>(T);
     SegMeta* d_sm = A.take<SegMeta>(nseg + 1);
     QueryMeta* d_qm = A.take<QueryMeta>(nq);
-    uint32_t* d_segq = A.take<uint32_t>(nseg);
-    uint64_t* d_off64 = A.take<uint64_t>(nseg + 1);
-    uint32_t* d_off32 = A.take<uint32_t>(nseg + 1);
+    uint32_t* d_segq = A.take<uint32_t>(nseg + 1);
+    uint32_t* d_segb = A.take<uint32_t>(nseg + 2);
     unsigned long long* d_counts = A.take<unsigned long long>(nq);
-    void* d_tmp = A.take<uint8_t>(std::max(sort_tmp, scan_tmp));
-    if (!d_tmp) return fail(VLG_E_INTERNAL, "arena carve failed");
-    std::vector<uint32_t> off32(nseg + 1);
-    for (uint32_t i = 0; i <= nseg; ++i) off32[i] = (uint32_t)off64[i];
+    void* d_tmp = A.take<uint8_t>(scan_tmp + 256);
+    if (!d_tmp) return fail(VLG_E_INTERNAL, "arena carve failed (join)");
     VLG_HIP_TRY(hipMemcpyAsync(d_sm, sm.data(), (nseg + 1) * sizeof(SegMeta), hipMemcpyHostToDevice, st));
-    VLG_HIP_TRY(hipMemcpyAsync(d_segq, seg_query.data(), nseg * 4, hipMemcpyHostToDevice, st));
-    VLG_HIP_TRY(hipMemcpyAsync(d_off64, off64.data(), (nseg + 1) * 8, hipMemcpyHostToDevice, st));
-    VLG_HIP_TRY(hipMemcpyAsync(d_off32, off32.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_segq, seg_query.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_segb, seg_begin.data(), (nseg + 2) * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
-    // ---- locate -------------------------------------------------------------------------------------
-    {
-        Timed t(ws, KS_EXPAND, 0);
-        // NB: segment ids are global sub-pattern ids minus nothing: expand writes p relative to d_l + s0
-        if (vlg_status s = launch_expand<pos_t>(d_l + s0, d_off64, nseg, T, P0, seg, st)) return s;
-    }
-    {
-        Timed t(ws, KS_LOCATE, 0);
-        if (vlg_status s = launch_locate<pos_t>(idx->view, P0, T, d_stats, st)) return s;
-    }
-    // ---- sort every occurrence list ascending (std::sort, index_sasearch.hpp:80) --------------------
-    {
-        Timed t(ws, KS_SORT, 2ull * T * sizeof(pos_t));
-        unsigned bits = bit_width64(idx->hdr.n);
-        size_t tb = sort_tmp;
-        VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(d_tmp, tb, P0, P, (unsigned)T, nseg, d_off32, d_off32 + 1, 0, bits, st));
-    }
-    // ---- join ---------------------------------------------------------------------------------------
     const uint32_t g = grid_for(T);
     {
         Timed t(ws, KS_JOIN_LINK, 0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_init_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, 0u, T, feas, endp, link);
+        hipLaunchKernelGGL(seg_ids_kernel, dim3(grid_for(T, 32768)), dim3(256), 0, st, d_segb, nseg, T, seg);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_init_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, T, feas, endp, link);
     }
     for (uint32_t dist = 1; dist < kmax; ++dist) {
         {
-            Timed t(ws, KS_JOIN_LINK, 0);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, 0u, T, dist, nf, feas, endp, link);
+            Timed t(ws, KS_JOIN_LINK, 8ull * T);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, T, dist, nf, feas, endp, link);
         }
         {
             Timed t(ws, KS_JOIN_SCAN, 8ull * T);
@@ -675,7 +751,7 @@ vlg_status run_chunk(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
     if (kmax <= 1) VLG_HIP_TRY(hipMemcpyAsync(nf, feas, T * 4, hipMemcpyDeviceToDevice, st));   // single sub-patterns: identity
     {
         Timed t(ws, KS_JOIN_CHAIN, 0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, d_qm, d_segq, 0u, T, nf, endp, jump);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, d_qm, d_segq, T, nf, endp, jump);
         hipLaunchKernelGGL(join_chain_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, d_sm, d_qm, nq, nf, jump, mlist, d_counts);
     }
     VLG_HIP_TRY(hipGetLastError());
@@ -696,7 +772,7 @@ vlg_status run_chunk(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         res->pieces.push_back(piece);
         VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
         Timed t(ws, KS_GATHER, 8ull * (M + TV));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, d_qm, d_segq, 0u, T, link, mlist,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, d_qm, d_segq, T, link, mlist,
                            d_counts, piece.d_first, piece.d_tuples, d_stats + 2);
         VLG_HIP_TRY(hipGetLastError());
     } else {
@@ -705,8 +781,91 @@ vlg_status run_chunk(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
     VLG_HIP_TRY(hipStreamSynchronize(st));     // qm / counts host buffers are read by the async copies above
     res->sum.n_matches += M;
     res->sum.n_tuple_values += TV;
-    res->sum.located_occurrences += T;
     res->sum.n_chunks++;
+    return VLG_OK;
+}
+
+// A super-chunk = a run of queries whose distinct occurrence lists fit the physical budget; inside it
+// the queries are joined in chunks bounded by the logical budget.
+template <typename pos_t>
+vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result* res, const Plan& pl,
+                     unsigned long long* d_stats)
+{
+    const uint64_t fixed = 64ull << 20;
+    if (ws->cap_bytes <= 2 * fixed) return fail(VLG_E_WORKSPACE, "workspace cap too small");
+    const uint64_t budget = ws->cap_bytes - fixed;
+    // physical lists take at most half of the budget (two buffers during the sort)
+    const uint64_t phys_cap = std::min<uint64_t>(budget / 2 / (2 * sizeof(pos_t) + 1), 0xFFFFFF00ull);
+    std::vector<uint32_t> stamp(pl.dl.size(), 0xFFFFFFFFu);
+    std::vector<uint32_t> poff(pl.dl.size(), 0);
+    uint64_t Q0 = 0;
+    uint32_t epoch = 0;
+    while (Q0 < q->nq) {
+        // ---- choose the super-chunk ----------------------------------------------------------------
+        std::vector<uint32_t> dlist;
+        uint64_t phys = 0, Q1 = Q0;
+        while (Q1 < q->nq) {
+            uint64_t add = 0;
+            size_t mark = dlist.size();
+            for (uint64_t s = q->qsub[Q1]; s < q->qsub[Q1 + 1]; ++s)
+                if (pl.occ[s] && stamp[pl.did[s]] != epoch) { stamp[pl.did[s]] = epoch; dlist.push_back(pl.did[s]); add += pl.occ[s]; }
+            if (phys + add > phys_cap) {
+                for (size_t i = mark; i < dlist.size(); ++i) stamp[dlist[i]] = 0xFFFFFFFFu;
+                dlist.resize(mark);
+                if (Q1 == Q0)
+                    return fail(VLG_E_WORKSPACE, "query " + std::to_string(Q1) + " needs " + std::to_string(add) +
+                                                     " occurrence slots; workspace cap allows " + std::to_string(phys_cap));
+                break;
+            }
+            phys += add;
+            ++Q1;
+        }
+        ++epoch;
+        // ---- arena: physical lists first, join scratch behind them -----------------------------------
+        uint64_t logical_total = 0, logical_max_query = 0;
+        for (uint64_t qi = Q0; qi < Q1; ++qi) {
+            uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
+            uint64_t t = 0;
+            for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += pl.occ[q->qsub[qi] + i];
+            logical_total += t;
+            logical_max_query = std::max(logical_max_query, t);
+        }
+        size_t sort_tmp = 0;
+        if (phys) {
+            pos_t* np = nullptr; uint32_t* nu = nullptr;
+            VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, np, np, (unsigned)phys, (unsigned)dlist.size(), nu, nu, 0,
+                                                           bit_width64(idx->hdr.n), ws->stream));
+        }
+        const uint64_t phys_bytes = 2 * phys * sizeof(pos_t) + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20);
+        uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
+        uint64_t cap_slots = std::min<uint64_t>(join_budget / kJoinBytesPerSlot, 0xFFFFFF00ull);
+        if (logical_max_query > cap_slots)
+            return fail(VLG_E_WORKSPACE, "a query needs " + std::to_string(logical_max_query) + " join slots; workspace cap allows " +
+                                             std::to_string(cap_slots));
+        uint64_t want_slots = std::min<uint64_t>(logical_total, cap_slots);
+        uint64_t meta = (q->qsub[Q1] - q->qsub[Q0] + 4) * (sizeof(SegMeta) + 16) + (Q1 - Q0 + 4) * (sizeof(QueryMeta) + 16);
+        if (vlg_status s = ws_reserve(ws, phys_bytes + want_slots * kJoinBytesPerSlot + meta + fixed)) return s;
+        Arena A{ws->arena, ws->arena_bytes};
+        pos_t* P = nullptr;
+        uint64_t Tphys = 0;
+        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats)) return s;
+        // ---- join chunks ----------------------------------------------------------------------------
+        uint64_t q0 = Q0;
+        while (q0 < Q1) {
+            uint64_t T = 0, q1 = q0;
+            while (q1 < Q1) {
+                uint32_t k = (uint32_t)(q->qsub[q1 + 1] - q->qsub[q1]);
+                uint64_t t = 0;
+                for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += pl.occ[q->qsub[q1] + i];
+                if ((T + t > want_slots && q1 > q0) || (q1 - q0) >= (1u << 22)) break;
+                T += t;
+                ++q1;
+            }
+            if (vlg_status s = run_join_chunk<pos_t>(idx, q, ws, res, q0, q1, pl, poff, P, A, d_stats)) return s;
+            q0 = q1;
+        }
+        Q0 = Q1;
+    }
     return VLG_OK;
 }
 
@@ -737,43 +896,42 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
             Timed t(ws, KS_BSEARCH, 0);
             if (vlg_status s = launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_l, d_r, d_stats + 3, st)) return s;
         }
-        std::vector<uint64_t> l(nsub), r(nsub), occ(nsub, 0);
+        std::vector<uint64_t> l(nsub), r(nsub);
         if (nsub) {
             VLG_HIP_TRY(hipMemcpyAsync(l.data(), d_l, nsub * 8, hipMemcpyDeviceToHost, st));
             VLG_HIP_TRY(hipMemcpyAsync(r.data(), d_r, nsub * 8, hipMemcpyDeviceToHost, st));
         }
         VLG_HIP_TRY(hipStreamSynchronize(st));
-        // a query with an empty sub-pattern list has no match: none of its lists is materialised
+        // a query with an empty occurrence list has no match: none of its lists is materialised
         // (vlg_index.hpp:315-316 returns at the first empty range)
+        Plan pl;
+        pl.occ.assign(nsub, 0);
+        pl.did.assign(nsub, 0);
         for (uint64_t qi = 0; qi < q->nq; ++qi) {
             bool live = q->qsub[qi + 1] > q->qsub[qi];
             for (uint64_t s = q->qsub[qi]; s < q->qsub[qi + 1] && live; ++s) live = (r[s] + 1 - l[s]) > 0;
-            if (live) for (uint64_t s = q->qsub[qi]; s < q->qsub[qi + 1]; ++s) occ[s] = r[s] + 1 - l[s];
+            if (live) for (uint64_t s = q->qsub[qi]; s < q->qsub[qi + 1]; ++s) pl.occ[s] = r[s] + 1 - l[s];
         }
-        // ---- chunks of whole queries that fit the workspace -----------------------------------------
-        const uint64_t pos_bytes = idx->hdr.sample_bytes;
-        const uint64_t per_occ = 3 * pos_bytes + 6 * 4 + 8;          // arrays of run_chunk + sort temp slack
-        const uint64_t fixed = 64ull << 20;
-        uint64_t cap_occ = ws->cap_bytes > fixed ? (ws->cap_bytes - fixed) / per_occ : 0;
-        cap_occ = std::min<uint64_t>(cap_occ, 0xFFFFFF00ull);
-        uint64_t q0 = 0;
-        while (q0 < q->nq) {
-            uint64_t T = 0, q1 = q0;
-            while (q1 < q->nq) {
-                uint64_t t = 0;
-                for (uint64_t s = q->qsub[q1]; s < q->qsub[q1 + 1]; ++s) t += occ[s];
-                if (t > cap_occ)
-                    return fail(VLG_E_WORKSPACE, "query " + std::to_string(q1) + " needs " + std::to_string(t) +
-                                                     " occurrence slots; workspace cap allows " + std::to_string(cap_occ));
-                if (T + t > cap_occ || (q1 - q0) >= (1u << 24)) break;
-                T += t;
-                ++q1;
+        // identical SA intervals are the same occurrence list: locate + sort each distinct one once per
+        // super-chunk and let every query that uses it share the sorted list.
+        {
+            std::vector<uint64_t> order;
+            order.reserve(nsub);
+            for (uint64_t s = 0; s < nsub; ++s) if (pl.occ[s]) { order.push_back(s); res->sum.logical_occurrences += pl.occ[s]; }
+            if (ws->dedup) {
+                std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return l[a] != l[b] ? l[a] < l[b] : r[a] < r[b]; });
+                for (size_t i = 0; i < order.size(); ++i) {
+                    uint64_t s = order[i];
+                    if (i == 0 || l[s] != l[order[i - 1]] || r[s] != r[order[i - 1]]) { pl.dl.push_back(l[s]); pl.docc.push_back(pl.occ[s]); }
+                    pl.did[s] = (uint32_t)(pl.dl.size() - 1);
+                }
+            } else {
+                for (uint64_t s : order) { pl.did[s] = (uint32_t)pl.dl.size(); pl.dl.push_back(l[s]); pl.docc.push_back(pl.occ[s]); }
             }
-            vlg_status s = (pos_bytes == 4) ? run_chunk<uint32_t>(idx, q, ws, res, q0, q1, occ, d_l, T, d_stats)
-                                            : run_chunk<uint64_t>(idx, q, ws, res, q0, q1, occ, d_l, T, d_stats);
-            if (s) return s;
-            q0 = q1;
         }
+        const uint64_t pos_bytes = idx->hdr.sample_bytes;
+        vlg_status s = (pos_bytes == 4) ? run_batch<uint32_t>(idx, q, ws, res, pl, d_stats) : run_batch<uint64_t>(idx, q, ws, res, pl, d_stats);
+        if (s) return s;
         unsigned long long hs[4];
         VLG_HIP_TRY(hipMemcpyAsync(hs, d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
         VLG_HIP_TRY(hipStreamSynchronize(st));

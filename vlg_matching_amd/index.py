@@ -83,6 +83,9 @@ class Workspace:
         except Exception:
             pass
 
+    def set_option(self, name, value):
+        check(lib().vlg_workspace_set_option(self._h, name.encode(), int(value)))
+
     def profile(self, enable=True):
         check(lib().vlg_workspace_profile(self._h, 1 if enable else 0))
 
