@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink text and batch (development only)")
-    ap.add_argument("--workspace-gb", type=float, default=48.0)
+    ap.add_argument("--workspace-gb", type=float, default=160.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -492,62 +492,126 @@ __global__ void join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __
     }
 }
 
-// jump[e] for level-0 elements: first feasible element of list 0 at or after end(e)+end_len
+// jump[e] for level-0 elements: first feasible element of list 0 at or after end(e)+end_len (kNone = none);
+// slots of other levels get kNone so the tile pass can treat every slot alike.  Also the start of each chain.
 template <typename pos_t>
 __global__ void join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
                                  const QueryMeta* __restrict__ qm, const uint32_t* __restrict__ seg_query, uint64_t total,
-                                 const uint32_t* __restrict__ nf, const pos_t* __restrict__ endp, uint32_t* __restrict__ jump)
+                                 const uint32_t* __restrict__ nf, const pos_t* __restrict__ endp, uint32_t* __restrict__ jump,
+                                 uint32_t* __restrict__ qstart)
 {
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t s = seg[e];
         const SegMeta m = sm[s];
-        if (m.level != 0) continue;
-        uint32_t out = m.end;
-        if (nf[e] == (uint32_t)e) {                           // feasible start
-            uint64_t lim = sat_add((uint64_t)endp[e], qm[seg_query[s]].end_len);
-            uint32_t jp = lower_bound_dev(P, phys_of(m, (uint32_t)e) + 1, m.pend, lim);
-            if (jp < m.pend) {
-                uint32_t ej = nf[m.begin + (jp - m.pbegin)];
-                out = ej < m.end ? ej : m.end;
+        uint32_t out = kNone;
+        if (m.level == 0) {
+            uint32_t me = nf[e];
+            if (me == (uint32_t)e) {                          // feasible start
+                uint64_t lim = sat_add((uint64_t)endp[e], qm[seg_query[s]].end_len);
+                uint32_t jp = lower_bound_dev(P, phys_of(m, (uint32_t)e) + 1, m.pend, lim);
+                if (jp < m.pend) {
+                    uint32_t ej = nf[m.begin + (jp - m.pbegin)];
+                    if (ej < m.end) out = ej;
+                }
             }
+            if ((uint32_t)e == m.begin) qstart[seg_query[s]] = me < m.end ? me : kNone;
         }
         jump[e] = out;
     }
 }
 
-// One wavefront per query: hop along list 0.  A window of 64 consecutive jump targets is fetched with
-// one coalesced load; hops that stay inside the window are resolved through cross-lane reads.
-__global__ void __launch_bounds__(256) join_chain_kernel(const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint32_t nq,
-                                                         const uint32_t* __restrict__ nf, const uint32_t* __restrict__ jump,
-                                                         uint32_t* __restrict__ mlist, unsigned long long* __restrict__ counts)
+// The chain a -> jump[a] -> ... of a query is resolved in three data-parallel passes instead of one serial walk:
+//   tiles : inside every tile of kTile slots, pointer doubling in LDS gives each slot its exit (first chain
+//           element beyond the tile) and the number of chain elements it covers inside the tile;
+//   walk  : one lane per query hops tile to tile (a heavy query costs |list|/kTile dependent loads, not |matches|),
+//           leaving one record per tile visited and the query's match count;
+//   emit  : one lane per record lists the matches inside its tile.
+constexpr uint32_t kTile = 1024;
+constexpr uint32_t kTerm = 0xFFFFu;
+
+__global__ void __launch_bounds__(256) chain_tiles_kernel(const uint32_t* __restrict__ jump, uint64_t total, uint2* __restrict__ xh)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    __shared__ uint32_t s_ext[kTile];
+    __shared__ uint16_t s_nxt[kTile];
+    __shared__ uint16_t s_hop[kTile];
+    const uint64_t base = (uint64_t)blockIdx.x * kTile;
+    const uint64_t tile_end = base + kTile;
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+        uint32_t li = threadIdx.x + 256 * r;
+        uint64_t e = base + li;
+        uint32_t j = e < total ? jump[e] : kNone;
+        bool inside = j != kNone && (uint64_t)j < tile_end;
+        s_ext[li] = j;                                   // exit if it leaves the tile (or kNone)
+        s_nxt[li] = inside ? (uint16_t)(j - base) : (uint16_t)kTerm;
+        s_hop[li] = 1;
+    }
+    __syncthreads();
+    for (uint32_t round = 0; round < 10; ++round) {        // jump[e] > e, so chains inside a tile are shorter than 2^10
+        uint32_t nn[4], hh[4], ee[4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            uint32_t li = threadIdx.x + 256 * r;
+            uint32_t n = s_nxt[li];
+            nn[r] = n; hh[r] = s_hop[li]; ee[r] = s_ext[li];
+            if (n != kTerm) { hh[r] += s_hop[n]; ee[r] = s_ext[n]; nn[r] = s_nxt[n]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            uint32_t li = threadIdx.x + 256 * r;
+            s_nxt[li] = (uint16_t)nn[r]; s_hop[li] = (uint16_t)hh[r]; s_ext[li] = ee[r];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+        uint32_t li = threadIdx.x + 256 * r;
+        uint64_t e = base + li;
+        if (e < total) xh[e] = make_uint2(s_ext[li], (uint32_t)s_hop[li]);
+    }
+}
+
+__global__ void chain_walk_kernel(const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint32_t nq,
+                                  const uint32_t* __restrict__ qstart, const uint2* __restrict__ xh, const uint32_t* __restrict__ rec_begin,
+                                  uint2* __restrict__ records, uint32_t* __restrict__ rec_count, unsigned long long* __restrict__ counts)
+{
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const QueryMeta Q = qm[q];
     unsigned long long n_match = 0;
+    uint32_t nrec = 0;
     if (Q.seg0 != kNone) {
-        const SegMeta m = sm[Q.seg0];
-        uint32_t cur = m.begin < m.end ? nf[m.begin] : m.end;
-        if (cur > m.end) cur = m.end;
-        while (cur < m.end) {                                   // wave-uniform loop
-            uint32_t idx = cur + lane;
-            uint32_t jv = idx < m.end ? jump[idx] : m.end;      // window [cur, cur+64)
-            uint32_t wbase = cur;
-            uint32_t pend = 0;                                  // match held by this lane for a coalesced store
-            uint32_t npend = 0;
-            for (;;) {                                          // every lane runs the same scalar walk
-                if (lane == npend) pend = cur;
-                ++npend;
-                uint32_t nxt = __shfl(jv, (int)(cur - wbase));
-                cur = nxt;
-                if (cur >= m.end || cur - wbase >= 64 || npend == 64) break;
-            }
-            if (lane < npend) mlist[m.begin + n_match + lane] = pend;
-            n_match += npend;
+        const uint32_t mbegin = sm[Q.seg0].begin;
+        uint2* rec = records + rec_begin[q];
+        uint32_t cur = qstart[q];
+        while (cur != kNone) {
+            uint2 v = xh[cur];
+            rec[nrec++] = make_uint2(cur, mbegin + (uint32_t)n_match);
+            n_match += v.y;
+            cur = v.x;
         }
     }
-    if (lane == 0) counts[q] = n_match;
+    rec_count[q] = nrec;
+    counts[q] = n_match;
+}
+
+__global__ void chain_emit_kernel(uint32_t nq, const uint32_t* __restrict__ rec_begin, const uint32_t* __restrict__ rec_count,
+                                  const uint2* __restrict__ records, uint32_t total_rec_slots, const uint32_t* __restrict__ rec_query,
+                                  const uint32_t* __restrict__ jump, uint32_t* __restrict__ mlist)
+{
+    (void)nq;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < total_rec_slots; r += gridDim.x * blockDim.x) {
+        uint32_t q = rec_query[r];                       // slot r belongs to query q; used only if r - rec_begin[q] < rec_count[q]
+        if (r - rec_begin[q] >= rec_count[q]) continue;
+        uint2 rc = records[r];
+        uint32_t cur = rc.x, out = rc.y;
+        const uint32_t tile_end = (cur / kTile + 1) * kTile;
+        while (cur != kNone && cur < tile_end) {
+            mlist[out++] = cur;
+            cur = jump[cur];
+        }
+    }
 }
 
 // tuples of every match: walk the links from the level-0 element
@@ -604,7 +668,7 @@ struct Plan {                       // host view of the batch after backward sea
     std::vector<uint64_t> dl, docc; // per distinct interval: left border, size
 };
 
-constexpr uint64_t kJoinBytesPerSlot = 7 * 4 + 8;     // seg, link, nf, feas, jump, mlist, endp(<=8)
+constexpr uint64_t kJoinBytesPerSlot = 7 * 4 + 8 + 1; // seg, link, nf, feas, jump, mlist, endp(<=8), chain records
 
 // ---- physical pass: locate + sort every distinct interval used by queries [Q0,Q1) -------------------
 template <typename pos_t>
@@ -713,8 +777,10 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     uint32_t* seg = A.take<uint32_t>(T);
     uint32_t* link = A.take<uint32_t>(T);
     pos_t* endp = A.take<pos_t>(T);
-    uint32_t* nf = A.take<uint32_t>(T);
-    uint32_t* feas = A.take<uint32_t>(T);
+    const uint64_t Tal = align_up(T, 64);
+    uint32_t* fn = A.take<uint32_t>(2 * Tal);            // feas | nf; reused as the (exit, hops) pairs of the chain tiles
+    uint32_t* feas = fn;
+    uint32_t* nf = fn ? fn + Tal : nullptr;
     uint32_t* jump = A.take<uint32_t>(T);
     uint32_t* mlist = A.take<uint32_t>(T);
     SegMeta* d_sm = A.take<SegMeta>(nseg + 1);
@@ -722,8 +788,28 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     uint32_t* d_segq = A.take<uint32_t>(nseg + 1);
     uint32_t* d_segb = A.take<uint32_t>(nseg + 2);
     unsigned long long* d_counts = A.take<unsigned long long>(nq);
+    // chain records: one per tile a level-0 list overlaps (upper bound of the tiles its chain can visit)
+    std::vector<uint32_t> rec_begin(nq + 1, 0), rec_query;
+    for (uint32_t i = 0; i < nq; ++i) {
+        uint32_t cnt = 0;
+        if (qm[i].seg0 != kNone) {
+            const SegMeta& m0 = sm[qm[i].seg0];
+            if (m0.end > m0.begin) cnt = (m0.end - 1) / kTile - m0.begin / kTile + 1;
+        }
+        rec_begin[i + 1] = rec_begin[i] + cnt;
+        rec_query.insert(rec_query.end(), cnt, i);
+    }
+    const uint32_t n_rec = rec_begin[nq];
+    uint32_t* d_qstart = A.take<uint32_t>(nq);
+    uint32_t* d_recb = A.take<uint32_t>(nq + 1);
+    uint32_t* d_recc = A.take<uint32_t>(nq);
+    uint32_t* d_recq = A.take<uint32_t>(n_rec + 1);
+    uint2* d_rec = A.take<uint2>(n_rec + 1);
     void* d_tmp = A.take<uint8_t>(scan_tmp + 256);
     if (!d_tmp) return fail(VLG_E_INTERNAL, "arena carve failed (join)");
+    VLG_HIP_TRY(hipMemcpyAsync(d_recb, rec_begin.data(), (nq + 1) * 4, hipMemcpyHostToDevice, st));
+    if (n_rec) VLG_HIP_TRY(hipMemcpyAsync(d_recq, rec_query.data(), n_rec * 4, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemsetAsync(d_qstart, 0xFF, nq * 4, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_sm, sm.data(), (nseg + 1) * sizeof(SegMeta), hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_segq, seg_query.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_segb, seg_begin.data(), (nseg + 2) * 4, hipMemcpyHostToDevice, st));
@@ -751,8 +837,15 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     if (kmax <= 1) VLG_HIP_TRY(hipMemcpyAsync(nf, feas, T * 4, hipMemcpyDeviceToDevice, st));   // single sub-patterns: identity
     {
         Timed t(ws, KS_JOIN_CHAIN, 0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, d_qm, d_segq, T, nf, endp, jump);
-        hipLaunchKernelGGL(join_chain_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, d_sm, d_qm, nq, nf, jump, mlist, d_counts);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, d_qm, d_segq, T, nf, endp, jump,
+                           d_qstart);
+        uint2* xh = reinterpret_cast<uint2*>(fn);           // feas / nf are dead from here on
+        hipLaunchKernelGGL(chain_tiles_kernel, dim3((uint32_t)((T + kTile - 1) / kTile)), dim3(256), 0, st, jump, T, xh);
+        hipLaunchKernelGGL(chain_walk_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, d_sm, d_qm, nq, d_qstart, xh, d_recb, d_rec, d_recc,
+                           d_counts);
+        if (n_rec)
+            hipLaunchKernelGGL(chain_emit_kernel, dim3(grid_for(n_rec)), dim3(256), 0, st, nq, d_recb, d_recc, d_rec, n_rec, d_recq, jump,
+                               mlist);
     }
     VLG_HIP_TRY(hipGetLastError());
     // ---- sizes of the result, then gather -------------------------------------------------------------
