@@ -272,3 +272,30 @@ def test_search_chunked_equals_unchunked(V):
     fa, fb = a.fetch(), b.fetch()
     for x, y in zip(fa, fb):
         assert (x == y).all()
+
+
+@pytest.mark.parametrize("name,seed", [("dna_50k", 21), ("zipf40", 22), ("100a", 23)])
+def test_locate_sorted_sweep_equals_random_access_kernel(V, oracle, name, seed):
+    """The sorted LF sweep (K3s) and the persistent random-access kernel (K3) must agree with each other and the oracle,
+    including LF-step and tree-level counts (the algorithmic-bytes accounting)."""
+    from vlg_matching_amd.index import Workspace
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    qs = random_queries(text, np.random.default_rng(seed), 300, kmax=4, mmax=4)
+    ws_a, ws_b = Workspace(), Workspace()
+    for ws in (ws_a, ws_b):
+        ws.set_option("dedup", 0)
+    ws_a.set_option("sweep", 0)
+    ws_b.set_option("sweep_min", 1)
+    ws_b.set_option("sweep_tail", 100)
+    a, b = idx.search(qs, workspace=ws_a), idx.search(qs, workspace=ws_b)
+    for k in ("n_matches", "checksum", "located_occurrences", "lf_steps", "wt_levels_locate"):
+        assert a.summary[k] == b.summary[k], k
+    for x, y in zip(a.fetch(), b.fetch()):
+        assert (x == y).all()
+    occ = np.zeros(4, dtype=np.uint64)
+    for i, q in enumerate(qs):
+        assert b.tuples(i).tolist() == o.search(q, stats=occ).tolist()
+    assert b.summary["lf_steps"] == int(occ[1]) and b.summary["wt_levels_locate"] == int(occ[2])
+    assert "locate_partition" in ws_b.kernel_stats() and ws_b.kernel_stats()["locate_partition"]["launches"] > 0

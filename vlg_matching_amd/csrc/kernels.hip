@@ -5,6 +5,7 @@
 #include "common.hpp"
 #include "device_rank.hpp"
 #include "kernels.hpp"
+#include <rocprim/rocprim.hpp>
 
 using namespace vlg;
 
@@ -324,6 +325,133 @@ __global__ void expand_kernel(const uint64_t* __restrict__ l, const uint64_t* __
     }
 }
 
+// =============================================================================================
+// K3s: locate as a synchronous SORTED SWEEP (n <= 2^32).
+//
+// All occurrences advance one LF step per round.  The round's elements are kept in ascending SA-index order:
+// LF restricted to one symbol is monotone (LF(i) = C[c] + rank_c(i)), so after a round a STABLE partition of the
+// elements by the symbol they read restores the order -- no comparison sort.  With ascending positions the 64
+// lanes of a wave read the same or neighbouring super-blocks at every level of the tree (coalesced loads instead
+// of 64 unrelated 64-byte requests), which is what lifts the kernel off the random-access wall of HBM
+// (tools/k1_bench.py: ~50 G random ranks/s vs ~280 G sorted ranks/s).
+// An element leaves the sweep when it reaches a sampled SA index (csa_sampling_strategy.hpp:102-111).
+// val = slot << 32 | position;  key = comp of the symbol read, or sigma for "finished".
+// =============================================================================================
+__global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t total,
+                                  uint64_t* __restrict__ val)
+{
+    __shared__ uint64_t s_first;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256; base < total; base += (uint64_t)gridDim.x * 256) {
+        if (threadIdx.x == 0) {
+            uint64_t lo = 0, hi = n_pat;
+            while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (out_off[mid] <= base) lo = mid; else hi = mid; }
+            s_first = lo;
+        }
+        __syncthreads();
+        uint64_t t = base + threadIdx.x;
+        if (t < total) {
+            uint64_t p = s_first;
+            while (out_off[p + 1] <= t) ++p;
+            val[t] = (t << 32) | (uint32_t)(l[p] + (t - out_off[p]));
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count,
+                                                         uint32_t step, uint32_t* __restrict__ out,
+                                                         unsigned long long* __restrict__ stats /* lf, levels */,
+                                                         unsigned long long* __restrict__ n_done)
+{
+    __shared__ TreeLds s;
+    stage_tree(s, iv);
+    const uint32_t dens = iv.dens;
+    const bool pow2 = (dens & (dens - 1)) == 0;
+    const uint32_t dmask = dens - 1;
+    const uint32_t dshift = 31 - __clz(dens);
+    const uint32_t* samples = reinterpret_cast<const uint32_t*>(iv.samples);
+    uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v64 = val[e];
+        uint32_t i = (uint32_t)v64;
+        bool sampled = pow2 ? ((i & dmask) == 0) : (i % dens == 0);
+        if (sampled) {
+            uint32_t q = pow2 ? (i >> dshift) : (i / dens);
+            uint64_t r = (uint64_t)samples[q] + step;
+            if (r >= iv.n) r -= iv.n;                        // csa_wt.hpp:343-347
+            out[(uint32_t)(v64 >> 32)] = (uint32_t)r;
+            key[e] = (uint16_t)iv.sigma;
+            ++n_fin;
+        } else {
+            uint32_t v = 0, c;
+            uint64_t pos = i;
+            for (;;) {                                       // inverse_select: wt_pc.hpp:385-402
+                const DNode nd = s.nodes[v];
+                uint32_t blk, o;
+                split224(pos, blk, o);
+                BlockRegs R = load_block(iv.blocks, nd.base + blk);
+                uint32_t bit = block_bit(R, o);
+                uint64_t r1 = block_rank(R, o);
+                ++n_lv;
+                pos = bit ? r1 : pos - r1;
+                uint32_t ch = nd.child[bit];
+                if (ch & kLeafFlag) { c = ch & ~kLeafFlag; break; }
+                v = ch;
+            }
+            ++n_lf;
+            val[e] = (v64 & 0xFFFFFFFF00000000ull) | (uint32_t)(s.C[c] + pos);    // LF: suffix_array_helper.hpp:341-348
+            key[e] = (uint16_t)c;
+        }
+    }
+    unsigned long long a = n_lf, b = n_lv, d = n_fin;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); d += __shfl_down(d, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(&stats[0], a);
+        if (b) atomicAdd(&stats[1], b);
+        if (d) atomicAdd(n_done, d);
+    }
+}
+
+// stragglers: finish the few elements still alive after the sweep, one lane each
+__global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uint64_t* __restrict__ val, uint64_t count, uint32_t step,
+                                                         uint32_t* __restrict__ out, unsigned long long* __restrict__ stats)
+{
+    __shared__ TreeLds s;
+    stage_tree(s, iv);
+    const uint32_t dens = iv.dens;
+    const uint32_t* samples = reinterpret_cast<const uint32_t*>(iv.samples);
+    uint32_t n_lv = 0, n_lf = 0;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v64 = val[e];
+        uint64_t i = (uint32_t)v64;
+        uint64_t off = step;
+        while (i % dens) {
+            uint32_t v = 0;
+            uint64_t pos = i;
+            for (;;) {
+                const DNode nd = s.nodes[v];
+                uint32_t blk, o;
+                split224(pos, blk, o);
+                BlockRegs R = load_block(iv.blocks, nd.base + blk);
+                uint32_t bit = block_bit(R, o);
+                uint64_t r1 = block_rank(R, o);
+                ++n_lv;
+                pos = bit ? r1 : pos - r1;
+                uint32_t ch = nd.child[bit];
+                if (ch & kLeafFlag) { i = s.C[ch & ~kLeafFlag] + pos; break; }
+                v = ch;
+            }
+            ++off; ++n_lf;
+        }
+        uint64_t r = (uint64_t)samples[i / dens] + off;
+        if (r >= iv.n) r -= iv.n;
+        out[(uint32_t)(v64 >> 32)] = (uint32_t)r;
+    }
+    unsigned long long a = n_lf, b = n_lv;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+    if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&stats[0], a); if (b) atomicAdd(&stats[1], b); }
+}
+
 template <typename pos_t>
 __global__ void widen_kernel(const pos_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t count)
 {
@@ -383,6 +511,60 @@ vlg_status launch_locate(const IndexView& iv, pos_t* d_io, uint64_t total, unsig
 }
 template vlg_status launch_locate<uint32_t>(const IndexView&, uint32_t*, uint64_t, unsigned long long*, hipStream_t);
 template vlg_status launch_locate<uint64_t>(const IndexView&, uint64_t*, uint64_t, unsigned long long*, hipStream_t);
+
+
+size_t sweep_temp_bytes(uint64_t total, uint32_t sigma, hipStream_t stream)
+{
+    size_t tb = 0;
+    uint16_t* k = nullptr; uint64_t* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tb, k, k, v, v, total, 0, bit_width64(sigma), stream);
+    return tb;
+}
+
+// d_l / d_out_off: SA interval starts and output offsets of the n_pat lists; d_out receives SA values (unsorted, SA order).
+// Scratch (caller-provided): val_a, val_b (total u64 each), key_a, key_b (total u16 each), temp (sweep_temp_bytes), counter (8 B, zeroed here).
+vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
+                               uint32_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
+                               size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
+                               hipStream_t stream, LaunchTimer* timer)
+{
+    if (!total) return VLG_OK;
+    hipLaunchKernelGGL(sweep_init_kernel, dim3(grid_for(total, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat, total, val_a);
+    VLG_HIP_TRY(hipGetLastError());
+    const unsigned bits = bit_width64(iv.sigma);            // keys 0..sigma (sigma = finished, sorts last)
+    uint64_t alive = total;
+    uint32_t step = 0;
+    unsigned long long scratch_stats[2];
+    (void)scratch_stats;
+    while (alive > tail_threshold) {
+        VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
+        if (timer) timer->begin(0);
+        hipLaunchKernelGGL(sweep_step_kernel, dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, key_a, alive, step, d_out,
+                           d_stats, d_counter);
+        if (timer) timer->end(0);
+        VLG_HIP_TRY(hipGetLastError());
+        size_t tb = temp_bytes;
+        if (timer) timer->begin(1);
+        hipError_t se = rocprim::radix_sort_pairs(temp, tb, key_a, key_b, val_a, val_b, alive, 0, bits, stream);
+        if (timer) timer->end(1);
+        VLG_HIP_TRY(se);
+        unsigned long long done = 0;
+        VLG_HIP_TRY(hipMemcpyAsync(&done, d_counter, 8, hipMemcpyDeviceToHost, stream));
+        VLG_HIP_TRY(hipStreamSynchronize(stream));
+        std::swap(val_a, val_b);
+        std::swap(key_a, key_b);
+        alive -= done;
+        ++step;
+        if (step > 1u << 20) return fail(VLG_E_INTERNAL, "locate sweep did not converge");
+    }
+    if (alive) {
+        if (timer) timer->begin(0);
+        hipLaunchKernelGGL(sweep_tail_kernel, dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, alive, step, d_out, d_stats);
+        if (timer) timer->end(0);
+        VLG_HIP_TRY(hipGetLastError());
+    }
+    return VLG_OK;
+}
 
 }  // namespace vlg
 

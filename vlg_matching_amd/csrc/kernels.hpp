@@ -12,4 +12,17 @@ vlg_status launch_expand(const uint64_t* d_l, const uint64_t* d_out_off, uint64_
 template <typename pos_t>
 vlg_status launch_locate(const IndexView& iv, pos_t* d_io, uint64_t total, unsigned long long* d_stats, hipStream_t stream);
 
+// Optional per-launch timing hooks (HIP events on the stream), implemented by the workspace.
+struct LaunchTimer {
+    virtual ~LaunchTimer() {}
+    virtual void begin(int which) = 0;     // which: 0 = LF step kernel, 1 = stable partition by symbol
+    virtual void end(int which) = 0;
+};
+
+size_t sweep_temp_bytes(uint64_t total, uint32_t sigma, hipStream_t stream);
+vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
+                               uint32_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
+                               size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
+                               hipStream_t stream, LaunchTimer* timer);
+
 }  // namespace vlg

@@ -221,8 +221,8 @@ extern "C" void vlg_queries_destroy(vlg_queries* q)
 // =============================================================================================
 // Workspace
 // =============================================================================================
-enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_SORT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_COUNT };
-static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "sort", "join_link", "join_scan", "join_chain", "gather"};
+enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_LOCATE_PART, KS_SORT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_COUNT };
+static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "locate_partition", "sort", "join_link", "join_scan", "join_chain", "gather"};
 
 struct vlg_workspace {
     hipStream_t stream = nullptr;
@@ -231,6 +231,9 @@ struct vlg_workspace {
     uint64_t arena_bytes = 0;
     bool profile = false;
     bool dedup = true;
+    bool sweep = true;          // sorted-sweep locate (n <= 2^32) instead of the random-access persistent kernel
+    uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
+    uint64_t sweep_tail = 1ull << 20;   // stragglers of a sweep are finished one lane each
     vlg_kernel_stat stats[KS_COUNT];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KS_COUNT];
     std::vector<hipEvent_t> free_events;
@@ -255,6 +258,23 @@ struct Timed {      // RAII: HIP events around one launch (or one library call) 
         if (ws->profile) { a = ws_event(ws); b = ws_event(ws); if (a) (void)hipEventRecord(a, ws->stream); }
     }
     ~Timed() { if (a && b) { (void)hipEventRecord(b, ws->stream); ws->pending[k].emplace_back(a, b); } }
+};
+
+struct SweepTimer : LaunchTimer {      // one event pair per launch of the sweep, accounted per kernel class
+    vlg_workspace* ws; hipEvent_t a = nullptr, b = nullptr;
+    explicit SweepTimer(vlg_workspace* w) : ws(w) {}
+    void begin(int which) override
+    {
+        int k = which == 0 ? KS_LOCATE : KS_LOCATE_PART;
+        ws->stats[k].launches++;
+        a = b = nullptr;
+        if (ws->profile) { a = ws_event(ws); b = ws_event(ws); if (a) (void)hipEventRecord(a, ws->stream); }
+    }
+    void end(int which) override
+    {
+        int k = which == 0 ? KS_LOCATE : KS_LOCATE_PART;
+        if (a && b) { (void)hipEventRecord(b, ws->stream); ws->pending[k].emplace_back(a, b); }
+    }
 };
 
 void ws_collect(vlg_workspace* ws)
@@ -326,6 +346,9 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
 {
     if (!ws || !name) return fail(VLG_E_INVALID, "null argument");
     if (!strcmp(name, "dedup")) { ws->dedup = value != 0; return VLG_OK; }
+    if (!strcmp(name, "sweep")) { ws->sweep = value != 0; return VLG_OK; }
+    if (!strcmp(name, "sweep_min")) { ws->sweep_min = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "sweep_tail")) { ws->sweep_tail = (uint64_t)value; return VLG_OK; }
     return fail(VLG_E_INVALID, std::string("unknown workspace option ") + name);
 }
 
@@ -402,11 +425,15 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 // Occurrence lists are PHYSICAL: one sorted list per distinct SA interval of the batch, shared by every
 // query that uses the sub-pattern.  Join state (link / end / feasibility ...) is LOGICAL: one slot per
 // element of every (query, level) whose level is not the query's last one (the last list is only searched).
-struct SegMeta {            // one per sub-pattern of the chunk (device array)
+// Logical slots are laid out class-major: all segments with the same `dist` (sub-patterns after them in their
+// query) are contiguous, so every pass of the join streams exactly the slots it works on.
+struct SegMeta {            // one per sub-pattern of the chunk (device array, class-major order)
     uint32_t begin, end;    // logical slots (begin == end for the last level of a k>=2 query)
     uint32_t pbegin, pend;  // physical list inside P
     uint32_t dist;          // sub-patterns after it in its query (0 = last)
     uint32_t level;         // index inside the query (0 = first)
+    uint32_t next;          // segment of the query's next sub-pattern (valid when dist > 0)
+    uint32_t query;         // query of the chunk
     uint64_t lo, hi;        // gap bounds between the previous sub-pattern and this one
 };
 
@@ -431,8 +458,33 @@ __device__ __forceinline__ uint32_t lower_bound_dev(const pos_t* __restrict__ P,
     return a;
 }
 
+// Lower bound for 64 consecutive slots at once.  When the whole wave works on one segment its keys ascend
+// with the lane, so the answers lie between the answers of lane 0 and lane 63: two full searches bracket the
+// range and the other lanes finish inside it (a handful of probes instead of log2 |list|).
+template <typename pos_t>
+__device__ __forceinline__ uint32_t lower_bound_wave(const pos_t* __restrict__ P, uint32_t a, uint32_t b, uint64_t key, bool active,
+                                                     uint32_t seg_id)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long act = __ballot(active);
+    bool uniform = false;
+    uint32_t first = 0, last = 0;
+    if (act) {
+        first = (uint32_t)__ffsll((long long)act) - 1;
+        last = 63u - (uint32_t)__clzll((long long)act);
+        uint32_t s0 = __shfl(seg_id, (int)first), s1 = __shfl(seg_id, (int)last);
+        uniform = (s0 == s1) && (last - first >= 8);
+    }
+    if (!uniform) return active ? lower_bound_dev(P, a, b, key) : a;
+    uint32_t r = a;
+    if (active && (lane == first || lane == last)) r = lower_bound_dev(P, a, b, key);
+    uint32_t rlo = __shfl(r, (int)first), rhi = __shfl(r, (int)last);
+    if (active && lane != first && lane != last) r = lower_bound_dev(P, rlo, rhi, key);
+    return r;
+}
+
 // seg[t] = segment owning logical slot t (tile of 256 slots, one binary search per tile)
-__global__ void seg_ids_kernel(const uint32_t* __restrict__ seg_begin /* [nseg+1], non-decreasing */, uint32_t nseg, uint64_t total,
+__global__ void seg_ids_kernel(const uint32_t* __restrict__ seg_begin /* [nseg+2], non-decreasing */, uint32_t nseg, uint64_t total,
                                uint32_t* __restrict__ seg)
 {
     __shared__ uint32_t s_first;
@@ -453,33 +505,43 @@ __global__ void seg_ids_kernel(const uint32_t* __restrict__ seg_begin /* [nseg+1
     }
 }
 
-// single-sub-pattern queries: every element is a feasible chain that ends at itself
+// single-sub-pattern queries (class dist 0): every element is a feasible chain that ends at itself
 template <typename pos_t>
 __global__ void join_init_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
-                                 uint64_t total, uint32_t* __restrict__ feas, pos_t* __restrict__ endp, uint32_t* __restrict__ link)
+                                 uint64_t r0, uint64_t r1, uint32_t* __restrict__ feas, pos_t* __restrict__ endp)
 {
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t e = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < r1; e += (uint64_t)gridDim.x * blockDim.x) {
         const SegMeta m = sm[seg[e]];
-        if (m.dist == 0) { feas[e] = (uint32_t)e; endp[e] = P[phys_of(m, (uint32_t)e)]; }
-        else feas[e] = kNone;          // not known yet
-        link[e] = kNone;
+        feas[e] = (uint32_t)e;
+        endp[e] = P[phys_of(m, (uint32_t)e)];
     }
 }
 
-// link pass for the elements with `dist` sub-patterns after them
+// link pass over the class [r0,r1) of slots that have `dist` sub-patterns after them
 template <typename pos_t>
-__global__ void join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
-                                 uint64_t total, uint32_t dist, const uint32_t* __restrict__ nf_in, uint32_t* __restrict__ feas_out,
-                                 pos_t* __restrict__ endp, uint32_t* __restrict__ link)
+__global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg,
+                                                        const SegMeta* __restrict__ sm, uint64_t r0, uint64_t r1, uint32_t dist,
+                                                        const uint32_t* __restrict__ nf_in, uint32_t* __restrict__ feas_out,
+                                                        pos_t* __restrict__ endp, uint32_t* __restrict__ link)
 {
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t s = seg[e];
-        const SegMeta m = sm[s];
-        if (m.dist != dist) continue;
-        const SegMeta nx = sm[s + 1];
-        uint64_t x = P[phys_of(m, (uint32_t)e)];
-        uint64_t tlo = sat_add(x, nx.lo), thi = sat_add(x, nx.hi);
-        uint32_t j = lower_bound_dev(P, nx.pbegin, nx.pend, tlo);     // physical index in the next list
+    const uint64_t span = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = r0 + (uint64_t)blockIdx.x * blockDim.x; base < r1; base += span) {   // wave-uniform trip count
+        const uint64_t e = base + threadIdx.x;
+        const bool active = e < r1;
+        uint32_t s = 0;
+        SegMeta m, nx;
+        uint64_t tlo = 0, thi = 0;
+        uint32_t a = 0, b = 0;
+        if (active) {
+            s = seg[e];
+            m = sm[s];
+            nx = sm[m.next];
+            uint64_t x = P[phys_of(m, (uint32_t)e)];
+            tlo = sat_add(x, nx.lo); thi = sat_add(x, nx.hi);
+            a = nx.pbegin; b = nx.pend;
+        }
+        uint32_t j = lower_bound_wave(P, a, b, tlo, active, s);      // physical index in the next list
+        if (!active) continue;
         bool ok = false;
         if (dist == 1) {                                              // next list is the last one: every element is feasible
             ok = j < nx.pend && (uint64_t)P[j] <= thi;
@@ -495,27 +557,40 @@ __global__ void join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __
 // jump[e] for level-0 elements: first feasible element of list 0 at or after end(e)+end_len (kNone = none);
 // slots of other levels get kNone so the tile pass can treat every slot alike.  Also the start of each chain.
 template <typename pos_t>
-__global__ void join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
-                                 const QueryMeta* __restrict__ qm, const uint32_t* __restrict__ seg_query, uint64_t total,
-                                 const uint32_t* __restrict__ nf, const pos_t* __restrict__ endp, uint32_t* __restrict__ jump,
-                                 uint32_t* __restrict__ qstart)
+__global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg,
+                                                        const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint64_t r0,
+                                                        uint64_t r1, const uint32_t* __restrict__ nf, const pos_t* __restrict__ endp,
+                                                        uint32_t* __restrict__ jump, uint32_t* __restrict__ qstart)
 {
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t s = seg[e];
-        const SegMeta m = sm[s];
-        uint32_t out = kNone;
-        if (m.level == 0) {
-            uint32_t me = nf[e];
-            if (me == (uint32_t)e) {                          // feasible start
-                uint64_t lim = sat_add((uint64_t)endp[e], qm[seg_query[s]].end_len);
-                uint32_t jp = lower_bound_dev(P, phys_of(m, (uint32_t)e) + 1, m.pend, lim);
-                if (jp < m.pend) {
-                    uint32_t ej = nf[m.begin + (jp - m.pbegin)];
-                    if (ej < m.end) out = ej;
+    const uint64_t span = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = r0 + (uint64_t)blockIdx.x * blockDim.x; base < r1; base += span) {
+        const uint64_t e = base + threadIdx.x;
+        const bool inr = e < r1;
+        uint32_t s = 0, me = kNone;
+        SegMeta m;
+        bool active = false;
+        uint64_t lim = 0;
+        uint32_t a = 0, b = 0;
+        if (inr) {
+            s = seg[e];
+            m = sm[s];
+            if (m.level == 0) {
+                me = nf[e];
+                if (me == (uint32_t)e) {                      // feasible start
+                    active = true;
+                    lim = sat_add((uint64_t)endp[e], qm[m.query].end_len);
+                    a = phys_of(m, (uint32_t)e) + 1; b = m.pend;
                 }
             }
-            if ((uint32_t)e == m.begin) qstart[seg_query[s]] = me < m.end ? me : kNone;
         }
+        uint32_t jp = lower_bound_wave(P, a, b, lim, active, s);
+        if (!inr) continue;
+        uint32_t out = kNone;
+        if (active && jp < m.pend) {
+            uint32_t ej = nf[m.begin + (jp - m.pbegin)];
+            if (ej < m.end) out = ej;
+        }
+        if (m.level == 0 && (uint32_t)e == m.begin) qstart[m.query] = me < m.end ? me : kNone;
         jump[e] = out;
     }
 }
@@ -529,18 +604,19 @@ __global__ void join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __
 constexpr uint32_t kTile = 1024;
 constexpr uint32_t kTerm = 0xFFFFu;
 
-__global__ void __launch_bounds__(256) chain_tiles_kernel(const uint32_t* __restrict__ jump, uint64_t total, uint2* __restrict__ xh)
+__global__ void __launch_bounds__(256) chain_tiles_kernel(const uint32_t* __restrict__ jump, uint64_t t0 /* multiple of kTile */,
+                                                          uint64_t r1, uint2* __restrict__ xh)
 {
     __shared__ uint32_t s_ext[kTile];
     __shared__ uint16_t s_nxt[kTile];
     __shared__ uint16_t s_hop[kTile];
-    const uint64_t base = (uint64_t)blockIdx.x * kTile;
+    const uint64_t base = t0 + (uint64_t)blockIdx.x * kTile;
     const uint64_t tile_end = base + kTile;
 #pragma unroll
     for (uint32_t r = 0; r < 4; ++r) {
         uint32_t li = threadIdx.x + 256 * r;
         uint64_t e = base + li;
-        uint32_t j = e < total ? jump[e] : kNone;
+        uint32_t j = e < r1 ? jump[e] : kNone;
         bool inside = j != kNone && (uint64_t)j < tile_end;
         s_ext[li] = j;                                   // exit if it leaves the tile (or kNone)
         s_nxt[li] = inside ? (uint16_t)(j - base) : (uint16_t)kTerm;
@@ -568,7 +644,7 @@ __global__ void __launch_bounds__(256) chain_tiles_kernel(const uint32_t* __rest
     for (uint32_t r = 0; r < 4; ++r) {
         uint32_t li = threadIdx.x + 256 * r;
         uint64_t e = base + li;
-        if (e < total) xh[e] = make_uint2(s_ext[li], (uint32_t)s_hop[li]);
+        if (e < r1) xh[e] = make_uint2(s_ext[li], (uint32_t)s_hop[li]);
     }
 }
 
@@ -596,11 +672,10 @@ __global__ void chain_walk_kernel(const SegMeta* __restrict__ sm, const QueryMet
     counts[q] = n_match;
 }
 
-__global__ void chain_emit_kernel(uint32_t nq, const uint32_t* __restrict__ rec_begin, const uint32_t* __restrict__ rec_count,
+__global__ void chain_emit_kernel(const uint32_t* __restrict__ rec_begin, const uint32_t* __restrict__ rec_count,
                                   const uint2* __restrict__ records, uint32_t total_rec_slots, const uint32_t* __restrict__ rec_query,
                                   const uint32_t* __restrict__ jump, uint32_t* __restrict__ mlist)
 {
-    (void)nq;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < total_rec_slots; r += gridDim.x * blockDim.x) {
         uint32_t q = rec_query[r];                       // slot r belongs to query q; used only if r - rec_begin[q] < rec_count[q]
         if (r - rec_begin[q] >= rec_count[q]) continue;
@@ -614,34 +689,35 @@ __global__ void chain_emit_kernel(uint32_t nq, const uint32_t* __restrict__ rec_
     }
 }
 
-// tuples of every match: walk the links from the level-0 element
+// tuples of every match: walk the links from the level-0 element.  One thread per (query, match) slot of list 0.
 template <typename pos_t>
 __global__ void join_gather_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
-                                   const QueryMeta* __restrict__ qm, const uint32_t* __restrict__ seg_query, uint64_t total,
-                                   const uint32_t* __restrict__ link, const uint32_t* __restrict__ mlist,
-                                   const unsigned long long* __restrict__ counts, uint64_t* __restrict__ out_first,
-                                   uint64_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
+                                   const QueryMeta* __restrict__ qm, uint64_t r0, uint64_t r1, const uint32_t* __restrict__ link,
+                                   const uint32_t* __restrict__ mlist, const unsigned long long* __restrict__ counts,
+                                   uint64_t* __restrict__ out_first, uint64_t* __restrict__ out_tuples,
+                                   unsigned long long* __restrict__ checksum)
 {
     unsigned long long local = 0;
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t s = seg[e];
-        const SegMeta m = sm[s];
+    for (uint64_t e = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < r1; e += (uint64_t)gridDim.x * blockDim.x) {
+        const SegMeta m = sm[seg[e]];
         if (m.level != 0) continue;
-        uint32_t qi = seg_query[s];
         uint64_t t = e - m.begin;
-        if (t >= counts[qi]) continue;
-        const QueryMeta Q = qm[qi];
+        if (t >= counts[m.query]) continue;
+        const QueryMeta Q = qm[m.query];
         uint32_t el = mlist[e];                                // logical element of level 0
         uint64_t first = P[phys_of(m, el)];
         out_first[Q.out_first + t] = first;
         local += first;
         uint64_t* tp = out_tuples + Q.out_tuple + t * Q.k;
         tp[0] = first;
-        uint32_t cur = link[el];
-        for (uint32_t i = 1; i < Q.k; ++i) {
-            const SegMeta mi = sm[s + i];
-            if (mi.dist == 0) { tp[i] = P[cur]; }              // link of a dist-1 element is a physical index
-            else { tp[i] = P[phys_of(mi, cur)]; cur = link[cur]; }
+        if (Q.k > 1) {
+            uint32_t cur = link[el];
+            uint32_t sg = m.next;
+            for (uint32_t i = 1; i < Q.k; ++i) {
+                const SegMeta mi = sm[sg];
+                if (mi.dist == 0) { tp[i] = P[cur]; }          // link of a dist-1 element is a physical index
+                else { tp[i] = P[phys_of(mi, cur)]; cur = link[cur]; sg = mi.next; }
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
@@ -668,6 +744,7 @@ struct Plan {                       // host view of the batch after backward sea
     std::vector<uint64_t> dl, docc; // per distinct interval: left border, size
 };
 
+template <typename pos_t> constexpr uint64_t kPhysScratchPerElem() { return sizeof(pos_t) == 4 ? 20 : sizeof(pos_t); }
 constexpr uint64_t kJoinBytesPerSlot = 7 * 4 + 8 + 1; // seg, link, nf, feas, jump, mlist, endp(<=8), chain records
 
 // ---- physical pass: locate + sort every distinct interval used by queries [Q0,Q1) -------------------
@@ -691,23 +768,37 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     P_out = nullptr;
     if (!acc) return VLG_OK;
     const unsigned bits = bit_width64(idx->hdr.n);
+    const bool use_sweep = ws->sweep && sizeof(pos_t) == 4 && acc >= ws->sweep_min;
     pos_t* Pa = A.take<pos_t>(acc);
-    pos_t* Pb = A.take<pos_t>(acc);
+    // scratch of the sweep (20 B per element); the sorted lists Pb reuse it once locate is done
+    uint8_t* scratch = A.take<uint8_t>(acc * kPhysScratchPerElem<pos_t>());
     uint64_t* d_off64 = A.take<uint64_t>(nd + 1);
     uint32_t* d_off32 = A.take<uint32_t>(nd + 1);
     uint64_t* d_lh = A.take<uint64_t>(nd);
+    unsigned long long* d_counter = A.take<unsigned long long>(1);
     void* d_tmp = A.take<uint8_t>(sort_tmp + 256);
     if (!d_tmp) return fail(VLG_E_INTERNAL, "arena carve failed (physical)");
+    pos_t* Pb = reinterpret_cast<pos_t*>(scratch);
     VLG_HIP_TRY(hipMemcpyAsync(d_off64, off64.data(), (nd + 1) * 8, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_off32, off32.data(), (nd + 1) * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_lh, lh.data(), nd * 8, hipMemcpyHostToDevice, st));
-    {
-        Timed t(ws, KS_EXPAND, 0);
-        if (vlg_status s = launch_expand<pos_t>(d_lh, d_off64, nd, acc, Pa, nullptr, st)) return s;
-    }
-    {
-        Timed t(ws, KS_LOCATE, 0);
-        if (vlg_status s = launch_locate<pos_t>(idx->view, Pa, acc, d_stats, st)) return s;
+    if (use_sweep) {
+        uint64_t* val_a = reinterpret_cast<uint64_t*>(scratch);
+        uint64_t* val_b = val_a + acc;
+        uint16_t* key_a = reinterpret_cast<uint16_t*>(val_b + acc);
+        uint16_t* key_b = key_a + acc;
+        SweepTimer timer(ws);
+        if (vlg_status s = launch_locate_sweep(idx->view, d_lh, d_off64, nd, acc, reinterpret_cast<uint32_t*>(Pa), val_a, val_b, key_a, key_b,
+                                               d_tmp, sort_tmp, d_counter, d_stats, ws->sweep_tail, st, &timer)) return s;
+    } else {
+        {
+            Timed t(ws, KS_EXPAND, 0);
+            if (vlg_status s = launch_expand<pos_t>(d_lh, d_off64, nd, acc, Pa, nullptr, st)) return s;
+        }
+        {
+            Timed t(ws, KS_LOCATE, 0);
+            if (vlg_status s = launch_locate<pos_t>(idx->view, Pa, acc, d_stats, st)) return s;
+        }
     }
     {   // sort every occurrence list ascending (std::sort, index_sasearch.hpp:80)
         Timed t(ws, KS_SORT, 2ull * acc * sizeof(pos_t));
@@ -732,41 +823,78 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     const uint32_t nseg = (uint32_t)(s1 - s0), nq = (uint32_t)(q1 - q0);
     ResultPiece piece;
     piece.q0 = q0; piece.q1 = q1;
-    // ---- host-side metadata of the chunk ---------------------------------------------------------
-    std::vector<SegMeta> sm(nseg + 1);
+    // ---- host-side metadata of the chunk: segments in class-major order (dist descending) -------------
     std::vector<QueryMeta> qm(nq);
-    std::vector<uint32_t> seg_query(nseg + 1, 0), seg_begin(nseg + 2, 0);
     uint32_t kmax = 0;
-    uint64_t acc = 0;
     for (uint64_t qi = q0; qi < q1; ++qi) {
         uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
         QueryMeta& Q = qm[qi - q0];
-        Q.k = k; Q.end_len = q->end_len[qi]; Q.out_first = Q.out_tuple = 0;
+        Q.k = k; Q.end_len = q->end_len[qi]; Q.out_first = Q.out_tuple = 0; Q.seg0 = kNone;
         bool live = k > 0 && pl.occ[q->qsub[qi]] > 0;
-        Q.seg0 = live ? (uint32_t)(q->qsub[qi] - s0) : kNone;
         if (live) kmax = std::max(kmax, k);
+    }
+    std::vector<uint32_t> cls_count(kmax + 1, 0), cls_first(kmax + 2, 0);   // segments per dist class
+    for (uint64_t qi = q0; qi < q1; ++qi) {
+        uint32_t k = qm[qi - q0].k;
+        if (!(k > 0 && pl.occ[q->qsub[qi]] > 0)) continue;
+        for (uint32_t i = 0; i < k; ++i) cls_count[k - 1 - i]++;
+    }
+    // classes are stored from the highest dist down to 0
+    uint32_t nlive = 0;
+    for (int d = (int)kmax - 1; d >= 0; --d) { cls_first[d] = nlive; nlive += cls_count[d]; }
+    std::vector<SegMeta> sm(nlive + 1);
+    std::vector<uint32_t> seg_begin(nlive + 2, 0), fill(kmax + 1, 0);
+    std::vector<uint32_t> seg_of_sub(nseg, kNone);
+    for (uint64_t qi = q0; qi < q1; ++qi) {
+        uint32_t k = qm[qi - q0].k;
+        if (!(k > 0 && pl.occ[q->qsub[qi]] > 0)) continue;
+        for (uint32_t i = 0; i < k; ++i) {
+            uint32_t d = k - 1 - i;
+            seg_of_sub[q->qsub[qi] + i - s0] = cls_first[d] + fill[d]++;
+        }
+        qm[qi - q0].seg0 = seg_of_sub[q->qsub[qi] - s0];
+    }
+    for (uint64_t qi = q0; qi < q1; ++qi) {
+        uint32_t k = qm[qi - q0].k;
+        if (qm[qi - q0].seg0 == kNone) continue;
         for (uint32_t i = 0; i < k; ++i) {
             uint64_t s = q->qsub[qi] + i;
-            SegMeta& m = sm[s - s0];
+            SegMeta& m = sm[seg_of_sub[s - s0]];
             m.level = i; m.dist = k - 1 - i;
             m.lo = q->lo[s]; m.hi = q->hi[s];
-            m.pbegin = m.pend = 0;
-            seg_begin[s - s0] = (uint32_t)acc;
-            m.begin = (uint32_t)acc;
-            if (live) {
-                m.pbegin = poff[pl.did[s]];
-                m.pend = m.pbegin + (uint32_t)pl.occ[s];
-                if (m.dist > 0 || k == 1) acc += pl.occ[s];      // the last list of a k>=2 query needs no join state
-            }
-            m.end = (uint32_t)acc;
-            seg_query[s - s0] = (uint32_t)(qi - q0);
+            m.pbegin = poff[pl.did[s]];
+            m.pend = m.pbegin + (uint32_t)pl.occ[s];
+            m.next = (i + 1 < k) ? seg_of_sub[s + 1 - s0] : kNone;
+            m.query = (uint32_t)(qi - q0);
         }
     }
+    // slots: class-major, segments of a class in query order
+    uint64_t acc = 0;
+    std::vector<uint64_t> cls_slot_begin(kmax + 1, 0), cls_slot_end(kmax + 1, 0);
+    for (int d = (int)kmax - 1; d >= 0; --d) {
+        cls_slot_begin[d] = acc;
+        for (uint32_t j = 0; j < cls_count[d]; ++j) {
+            SegMeta& m = sm[cls_first[d] + j];
+            seg_begin[cls_first[d] + j] = (uint32_t)acc;
+            m.begin = (uint32_t)acc;
+            if (m.dist > 0 || m.level == 0) acc += (m.pend - m.pbegin);      // the last list of a k>=2 query needs no join state
+            m.end = (uint32_t)acc;
+        }
+        cls_slot_end[d] = acc;
+    }
     const uint64_t T = acc;
-    seg_begin[nseg] = (uint32_t)acc;
-    seg_begin[nseg + 1] = 0xFFFFFFFFu;
-    sm[nseg] = SegMeta{(uint32_t)acc, (uint32_t)acc, 0, 0, 0, 0, 0, 0};
-    if (T == 0 || nseg == 0) { res->pieces.push_back(piece); return VLG_OK; }
+    seg_begin[nlive] = (uint32_t)acc;
+    seg_begin[nlive + 1] = 0xFFFFFFFFu;
+    sm[nlive] = SegMeta{(uint32_t)acc, (uint32_t)acc, 0, 0, 0, 0, kNone, 0, 0, 0};
+    if (T == 0 || nlive == 0) { res->pieces.push_back(piece); return VLG_OK; }
+    // level-0 slots span the classes k-1 of every live query: [lvl0_begin, lvl0_end) bounds them
+    uint64_t lvl0_begin = T, lvl0_end = 0;
+    for (uint32_t i = 0; i < nq; ++i)
+        if (qm[i].seg0 != kNone) {
+            const SegMeta& m0 = sm[qm[i].seg0];
+            if (m0.end > m0.begin) { lvl0_begin = std::min<uint64_t>(lvl0_begin, m0.begin); lvl0_end = std::max<uint64_t>(lvl0_end, m0.end); }
+        }
+    if (lvl0_end <= lvl0_begin) { res->pieces.push_back(piece); return VLG_OK; }
     // ---- carve the arena ---------------------------------------------------------------------------
     size_t scan_tmp = 0;
     {
@@ -783,10 +911,9 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     uint32_t* nf = fn ? fn + Tal : nullptr;
     uint32_t* jump = A.take<uint32_t>(T);
     uint32_t* mlist = A.take<uint32_t>(T);
-    SegMeta* d_sm = A.take<SegMeta>(nseg + 1);
+    SegMeta* d_sm = A.take<SegMeta>(nlive + 1);
     QueryMeta* d_qm = A.take<QueryMeta>(nq);
-    uint32_t* d_segq = A.take<uint32_t>(nseg + 1);
-    uint32_t* d_segb = A.take<uint32_t>(nseg + 2);
+    uint32_t* d_segb = A.take<uint32_t>(nlive + 2);
     unsigned long long* d_counts = A.take<unsigned long long>(nq);
     // chain records: one per tile a level-0 list overlaps (upper bound of the tiles its chain can visit)
     std::vector<uint32_t> rec_begin(nq + 1, 0), rec_query;
@@ -810,42 +937,50 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     VLG_HIP_TRY(hipMemcpyAsync(d_recb, rec_begin.data(), (nq + 1) * 4, hipMemcpyHostToDevice, st));
     if (n_rec) VLG_HIP_TRY(hipMemcpyAsync(d_recq, rec_query.data(), n_rec * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemsetAsync(d_qstart, 0xFF, nq * 4, st));
-    VLG_HIP_TRY(hipMemcpyAsync(d_sm, sm.data(), (nseg + 1) * sizeof(SegMeta), hipMemcpyHostToDevice, st));
-    VLG_HIP_TRY(hipMemcpyAsync(d_segq, seg_query.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, st));
-    VLG_HIP_TRY(hipMemcpyAsync(d_segb, seg_begin.data(), (nseg + 2) * 4, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_sm, sm.data(), (nlive + 1) * sizeof(SegMeta), hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_segb, seg_begin.data(), (nlive + 2) * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
-    const uint32_t g = grid_for(T);
     {
         Timed t(ws, KS_JOIN_LINK, 0);
-        hipLaunchKernelGGL(seg_ids_kernel, dim3(grid_for(T, 32768)), dim3(256), 0, st, d_segb, nseg, T, seg);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_init_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, T, feas, endp, link);
+        hipLaunchKernelGGL(seg_ids_kernel, dim3(grid_for(T, 32768)), dim3(256), 0, st, d_segb, nlive, T, seg);
+        if (cls_slot_end[0] > cls_slot_begin[0])
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_init_kernel<pos_t>), dim3(grid_for(cls_slot_end[0] - cls_slot_begin[0])), dim3(256), 0, st, P,
+                               seg, d_sm, cls_slot_begin[0], cls_slot_end[0], feas, endp);
     }
+    // nf is only ever read at slots of classes that are complete, so it is scanned class by class
+    auto scan_class = [&](uint32_t d) -> vlg_status {
+        uint64_t b0 = cls_slot_begin[d], b1 = cls_slot_end[d];
+        if (b1 <= b0) return VLG_OK;
+        Timed t(ws, KS_JOIN_SCAN, 8ull * (b1 - b0));
+        // nf[j] = nearest feasible element at or after j (reverse running minimum of feas inside the class)
+        auto rin = rocprim::make_reverse_iterator(feas + b1);
+        auto rout = rocprim::make_reverse_iterator(nf + b1);
+        size_t tb = scan_tmp;
+        VLG_HIP_TRY(rocprim::inclusive_scan(d_tmp, tb, rin, rout, b1 - b0, rocprim::minimum<uint32_t>(), st));
+        return VLG_OK;
+    };
+    if (vlg_status s = scan_class(0)) return s;
     for (uint32_t dist = 1; dist < kmax; ++dist) {
-        {
-            Timed t(ws, KS_JOIN_LINK, 8ull * T);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, T, dist, nf, feas, endp, link);
+        uint64_t b0 = cls_slot_begin[dist], b1 = cls_slot_end[dist];
+        if (b1 > b0) {
+            Timed t(ws, KS_JOIN_LINK, 8ull * (b1 - b0));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t>), dim3(grid_for(b1 - b0)), dim3(256), 0, st, P, seg, d_sm, b0, b1, dist, nf,
+                               feas, endp, link);
         }
-        {
-            Timed t(ws, KS_JOIN_SCAN, 8ull * T);
-            // nf[j] = nearest element at or after j whose chain is known to be feasible
-            VLG_HIP_TRY(hipMemcpyAsync(nf, feas, T * 4, hipMemcpyDeviceToDevice, st));
-            auto rin = rocprim::make_reverse_iterator(nf + T);
-            size_t tb = scan_tmp;
-            VLG_HIP_TRY(rocprim::inclusive_scan(d_tmp, tb, rin, rin, T, rocprim::minimum<uint32_t>(), st));
-        }
+        if (vlg_status s = scan_class(dist)) return s;
     }
-    if (kmax <= 1) VLG_HIP_TRY(hipMemcpyAsync(nf, feas, T * 4, hipMemcpyDeviceToDevice, st));   // single sub-patterns: identity
     {
         Timed t(ws, KS_JOIN_CHAIN, 0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, d_qm, d_segq, T, nf, endp, jump,
-                           d_qstart);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(grid_for(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, seg, d_sm, d_qm,
+                           lvl0_begin, lvl0_end, nf, endp, jump, d_qstart);
         uint2* xh = reinterpret_cast<uint2*>(fn);           // feas / nf are dead from here on
-        hipLaunchKernelGGL(chain_tiles_kernel, dim3((uint32_t)((T + kTile - 1) / kTile)), dim3(256), 0, st, jump, T, xh);
+        const uint64_t t0 = lvl0_begin / kTile * kTile;
+        if (t0 < lvl0_begin) VLG_HIP_TRY(hipMemsetAsync(jump + t0, 0xFF, (lvl0_begin - t0) * 4, st));   // slots of the first tile before the range
+        hipLaunchKernelGGL(chain_tiles_kernel, dim3((uint32_t)((lvl0_end - t0 + kTile - 1) / kTile)), dim3(256), 0, st, jump, t0, lvl0_end, xh);
         hipLaunchKernelGGL(chain_walk_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, d_sm, d_qm, nq, d_qstart, xh, d_recb, d_rec, d_recc,
                            d_counts);
         if (n_rec)
-            hipLaunchKernelGGL(chain_emit_kernel, dim3(grid_for(n_rec)), dim3(256), 0, st, nq, d_recb, d_recc, d_rec, n_rec, d_recq, jump,
-                               mlist);
+            hipLaunchKernelGGL(chain_emit_kernel, dim3(grid_for(n_rec)), dim3(256), 0, st, d_recb, d_recc, d_rec, n_rec, d_recq, jump, mlist);
     }
     VLG_HIP_TRY(hipGetLastError());
     // ---- sizes of the result, then gather -------------------------------------------------------------
@@ -865,8 +1000,8 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         res->pieces.push_back(piece);
         VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
         Timed t(ws, KS_GATHER, 8ull * (M + TV));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(g), dim3(256), 0, st, P, seg, d_sm, d_qm, d_segq, T, link, mlist,
-                           d_counts, piece.d_first, piece.d_tuples, d_stats + 2);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(grid_for(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, seg, d_sm, d_qm,
+                           lvl0_begin, lvl0_end, link, mlist, d_counts, piece.d_first, piece.d_tuples, d_stats + 2);
         VLG_HIP_TRY(hipGetLastError());
     } else {
         res->pieces.push_back(piece);
@@ -888,7 +1023,8 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
     if (ws->cap_bytes <= 2 * fixed) return fail(VLG_E_WORKSPACE, "workspace cap too small");
     const uint64_t budget = ws->cap_bytes - fixed;
     // physical lists take at most half of the budget (two buffers during the sort)
-    const uint64_t phys_cap = std::min<uint64_t>(budget / 2 / (2 * sizeof(pos_t) + 1), 0xFFFFFF00ull);
+    const uint64_t phys_per = sizeof(pos_t) + kPhysScratchPerElem<pos_t>();
+    const uint64_t phys_cap = std::min<uint64_t>(budget / 2 / (phys_per + 1), 0xFFFFFF00ull);
     std::vector<uint32_t> stamp(pl.dl.size(), 0xFFFFFFFFu);
     std::vector<uint32_t> poff(pl.dl.size(), 0);
     uint64_t Q0 = 0;
@@ -928,8 +1064,10 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             pos_t* np = nullptr; uint32_t* nu = nullptr;
             VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, np, np, (unsigned)phys, (unsigned)dlist.size(), nu, nu, 0,
                                                            bit_width64(idx->hdr.n), ws->stream));
+            if (ws->sweep && sizeof(pos_t) == 4 && phys >= ws->sweep_min)
+                sort_tmp = std::max(sort_tmp, sweep_temp_bytes(phys, idx->hdr.sigma, ws->stream));
         }
-        const uint64_t phys_bytes = 2 * phys * sizeof(pos_t) + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20);
+        const uint64_t phys_bytes = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20);
         uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
         uint64_t cap_slots = std::min<uint64_t>(join_budget / kJoinBytesPerSlot, 0xFFFFFF00ull);
         if (logical_max_query > cap_slots)
