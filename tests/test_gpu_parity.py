@@ -265,7 +265,7 @@ def test_search_chunked_equals_unchunked(V):
     qs = random_queries(text, np.random.default_rng(9), 300, kmax=3, mmax=3)
     from vlg_matching_amd.index import Workspace
     a = idx.search(qs)
-    b = idx.search(qs, workspace=Workspace(max_hbm_bytes=(150 << 20)))
+    b = idx.search(qs, workspace=Workspace(max_hbm_bytes=(90 << 20)))
     assert b.summary["n_chunks"] > a.summary["n_chunks"]
     for k in ("n_matches", "checksum", "n_tuple_values", "logical_occurrences"):
         assert a.summary[k] == b.summary[k], k

@@ -458,140 +458,153 @@ __device__ __forceinline__ uint32_t lower_bound_dev(const pos_t* __restrict__ P,
     return a;
 }
 
-// Lower bound for 64 consecutive slots at once.  When the whole wave works on one segment its keys ascend
-// with the lane, so the answers lie between the answers of lane 0 and lane 63: two full searches bracket the
-// range and the other lanes finish inside it (a handful of probes instead of log2 |list|).
+// Lower bound by galloping from a known lower fence: all indices below `lo` hold values < key.
+// Consecutive slots of a list have ascending keys, so the previous answer is a tight fence and the search costs
+// O(log distance) probes into lines the neighbouring lanes touch too, instead of log2 |list| cold probes.
 template <typename pos_t>
-__device__ __forceinline__ uint32_t lower_bound_wave(const pos_t* __restrict__ P, uint32_t a, uint32_t b, uint64_t key, bool active,
-                                                     uint32_t seg_id)
+__device__ __forceinline__ uint32_t gallop_lower_bound(const pos_t* __restrict__ P, uint32_t lo, uint32_t b, uint64_t key)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long act = __ballot(active);
-    bool uniform = false;
-    uint32_t first = 0, last = 0;
-    if (act) {
-        first = (uint32_t)__ffsll((long long)act) - 1;
-        last = 63u - (uint32_t)__clzll((long long)act);
-        uint32_t s0 = __shfl(seg_id, (int)first), s1 = __shfl(seg_id, (int)last);
-        uniform = (s0 == s1) && (last - first >= 8);
+    uint32_t step = 1, hi = b;
+    bool found = false;
+    while (lo < b) {
+        uint32_t p = lo + step - 1;
+        if (p >= b) p = b - 1;
+        if ((uint64_t)P[p] < key) { lo = p + 1; step <<= 1; }
+        else { hi = p; found = true; break; }
     }
-    if (!uniform) return active ? lower_bound_dev(P, a, b, key) : a;
-    uint32_t r = a;
-    if (active && (lane == first || lane == last)) r = lower_bound_dev(P, a, b, key);
-    uint32_t rlo = __shfl(r, (int)first), rhi = __shfl(r, (int)last);
-    if (active && lane != first && lane != last) r = lower_bound_dev(P, rlo, rhi, key);
-    return r;
+    if (!found) return b;
+    return lower_bound_dev(P, lo, hi, key);
 }
 
-// seg[t] = segment owning logical slot t (tile of 256 slots, one binary search per tile)
-__global__ void seg_ids_kernel(const uint32_t* __restrict__ seg_begin /* [nseg+2], non-decreasing */, uint32_t nseg, uint64_t total,
-                               uint32_t* __restrict__ seg)
+// Slots are dealt to waves in contiguous runs so a wave can carry the segment it is in and the last answer
+// of its searches from one 64-slot step to the next.
+constexpr uint32_t kRun = 2048;
+
+__device__ __forceinline__ uint32_t seg_find(const uint32_t* __restrict__ seg_begin, uint32_t nseg, uint64_t slot)
 {
-    __shared__ uint32_t s_first;
-    for (uint64_t base = (uint64_t)blockIdx.x * 256; base < total; base += (uint64_t)gridDim.x * 256) {
-        if (threadIdx.x == 0) {
-            uint32_t lo = 0, hi = nseg;                    // last p with seg_begin[p] <= base
-            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (seg_begin[mid] <= base) lo = mid; else hi = mid; }
-            s_first = lo;
-        }
-        __syncthreads();
-        uint64_t t = base + threadIdx.x;
-        if (t < total) {
-            uint32_t p = s_first;
-            while (seg_begin[p + 1] <= t) ++p;             // skips empty segments
-            seg[t] = p;
-        }
-        __syncthreads();
-    }
+    uint32_t lo = 0, hi = nseg;                        // last p with seg_begin[p] <= slot
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (seg_begin[mid] <= slot) lo = mid; else hi = mid; }
+    return lo;
 }
 
 // single-sub-pattern queries (class dist 0): every element is a feasible chain that ends at itself
 template <typename pos_t>
-__global__ void join_init_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
-                                 uint64_t r0, uint64_t r1, uint32_t* __restrict__ feas, pos_t* __restrict__ endp)
+__global__ void __launch_bounds__(256) join_init_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
+                                                        const SegMeta* __restrict__ sm, uint64_t r0, uint64_t r1, uint32_t* __restrict__ feas,
+                                                        pos_t* __restrict__ endp)
 {
-    for (uint64_t e = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < r1; e += (uint64_t)gridDim.x * blockDim.x) {
-        const SegMeta m = sm[seg[e]];
-        feas[e] = (uint32_t)e;
-        endp[e] = P[phys_of(m, (uint32_t)e)];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t run_begin = r0 + wave * kRun;
+    if (run_begin >= r1) return;
+    const uint64_t run_end = run_begin + kRun < r1 ? run_begin + kRun : r1;
+    uint32_t s_w = seg_find(seg_begin, nseg, run_begin);
+    for (uint64_t base = run_begin; base < run_end; base += 64) {
+        const uint64_t e = base + lane;
+        if (e < run_end) {
+            uint32_t s = s_w;
+            while (seg_begin[s + 1] <= e) ++s;
+            const SegMeta m = sm[s];
+            feas[e] = (uint32_t)e;
+            endp[e] = P[phys_of(m, (uint32_t)e)];
+            s_w = s;
+        }
+        s_w = __shfl(s_w, 0);                          // lane 0 is always in range and holds the smallest segment
     }
 }
 
 // link pass over the class [r0,r1) of slots that have `dist` sub-patterns after them
 template <typename pos_t>
-__global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg,
+__global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
                                                         const SegMeta* __restrict__ sm, uint64_t r0, uint64_t r1, uint32_t dist,
                                                         const uint32_t* __restrict__ nf_in, uint32_t* __restrict__ feas_out,
                                                         pos_t* __restrict__ endp, uint32_t* __restrict__ link)
 {
-    const uint64_t span = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t base = r0 + (uint64_t)blockIdx.x * blockDim.x; base < r1; base += span) {   // wave-uniform trip count
-        const uint64_t e = base + threadIdx.x;
-        const bool active = e < r1;
-        uint32_t s = 0;
-        SegMeta m, nx;
-        uint64_t tlo = 0, thi = 0;
-        uint32_t a = 0, b = 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t run_begin = r0 + wave * kRun;
+    if (run_begin >= r1) return;
+    const uint64_t run_end = run_begin + kRun < r1 ? run_begin + kRun : r1;
+    uint32_t s_w = seg_find(seg_begin, nseg, run_begin);
+    uint32_t hint_seg = kNone, hint = 0;               // answer of the last lane of the previous step and its segment
+    for (uint64_t base = run_begin; base < run_end; base += 64) {
+        const uint64_t e = base + lane;
+        const bool active = e < run_end;
+        uint32_t s = s_w, j = 0;
         if (active) {
-            s = seg[e];
-            m = sm[s];
-            nx = sm[m.next];
-            uint64_t x = P[phys_of(m, (uint32_t)e)];
-            tlo = sat_add(x, nx.lo); thi = sat_add(x, nx.hi);
-            a = nx.pbegin; b = nx.pend;
+            while (seg_begin[s + 1] <= e) ++s;
+            const SegMeta m = sm[s];
+            const SegMeta nx = sm[m.next];
+            const uint64_t x = P[phys_of(m, (uint32_t)e)];
+            const uint64_t tlo = sat_add(x, nx.lo), thi = sat_add(x, nx.hi);
+            const uint32_t fence = (s == hint_seg) ? hint : nx.pbegin;
+            j = gallop_lower_bound(P, fence, nx.pend, tlo);           // physical index in the next list
+            bool ok = false;
+            if (dist == 1) {                                          // next list is the last one: every element is feasible
+                ok = j < nx.pend && (uint64_t)P[j] <= thi;
+                if (ok) { link[e] = j; endp[e] = P[j]; }
+            } else if (j < nx.pend) {
+                uint32_t ej = nf_in[nx.begin + (j - nx.pbegin)];      // nearest feasible logical element at or after it
+                if (ej < nx.end && (uint64_t)P[phys_of(nx, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+            }
+            feas_out[e] = ok ? (uint32_t)e : kNone;
         }
-        uint32_t j = lower_bound_wave(P, a, b, tlo, active, s);      // physical index in the next list
-        if (!active) continue;
-        bool ok = false;
-        if (dist == 1) {                                              // next list is the last one: every element is feasible
-            ok = j < nx.pend && (uint64_t)P[j] <= thi;
-            if (ok) { link[e] = j; endp[e] = P[j]; }
-        } else if (j < nx.pend) {
-            uint32_t ej = nf_in[nx.begin + (j - nx.pbegin)];          // nearest feasible logical element at or after it
-            if (ej < nx.end && (uint64_t)P[phys_of(nx, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
-        }
-        feas_out[e] = ok ? (uint32_t)e : kNone;
+        const unsigned long long act = __ballot(active);
+        const int last = 63 - __clzll((long long)act);
+        hint_seg = __shfl(s, last);
+        hint = __shfl(j, last);
+        s_w = __shfl(s, 0);
     }
 }
 
 // jump[e] for level-0 elements: first feasible element of list 0 at or after end(e)+end_len (kNone = none);
 // slots of other levels get kNone so the tile pass can treat every slot alike.  Also the start of each chain.
 template <typename pos_t>
-__global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg,
+__global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
                                                         const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint64_t r0,
                                                         uint64_t r1, const uint32_t* __restrict__ nf, const pos_t* __restrict__ endp,
                                                         uint32_t* __restrict__ jump, uint32_t* __restrict__ qstart)
 {
-    const uint64_t span = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t base = r0 + (uint64_t)blockIdx.x * blockDim.x; base < r1; base += span) {
-        const uint64_t e = base + threadIdx.x;
-        const bool inr = e < r1;
-        uint32_t s = 0, me = kNone;
-        SegMeta m;
-        bool active = false;
-        uint64_t lim = 0;
-        uint32_t a = 0, b = 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t run_begin = r0 + wave * kRun;
+    if (run_begin >= r1) return;
+    const uint64_t run_end = run_begin + kRun < r1 ? run_begin + kRun : r1;
+    uint32_t s_w = seg_find(seg_begin, nseg, run_begin);
+    uint32_t hint_seg = kNone, hint = 0;
+    for (uint64_t base = run_begin; base < run_end; base += 64) {
+        const uint64_t e = base + lane;
+        const bool inr = e < run_end;
+        uint32_t s = s_w, jp = 0;
+        bool searched = false;
         if (inr) {
-            s = seg[e];
-            m = sm[s];
+            while (seg_begin[s + 1] <= e) ++s;
+            const SegMeta m = sm[s];
+            uint32_t out = kNone;
             if (m.level == 0) {
-                me = nf[e];
-                if (me == (uint32_t)e) {                      // feasible start
-                    active = true;
-                    lim = sat_add((uint64_t)endp[e], qm[m.query].end_len);
-                    a = phys_of(m, (uint32_t)e) + 1; b = m.pend;
+                const uint32_t me = nf[e];
+                if (me == (uint32_t)e) {                              // feasible start
+                    const uint64_t lim = sat_add((uint64_t)endp[e], qm[m.query].end_len);
+                    uint32_t fence = phys_of(m, (uint32_t)e) + 1;
+                    if (s == hint_seg && hint > fence) fence = hint;
+                    jp = gallop_lower_bound(P, fence, m.pend, lim);
+                    searched = true;
+                    if (jp < m.pend) {
+                        uint32_t ej = nf[m.begin + (jp - m.pbegin)];
+                        if (ej < m.end) out = ej;
+                    }
                 }
+                if ((uint32_t)e == m.begin) qstart[m.query] = me < m.end ? me : kNone;
             }
+            jump[e] = out;
         }
-        uint32_t jp = lower_bound_wave(P, a, b, lim, active, s);
-        if (!inr) continue;
-        uint32_t out = kNone;
-        if (active && jp < m.pend) {
-            uint32_t ej = nf[m.begin + (jp - m.pbegin)];
-            if (ej < m.end) out = ej;
+        const unsigned long long act = __ballot(searched);
+        if (act) {
+            const int last = 63 - __clzll((long long)act);
+            hint_seg = __shfl(s, last);
+            hint = __shfl(jp, last);
         }
-        if (m.level == 0 && (uint32_t)e == m.begin) qstart[m.query] = me < m.end ? me : kNone;
-        jump[e] = out;
+        s_w = __shfl(s, 0);
     }
 }
 
@@ -691,38 +704,52 @@ __global__ void chain_emit_kernel(const uint32_t* __restrict__ rec_begin, const 
 
 // tuples of every match: walk the links from the level-0 element.  One thread per (query, match) slot of list 0.
 template <typename pos_t>
-__global__ void join_gather_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg, const SegMeta* __restrict__ sm,
-                                   const QueryMeta* __restrict__ qm, uint64_t r0, uint64_t r1, const uint32_t* __restrict__ link,
-                                   const uint32_t* __restrict__ mlist, const unsigned long long* __restrict__ counts,
-                                   uint64_t* __restrict__ out_first, uint64_t* __restrict__ out_tuples,
-                                   unsigned long long* __restrict__ checksum)
+__global__ void __launch_bounds__(256) join_gather_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
+                                                          const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint64_t r0,
+                                                          uint64_t r1, const uint32_t* __restrict__ link, const uint32_t* __restrict__ mlist,
+                                                          const unsigned long long* __restrict__ counts, uint64_t* __restrict__ out_first,
+                                                          uint64_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
 {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t run_begin = r0 + wave * kRun;
+    if (run_begin >= r1) return;
+    const uint64_t run_end = run_begin + kRun < r1 ? run_begin + kRun : r1;
+    uint32_t s_w = seg_find(seg_begin, nseg, run_begin);
     unsigned long long local = 0;
-    for (uint64_t e = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < r1; e += (uint64_t)gridDim.x * blockDim.x) {
-        const SegMeta m = sm[seg[e]];
-        if (m.level != 0) continue;
-        uint64_t t = e - m.begin;
-        if (t >= counts[m.query]) continue;
-        const QueryMeta Q = qm[m.query];
-        uint32_t el = mlist[e];                                // logical element of level 0
-        uint64_t first = P[phys_of(m, el)];
-        out_first[Q.out_first + t] = first;
-        local += first;
-        uint64_t* tp = out_tuples + Q.out_tuple + t * Q.k;
-        tp[0] = first;
-        if (Q.k > 1) {
-            uint32_t cur = link[el];
-            uint32_t sg = m.next;
-            for (uint32_t i = 1; i < Q.k; ++i) {
-                const SegMeta mi = sm[sg];
-                if (mi.dist == 0) { tp[i] = P[cur]; }          // link of a dist-1 element is a physical index
-                else { tp[i] = P[phys_of(mi, cur)]; cur = link[cur]; sg = mi.next; }
+    for (uint64_t base = run_begin; base < run_end; base += 64) {
+        const uint64_t e = base + lane;
+        uint32_t s = s_w;
+        if (e < run_end) {
+            while (seg_begin[s + 1] <= e) ++s;
+            const SegMeta m = sm[s];
+            const uint64_t t = e - m.begin;
+            if (m.level == 0 && t < counts[m.query]) {
+                const QueryMeta Q = qm[m.query];
+                uint32_t el = mlist[e];                                // logical element of level 0
+                uint64_t first = P[phys_of(m, el)];
+                out_first[Q.out_first + t] = first;
+                local += first;
+                uint64_t* tp = out_tuples + Q.out_tuple + t * Q.k;
+                tp[0] = first;
+                if (Q.k > 1) {
+                    uint32_t cur = link[el];
+                    uint32_t sg = m.next;
+                    for (uint32_t i = 1; i < Q.k; ++i) {
+                        const SegMeta mi = sm[sg];
+                        if (mi.dist == 0) { tp[i] = P[cur]; }          // link of a dist-1 element is a physical index
+                        else { tp[i] = P[phys_of(mi, cur)]; cur = link[cur]; sg = mi.next; }
+                    }
+                }
             }
         }
+        s_w = __shfl(s, 0);
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(checksum, local);
+    if (lane == 0 && local) atomicAdd(checksum, local);
 }
+
+inline uint32_t runs_grid(uint64_t slots) { return (uint32_t)((((slots + kRun - 1) / kRun) + 3) / 4); }   // 4 waves per workgroup
 
 inline uint32_t grid_for(uint64_t n, uint32_t cap = 16384) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, cap)); }
 
@@ -745,7 +772,7 @@ struct Plan {                       // host view of the batch after backward sea
 };
 
 template <typename pos_t> constexpr uint64_t kPhysScratchPerElem() { return sizeof(pos_t) == 4 ? 20 : sizeof(pos_t); }
-constexpr uint64_t kJoinBytesPerSlot = 7 * 4 + 8 + 1; // seg, link, nf, feas, jump, mlist, endp(<=8), chain records
+constexpr uint64_t kJoinBytesPerSlot = 6 * 4 + 8 + 1; // link, nf, feas, jump, mlist, endp(<=8), chain records
 
 // ---- physical pass: locate + sort every distinct interval used by queries [Q0,Q1) -------------------
 template <typename pos_t>
@@ -902,7 +929,6 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         auto rin = rocprim::make_reverse_iterator(nu);
         VLG_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_tmp, rin, rin, T, rocprim::minimum<uint32_t>(), st));
     }
-    uint32_t* seg = A.take<uint32_t>(T);
     uint32_t* link = A.take<uint32_t>(T);
     pos_t* endp = A.take<pos_t>(T);
     const uint64_t Tal = align_up(T, 64);
@@ -942,10 +968,9 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
     {
         Timed t(ws, KS_JOIN_LINK, 0);
-        hipLaunchKernelGGL(seg_ids_kernel, dim3(grid_for(T, 32768)), dim3(256), 0, st, d_segb, nlive, T, seg);
         if (cls_slot_end[0] > cls_slot_begin[0])
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_init_kernel<pos_t>), dim3(grid_for(cls_slot_end[0] - cls_slot_begin[0])), dim3(256), 0, st, P,
-                               seg, d_sm, cls_slot_begin[0], cls_slot_end[0], feas, endp);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_init_kernel<pos_t>), dim3(runs_grid(cls_slot_end[0] - cls_slot_begin[0])), dim3(256), 0, st, P,
+                               d_segb, nlive, d_sm, cls_slot_begin[0], cls_slot_end[0], feas, endp);
     }
     // nf is only ever read at slots of classes that are complete, so it is scanned class by class
     auto scan_class = [&](uint32_t d) -> vlg_status {
@@ -964,15 +989,15 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         uint64_t b0 = cls_slot_begin[dist], b1 = cls_slot_end[dist];
         if (b1 > b0) {
             Timed t(ws, KS_JOIN_LINK, 8ull * (b1 - b0));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t>), dim3(grid_for(b1 - b0)), dim3(256), 0, st, P, seg, d_sm, b0, b1, dist, nf,
-                               feas, endp, link);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, d_segb, nlive, d_sm, b0, b1,
+                               dist, nf, feas, endp, link);
         }
         if (vlg_status s = scan_class(dist)) return s;
     }
     {
         Timed t(ws, KS_JOIN_CHAIN, 0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(grid_for(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, seg, d_sm, d_qm,
-                           lvl0_begin, lvl0_end, nf, endp, jump, d_qstart);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(runs_grid(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, d_segb, nlive, d_sm,
+                           d_qm, lvl0_begin, lvl0_end, nf, endp, jump, d_qstart);
         uint2* xh = reinterpret_cast<uint2*>(fn);           // feas / nf are dead from here on
         const uint64_t t0 = lvl0_begin / kTile * kTile;
         if (t0 < lvl0_begin) VLG_HIP_TRY(hipMemsetAsync(jump + t0, 0xFF, (lvl0_begin - t0) * 4, st));   // slots of the first tile before the range
@@ -1000,8 +1025,8 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         res->pieces.push_back(piece);
         VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
         Timed t(ws, KS_GATHER, 8ull * (M + TV));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(grid_for(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, seg, d_sm, d_qm,
-                           lvl0_begin, lvl0_end, link, mlist, d_counts, piece.d_first, piece.d_tuples, d_stats + 2);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(runs_grid(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, d_segb, nlive,
+                           d_sm, d_qm, lvl0_begin, lvl0_end, link, mlist, d_counts, piece.d_first, piece.d_tuples, d_stats + 2);
         VLG_HIP_TRY(hipGetLastError());
     } else {
         res->pieces.push_back(piece);
