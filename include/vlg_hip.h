@@ -167,6 +167,18 @@ vlg_status vlg_locate_batch(const vlg_index* idx, const uint64_t* d_l, const uin
 #define VLG_DIALECT_BENCHMARK 1
 #define VLG_MAX_SUBPATTERNS 64
 
+/* Host-only view of one parsed query (no device involved): sub-pattern i = re[sub_off[i], sub_off[i]+sub_len[i]);
+ * lo/hi[i] (i >= 1) = start-to-start distance bounds between sub-patterns i-1 and i; end_len = length added to the
+ * last position for the non-overlap rule.  Returns VLG_E_PARSE / VLG_E_INVALID like vlg_queries_parse. */
+typedef struct {
+    uint32_t k;
+    uint32_t reserved;
+    uint64_t sub_off[VLG_MAX_SUBPATTERNS], sub_len[VLG_MAX_SUBPATTERNS];
+    uint64_t lo[VLG_MAX_SUBPATTERNS], hi[VLG_MAX_SUBPATTERNS];
+    uint64_t end_len;
+} vlg_parsed_query;
+vlg_status vlg_parse_query(const char* h_regexp, uint64_t len, int dialect, vlg_parsed_query* out);
+
 /* Parse `n_queries` regexps (concatenated in h_text; query q = h_text[h_off[q], h_off[q+1])) and upload.
  * h_status (optional, n_queries ints) receives VLG_OK / VLG_E_PARSE / VLG_E_INVALID per query; an
  * unparsable query stays in the batch as an always-empty query (the reference driver skips such

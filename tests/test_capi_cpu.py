@@ -58,3 +58,41 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"oracle|vlgo_|libvlgref|/root/reference", s):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_host_parser_matches_oracle_parser(V, oracle):
+    """vlg_parse_query (host logic of the product) against the oracle's restatement of both reference dialects."""
+    cases = ["ab.{2,5}?cde.{0,7}?f", "a", "abc.{0,0}?abc", "a.{1,2}b", "a.{3,2}?b", "a.{x,2}?b", "a.{1,2", ".{1,2}?b", "a.{1,2}?",
+             "a.{ 1, 2}?b", "a.{+1,2}?b", "a.{1,2}?b.{3,4}c", "x.{0,18446744073709551616}?y", "x.{0,4611686018427387903}?y",
+             "ab.{2,5}cde.{0,7}f", "A.{0,100}C", "A.{0,100}?C", "q.{1}?r", "a.{1,2}?b.{5,6}?c.{7,8}?d"]
+    for dialect in (0, 1):
+        for c in cases:
+            try:
+                want = oracle.query_fields(oracle.parse(c, dialect))
+            except oracle.ParseError as e:
+                with pytest.raises(V.VlgError) as ee:
+                    V.parse_query(c, dialect)
+                assert ee.value.status == (V.capi.E_INVALID if e.code == 4 else V.capi.E_PARSE), c
+                continue
+            subs, lo, hi, end = V.parse_query(c, dialect)
+            assert (subs, lo, hi, end) == (want[0], want[1], want[2], want[3]), (c, dialect)
+
+
+def test_huge_gap_bounds_are_rejected_not_wrapped(V):
+    """The reference wraps `max + |s|` modulo 2^64 (vlg_index.hpp:95); the product rejects bounds >= 2^62."""
+    for c in ("x.{0,18446744073709551615}?y", "x.{0,4611686018427387904}?y"):
+        with pytest.raises(V.VlgError) as e:
+            V.parse_query(c, 0)
+        assert e.value.status == V.capi.E_INVALID
+
+
+def test_cpp_host_binaries_fail_loudly_without_gpu(V):
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(ROOT, "vlg_matching_amd", "bin", "vlg_matching_example")
+    if not os.path.exists(exe):
+        V.build_library()
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device" in r.stderr

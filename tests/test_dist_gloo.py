@@ -1,0 +1,91 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard a query batch, search their slices (the oracle stands in for
+the GPU matcher here -- tests may use it) and reduce the totals; the result must equal the single-process run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, text, queries, weights, out_q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from vlg_matching_amd import dist as vdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx = O.Index.from_text(text)
+
+    def search_fn(qs):
+        counts, chk, st = [], 0, np.zeros(4, dtype=np.uint64)
+        for q in qs:
+            t = idx.search(q, stats=st)
+            counts.append(len(t))
+            chk = (chk + int(t[:, 0].sum())) % (1 << 63) if len(t) else chk
+        return counts, chk, int(st[0])
+
+    r = vdist.run_sharded(search_fn, queries, dist, weights)
+    out_q.put((rank, r["local_range"], r["num_results"], r["checksum"], r["located"], list(map(int, r["counts"]))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("by_work", [False, True])
+def test_two_ranks_equal_one(oracle, by_work):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from util import dna_text
+    from vlg_matching_amd import dist as vdist
+    text = dna_text(30000, 5).tobytes()
+    rng = np.random.default_rng(4)
+    queries = []
+    for _ in range(61):
+        a, b = (int(x) for x in rng.integers(0, len(text) - 6, 2))
+        queries.append("%s.{0,40}?%s" % (text[a:a + int(rng.integers(1, 5))].decode(), text[b:b + int(rng.integers(1, 5))].decode()))
+    idx = oracle.Index.from_text(text)
+    st = np.zeros(4, dtype=np.uint64)
+    ref = [idx.search(q, stats=st) for q in queries]
+    want_counts = [len(t) for t in ref]
+    want_chk = sum(int(t[:, 0].sum()) for t in ref if len(t)) % (1 << 63)
+    weights = None
+    if by_work:
+        weights = [sum(idx.backward_search(s)[0] for s in oracle.query_fields(oracle.parse(q))[0]) for q in queries]
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, text, queries, weights, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(out_q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (b0, e0), (b1, e1) = got[0][1], got[1][1]
+    assert b0 == 0 and e0 == b1 and e1 == len(queries)
+    assert got[0][5] + got[1][5] == want_counts
+    for g in got:
+        assert g[2] == sum(want_counts) and g[3] == want_chk and g[4] == int(st[0])
+    if by_work:
+        assert vdist.shard_by_work(weights, 2) == [(b0, e0), (b1, e1)]
+
+
+def test_shard_bounds_cover_exactly():
+    from vlg_matching_amd import dist as vdist
+    for n in (0, 1, 7, 8, 100001):
+        for w in (1, 2, 3, 8):
+            parts = [vdist.shard_bounds(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert max(e - b for b, e in parts) - min(e - b for b, e in parts) <= 1

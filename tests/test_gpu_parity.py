@@ -265,7 +265,7 @@ def test_search_chunked_equals_unchunked(V):
     qs = random_queries(text, np.random.default_rng(9), 300, kmax=3, mmax=3)
     from vlg_matching_amd.index import Workspace
     a = idx.search(qs)
-    b = idx.search(qs, workspace=Workspace(max_hbm_bytes=(90 << 20)))
+    b = idx.search(qs, workspace=Workspace(max_hbm_bytes=(48 << 20)))
     assert b.summary["n_chunks"] > a.summary["n_chunks"]
     for k in ("n_matches", "checksum", "n_tuple_values", "logical_occurrences"):
         assert a.summary[k] == b.summary[k], k
@@ -299,3 +299,66 @@ def test_locate_sorted_sweep_equals_random_access_kernel(V, oracle, name, seed):
         assert b.tuples(i).tolist() == o.search(q, stats=occ).tolist()
     assert b.summary["lf_steps"] == int(occ[1]) and b.summary["wt_levels_locate"] == int(occ[2])
     assert "locate_partition" in ws_b.kernel_stats() and ws_b.kernel_stats()["locate_partition"]["launches"] > 0
+
+
+def _bin(name):
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vlg_matching_amd", "bin", name)
+
+
+def test_cpp_example_prints_reference_answers(V):
+    """vlg_matching_example mirrors examples/vlg_matching.cpp:10-22; expected values are the reference's known answers."""
+    import subprocess
+    out = subprocess.run([_bin("vlg_matching_example")], capture_output=True, text=True, check=True).stdout
+    want = """
+count(ac.{2,5}?a.{4,8}?b)=1
+locate(ac.{2,5}?a.{4,8}?b)=
+  1. occ starting at position 3
+     Subpattern positions: 3 10 18
+
+count(a.{0,10}?a.{0,10}?a)=2
+locate(a.{0,10}?a.{0,10}?a)=
+  1. occ starting at position 0
+     Subpattern positions: 0 3 5
+  2. occ starting at position 7
+     Subpattern positions: 7 10 15
+
+count(foo.{0,10}?bar)=0
+locate(foo.{0,10}?bar)=
+"""
+    assert out == want
+
+
+def test_cpp_driver_pipeline_matches_oracle(V, oracle, tmp_path):
+    """gm_index_gpu + gm_search_gpu on a generated collection: the machine-readable lines of gm_search.cpp:142-160."""
+    import subprocess
+    raw = dna_text(200000, 31).tobytes().replace(b"GATTACA", b"GAT\nACA")     # newline -> space like create_collection
+    (tmp_path / "raw.txt").write_bytes(raw)
+    col = str(tmp_path / "col")
+    subprocess.run([_bin("gm_index_gpu"), "-c", col, "-i", str(tmp_path / "raw.txt")], check=True, capture_output=True)
+    text = raw.replace(b"\n", b" ")
+    rng = np.random.default_rng(8)
+    pats = []
+    for _ in range(200):
+        k = int(rng.integers(2, 4))
+        subs = [text[s:s + 5].decode() for s in rng.integers(0, len(text) - 6, k)]
+        pats.append((".{%d,%d}" % (0, int(rng.integers(10, 300)))).join(subs))
+    pats.insert(7, "AC.{9,3}GT")                                                  # unparsable line is skipped
+    (tmp_path / "pats.txt").write_text("\n".join(pats) + "\n", encoding="latin-1")
+    out = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt")], check=True, capture_output=True, text=True).stdout
+    kv = dict(l[2:].split(" = ") for l in out.splitlines() if l.startswith("# ") and " = " in l)
+    o = oracle.Index.from_text(text)
+    n, chk = 0, 0
+    for p in pats:
+        try:
+            t = o.search(p, dialect=1)
+        except oracle.ParseError:
+            continue
+        n += len(t)
+        chk = (chk + int(t[:, 0].sum())) % (1 << 64) if len(t) else chk
+    assert int(kv["num_results"]) == n and int(kv["checksum"]) == chk
+    assert int(kv["num_patterns"]) == len(pats) - 1
+    for key in ("total_time_mus", "min_time_mus", "qrt_1st_time_mus", "mean_time_mus", "median_time_mus", "qrt_3rd_time_mus", "max_time_mus"):
+        assert key in kv
+    out1 = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt"), "-1"], check=True, capture_output=True, text=True).stdout
+    kv1 = dict(l[2:].split(" = ") for l in out1.splitlines() if l.startswith("# ") and " = " in l)
+    assert kv1["num_results"] == kv["num_results"] and kv1["checksum"] == kv["checksum"]

@@ -43,6 +43,11 @@ class ResultSummary(C.Structure):
                                            "logical_occurrences")]
 
 
+class ParsedQuery(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("reserved", C.c_uint32), ("sub_off", C.c_uint64 * 64), ("sub_len", C.c_uint64 * 64),
+                ("lo", C.c_uint64 * 64), ("hi", C.c_uint64 * 64), ("end_len", C.c_uint64)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_uint64)]
 
@@ -71,6 +76,7 @@ SYMBOLS = [
     ("vlg_backward_search_batch", _I, [_P, _P, _P, _U64, _P, _P, _P]),
     ("vlg_sa_batch", _I, [_P, _P, _P, _U64, _P]),
     ("vlg_locate_batch", _I, [_P, _P, _P, _P, _U64, _U64, _P, _P]),
+    ("vlg_parse_query", _I, [C.c_char_p, _U64, _I, C.POINTER(ParsedQuery)]),
     ("vlg_queries_parse", _I, [C.c_char_p, _P, _U64, _I, _P, C.POINTER(_P)]),
     ("vlg_queries_create", _I, [_P, _P, _P, _P, _P, _P, _U64, C.POINTER(_P)]),
     ("vlg_queries_count", _U64, [_P]),

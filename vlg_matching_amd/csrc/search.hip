@@ -83,6 +83,8 @@ vlg_status parse_one(const char* re, uint64_t len, int dialect, Parsed& out, std
             return VLG_E_PARSE;
         }
         if (a > b) { why = "invalid gap description: min-gap > max-gap"; return VLG_E_PARSE; }           // vlg_index.hpp:92-94
+        // the reference adds |s| modulo 2^64 (vlg_index.hpp:95); bounds that large are rejected instead of wrapped
+        if (b >= (1ull << 62)) { why = "gap bound too large (>= 2^62)"; return VLG_E_INVALID; }
         out.sub.emplace_back(start, gp - start);
         raw_lo.push_back(a);
         raw_hi.push_back(b);
@@ -105,16 +107,12 @@ vlg_status parse_one(const char* re, uint64_t len, int dialect, Parsed& out, std
         for (size_t i = 1; i < k; ++i) {                                                                // vlg_index.hpp:95
             out.lo[i] = raw_lo[i] + out.sub[i - 1].second;
             out.hi[i] = raw_hi[i] + out.sub[i - 1].second;
-            if (out.hi[i] < raw_hi[i]) out.hi[i] = ~0ull;
-            if (out.lo[i] < raw_lo[i]) out.lo[i] = ~0ull;
         }
         out.end_len = out.sub[k - 1].second;                                                            // vlg_index.hpp:262,306
     } else {
         for (size_t i = 1; i < k; ++i) {                                                                // index_sasearch.hpp:68-69
             out.lo[i] = raw_lo[1] + out.sub[0].second;
             out.hi[i] = raw_hi[1] + out.sub[0].second;
-            if (out.hi[i] < raw_hi[1]) out.hi[i] = ~0ull;
-            if (out.lo[i] < raw_lo[1]) out.lo[i] = ~0ull;
         }
         out.end_len = out.sub[0].second;                                                                // index_sasearch.hpp:113
     }
@@ -133,6 +131,24 @@ vlg_status upload_queries(vlg_queries* q)
 }
 
 }  // namespace
+
+extern "C" vlg_status vlg_parse_query(const char* re, uint64_t len, int dialect, vlg_parsed_query* out)
+{
+    if (!out || (len && !re)) return fail(VLG_E_INVALID, "null argument");
+    if (dialect != VLG_DIALECT_LIBRARY && dialect != VLG_DIALECT_BENCHMARK) return fail(VLG_E_INVALID, "unknown dialect");
+    memset(out, 0, sizeof *out);
+    Parsed p;
+    std::string why;
+    vlg_status st = parse_one(re, len, dialect, p, why);
+    if (st) return fail(st, why);
+    out->k = (uint32_t)p.sub.size();
+    for (uint32_t i = 0; i < out->k; ++i) {
+        out->sub_off[i] = p.sub[i].first; out->sub_len[i] = p.sub[i].second;
+        out->lo[i] = p.lo[i]; out->hi[i] = p.hi[i];
+    }
+    out->end_len = p.end_len;
+    return VLG_OK;
+}
 
 extern "C" vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_off, uint64_t n_queries, int dialect, int* h_status,
                                         vlg_queries** out)
@@ -194,6 +210,9 @@ extern "C" vlg_status vlg_queries_create(const uint8_t* h_blob, const uint64_t* 
     if (q->nsub) q->blob.assign(h_blob, h_blob + q->suboff[q->nsub]);
     q->lo.assign(h_lo, h_lo + q->nsub);
     q->hi.assign(h_hi, h_hi + q->nsub);
+    for (uint64_t i = 0; i < n_queries; ++i)
+        for (uint64_t sidx = q->qsub[i] + 1; sidx < q->qsub[i + 1]; ++sidx)
+            if (q->lo[sidx] > q->hi[sidx] || q->hi[sidx] >= (1ull << 63)) { delete q; return fail(VLG_E_INVALID, "bad gap bounds"); }
     q->end_len.assign(h_end_len, h_end_len + n_queries);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete q; return fail(VLG_E_NO_DEVICE, "no HIP device available"); }
@@ -1044,7 +1063,7 @@ template <typename pos_t>
 vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result* res, const Plan& pl,
                      unsigned long long* d_stats)
 {
-    const uint64_t fixed = 64ull << 20;
+    const uint64_t fixed = 8ull << 20;      // alignment slack + per-chunk metadata
     if (ws->cap_bytes <= 2 * fixed) return fail(VLG_E_WORKSPACE, "workspace cap too small");
     const uint64_t budget = ws->cap_bytes - fixed;
     // physical lists take at most half of the budget (two buffers during the sort)

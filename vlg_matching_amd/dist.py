@@ -1,0 +1,62 @@
+"""One process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm): the read-only index is built once and its
+contiguous HBM image is broadcast over xGMI, query batches are sharded, only three counters are reduced.
+There is no exchange step inside a query, so no other collective exists on this path."""
+import numpy as np
+
+
+def shard_bounds(n_items, rank, world):
+    """Contiguous, balanced [begin, end) slice of n_items for `rank` (sizes differ by at most one)."""
+    base, extra = divmod(n_items, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_by_work(weights, world):
+    """Contiguous slices with roughly equal total weight (e.g. sum of SA-interval sizes per query): heavy-tailed
+    occurrence counts make equal query counts a poor balance.  -> list of (begin, end)"""
+    w = np.asarray(weights, dtype=np.float64)
+    total = float(w.sum())
+    if total <= 0:
+        return [shard_bounds(len(w), r, world) for r in range(world)]
+    cum = np.cumsum(w)
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(max(cuts[-1], int(np.searchsorted(cum, total * r / world, side="left"))))
+    cuts.append(len(w))
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def replicate_index(idx, dist, device, src=0):
+    """Broadcast the index image from rank `src` to every rank's HBM and attach to it.  `idx` is None elsewhere."""
+    import torch
+    from .index import VlgIndex
+    rank = dist.get_rank()
+    nb = torch.tensor([idx.blob_bytes() if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(nb, src)
+    blob = torch.empty(int(nb.item()), dtype=torch.uint8, device=device)
+    if rank == src:
+        idx.blob_export(blob.data_ptr(), blob.numel())
+    dist.broadcast(blob, src)
+    if rank == src:
+        return idx
+    return VlgIndex.attach_blob(blob.data_ptr(), blob.numel(), keep=blob)
+
+
+def run_sharded(search_fn, queries, dist=None, weights=None):
+    """Search this rank's slice of `queries` with search_fn(list) -> (counts[q], checksum, located) and reduce the totals.
+    -> dict(local_range, counts (local), num_results, checksum, located)   [totals are global]"""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    b, e = (shard_by_work(weights, world)[rank] if weights is not None else shard_bounds(len(queries), rank, world))
+    counts, checksum, located = search_fn(queries[b:e])
+    tot = np.array([int(np.sum(counts)), int(checksum) % (1 << 63), int(located)], dtype=np.int64)
+    if dist is not None and world > 1:
+        import torch
+        t = torch.from_numpy(tot.copy())
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        # checksum is a wrapping 64-bit sum; summing the 63-bit residues mod 2^63 keeps it exact below 2^63
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tot = t.cpu().numpy()
+    return {"local_range": (b, e), "counts": np.asarray(counts), "num_results": int(tot[0]),
+            "checksum": int(tot[1]) % (1 << 63), "located": int(tot[2])}

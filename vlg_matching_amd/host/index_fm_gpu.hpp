@@ -1,0 +1,158 @@
+// index_fm_gpu -- satisfies the benchmark's index concept (what bench_index<t_idx> / create_and_store<t_idx> use:
+// benchmark/gapped-matching/src/gm_search.cpp:62-105, gm_index.cpp:38-60; exemplar index_sasearch.hpp:7-119) on top of
+// the C-ABI, plus the batched entry a GPU needs (search_batch).  Value semantics like the reference: the object owns
+// its HBM-resident index.
+#pragma once
+#include <iostream>
+#include <memory>
+#include "gapped_pattern.hpp"
+
+namespace vlg_host {
+
+class index_fm_gpu
+{
+  private:
+    vlg_index* m_idx = nullptr;
+    vlg_workspace* m_ws = nullptr;
+
+    void ensure_ws()
+    {
+        if (!m_ws) check(vlg_workspace_create(0, nullptr, &m_ws));
+    }
+
+  public:
+    typedef uint64_t size_type;
+    std::string name() const { return "FMGPU-csa_wt_wt_huff_d32"; }
+
+    index_fm_gpu() {}
+    // index_*(collection&): build from <col>/text.TEXT (index_sasearch.hpp:23-31) -- suffix sort, BWT, wavelet tree on the device
+    explicit index_fm_gpu(collection& col)
+    {
+        std::vector<uint8_t> text = read_text_file(col.file_map["TEXT"]);
+        check(vlg_index_build(text.data(), text.size(), 32, &m_idx));
+    }
+    explicit index_fm_gpu(const std::vector<uint8_t>& text) { check(vlg_index_build(text.data(), text.size(), 32, &m_idx)); }
+    index_fm_gpu(const index_fm_gpu&) = delete;
+    index_fm_gpu& operator=(const index_fm_gpu&) = delete;
+    ~index_fm_gpu()
+    {
+        if (m_ws) vlg_workspace_destroy(m_ws);
+        if (m_idx) vlg_index_destroy(m_idx);
+    }
+
+    // serialize / load: the index parts in the reference's own layout (bit-vector, tree nodes, C, samples)
+    size_type serialize(std::ostream& out, void* = nullptr, std::string = "") const
+    {
+        vlg_index_parts sz;
+        check(vlg_index_export_parts(m_idx, &sz, nullptr));
+        std::vector<uint8_t> c2c(256);
+        std::vector<uint64_t> C(257), bv((sz.bv_bits + 63) / 64 + 1), smp(sz.n_samples + 1);
+        std::vector<vlg_wt_node> nodes(sz.n_nodes + 1);
+        vlg_index_parts_out o{c2c.data(), C.data(), bv.data(), nodes.data(), smp.data()};
+        check(vlg_index_export_parts(m_idx, &sz, &o));
+        const char magic[8] = {'V', 'L', 'G', 'P', 'A', 'R', 'T', '1'};
+        uint64_t hdr[6] = {sz.n, sz.sigma, sz.sa_sample_dens, sz.bv_bits, sz.n_nodes, sz.n_samples};
+        out.write(magic, 8);
+        out.write((const char*)hdr, sizeof hdr);
+        out.write((const char*)c2c.data(), 256);
+        out.write((const char*)C.data(), 257 * 8);
+        out.write((const char*)bv.data(), (std::streamsize)(((sz.bv_bits + 63) / 64) * 8));
+        out.write((const char*)nodes.data(), (std::streamsize)(sz.n_nodes * sizeof(vlg_wt_node)));
+        out.write((const char*)smp.data(), (std::streamsize)(sz.n_samples * 8));
+        return 8 + sizeof hdr + 256 + 257 * 8 + ((sz.bv_bits + 63) / 64) * 8 + sz.n_nodes * sizeof(vlg_wt_node) + sz.n_samples * 8;
+    }
+
+    void load(std::istream& in)
+    {
+        char magic[8];
+        uint64_t hdr[6];
+        in.read(magic, 8);
+        in.read((char*)hdr, sizeof hdr);
+        if (!in || std::string(magic, 8) != "VLGPART1") throw std::runtime_error("not a VLG index file");
+        std::vector<uint8_t> c2c(256);
+        std::vector<uint64_t> C(257), bv((hdr[3] + 63) / 64 + 1), smp(hdr[5] + 1);
+        std::vector<vlg_wt_node> nodes(hdr[4] + 1);
+        in.read((char*)c2c.data(), 256);
+        in.read((char*)C.data(), 257 * 8);
+        in.read((char*)bv.data(), (std::streamsize)(((hdr[3] + 63) / 64) * 8));
+        in.read((char*)nodes.data(), (std::streamsize)(hdr[4] * sizeof(vlg_wt_node)));
+        in.read((char*)smp.data(), (std::streamsize)(hdr[5] * 8));
+        if (!in) throw std::runtime_error("truncated VLG index file");
+        vlg_index_parts p{hdr[0], (uint32_t)hdr[1], (uint32_t)hdr[2], c2c.data(), C.data(), bv.data(), hdr[3], nodes.data(), (uint32_t)hdr[4],
+                          smp.data(), hdr[5]};
+        if (m_idx) { vlg_index_destroy(m_idx); m_idx = nullptr; }
+        check(vlg_index_from_parts(&p, &m_idx));
+    }
+
+    void swap(index_fm_gpu& o)
+    {
+        std::swap(m_idx, o.m_idx);
+        std::swap(m_ws, o.m_ws);
+    }
+
+    std::string info(const gapped_pattern&) const { return ""; }
+    void prepare(const gapped_pattern&) {}
+
+    // idx.search(pat): one query (index_sasearch.hpp:58-118).  Per-query calls cannot feed a GPU; use search_batch.
+    gapped_search_result search(const gapped_pattern& pat)
+    {
+        std::vector<gapped_search_result> r = search_batch({pat});
+        return r[0];
+    }
+
+    // all patterns in one pass of the hot path; results[i].positions = first sub-pattern starts of query i
+    std::vector<gapped_search_result> search_batch(const std::vector<gapped_pattern>& pats, int dialect = VLG_DIALECT_BENCHMARK,
+                                                   vlg_result_summary* summary = nullptr)
+    {
+        ensure_ws();
+        std::string text;
+        std::vector<uint64_t> off(1, 0);
+        for (const auto& p : pats) { text += p.raw_regexp; off.push_back(text.size()); }
+        std::vector<int> status(pats.size() + 1, 0);
+        vlg_queries* q = nullptr;
+        check(vlg_queries_parse(text.data(), off.data(), pats.size(), dialect, status.data(), &q));
+        vlg_result* r = nullptr;
+        vlg_status st = vlg_search_batch(m_idx, q, m_ws, &r);
+        vlg_queries_destroy(q);
+        check(st);
+        vlg_result_summary s;
+        check(vlg_result_summary_get(r, &s));
+        if (summary) *summary = s;
+        std::vector<uint64_t> offsets(pats.size() + 1), first(s.n_matches + 1);
+        st = vlg_result_fetch(r, nullptr, offsets.data(), first.data(), nullptr);
+        vlg_result_destroy(r);
+        check(st);
+        std::vector<gapped_search_result> out(pats.size());
+        for (size_t i = 0; i < pats.size(); ++i) out[i].positions.assign(first.begin() + offsets[i], first.begin() + offsets[i + 1]);
+        return out;
+    }
+
+    // sdsl::locate(idx, query) (include/sdsl/vlg_index.hpp:395-401): every sub-pattern position of every match
+    std::vector<std::vector<uint64_t>> locate(const std::string& query)
+    {
+        ensure_ws();
+        uint64_t off[2] = {0, query.size()};
+        vlg_queries* q = nullptr;
+        check(vlg_queries_parse(query.data(), off, 1, VLG_DIALECT_LIBRARY, nullptr, &q));
+        uint32_t k = 0;
+        check(vlg_queries_k(q, &k));
+        vlg_result* r = nullptr;
+        vlg_status st = vlg_search_batch(m_idx, q, m_ws, &r);
+        vlg_queries_destroy(q);
+        check(st);
+        vlg_result_summary s;
+        check(vlg_result_summary_get(r, &s));
+        std::vector<uint64_t> tuples(s.n_tuple_values + 1);
+        st = vlg_result_fetch(r, nullptr, nullptr, nullptr, tuples.data());
+        vlg_result_destroy(r);
+        check(st);
+        std::vector<std::vector<uint64_t>> out(s.n_matches);
+        for (uint64_t m = 0; m < s.n_matches; ++m) out[m].assign(tuples.begin() + m * k, tuples.begin() + (m + 1) * k);
+        return out;
+    }
+    uint64_t count(const std::string& query) { return locate(query).size(); }
+
+    vlg_index* handle() const { return m_idx; }
+};
+
+}  // namespace vlg_host

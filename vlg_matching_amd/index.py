@@ -97,6 +97,15 @@ class Workspace:
                                            algorithmic_bytes=int(arr[i].algorithmic_bytes)) for i in range(n.value)}
 
 
+def parse_query(regexp, dialect=capi.DIALECT_LIBRARY):
+    """gapped_pattern_query / gapped_pattern on the host: -> (sub-patterns, lo[], hi[], end_len).  Raises VlgError(E_PARSE)."""
+    raw = regexp.encode("latin-1") if isinstance(regexp, str) else bytes(regexp)
+    p = capi.ParsedQuery()
+    check(lib().vlg_parse_query(raw, len(raw), dialect, C.byref(p)))
+    subs = [raw[p.sub_off[i]: p.sub_off[i] + p.sub_len[i]] for i in range(p.k)]
+    return subs, [int(p.lo[i]) for i in range(1, p.k)], [int(p.hi[i]) for i in range(1, p.k)], int(p.end_len)
+
+
 class Queries:
     """A parsed query batch resident in HBM."""
 
