@@ -23,6 +23,15 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
+# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/*_pmc_*.csv; FETCH_SIZE + WRITE_SIZE,
+# KiB -> bytes); filled in by tools/pmc_summary.py.  None = not measured for that kernel.
+PMC_TRAFFIC = {}
+try:
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as _f:
+        PMC_TRAFFIC = {k: v["bytes_per_launch"] for k, v in json.load(_f).items()}
+except Exception:
+    pass
+
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
@@ -168,11 +177,20 @@ def main():
     kstats = ws.kernel_stats()
 
     if rank == 0:
-        loc = kstats["locate"]
-        launches = max(loc["launches"], 1)
-        per_launch_ms = loc["total_ms"] / launches
-        alg_bytes_per_launch = loc["algorithmic_bytes"] / launches
-        achieved = alg_bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        def roof(name, kernel):
+            st = kstats[name]
+            launches = max(st["launches"], 1)
+            ms = st["total_ms"] / launches
+            alg = st["algorithmic_bytes"] / launches
+            ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"bound": "hbm", "kernel": kernel, "kernel_class": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC.get(kernel), "algorithmic_bytes_per_launch": alg,
+                    "avg_launch_ms": ms, "launches": st["launches"], "ms_per_step": st["total_ms"] / args.steps}
+        names = {"locate": "sweep_step_kernel" if kstats["locate_partition"]["launches"] else "locate_kernel",
+                 "join_link": "join_link_kernel", "join_scan": "rocprim scan (reverse min)", "join_chain": "join_jump+chain_tiles/walk/emit",
+                 "gather": "join_gather_kernel", "sort": "rocprim segmented_radix_sort", "locate_partition": "rocprim radix_sort_pairs",
+                 "backward_search": "backward_search_kernel", "expand": "expand_kernel"}
+        dominant = max(kstats, key=lambda k: kstats[k]["total_ms"])
         out = {
             "metric": "vlg_queries_per_sec",
             "value": n_queries * args.steps / dt,
@@ -203,10 +221,8 @@ def main():
             "index_build_s": t_build, "text_gen_s": t_gen,
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kstats.items()},
             "kernels_ms_sum_per_step": sum(v["total_ms"] for v in kstats.values()) / args.steps,
-            "roofline": {"bound": "hbm", "kernel": "locate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": per_launch_ms,
-                         "launches": loc["launches"]},
+            "roofline": roof(dominant, names[dominant]),                 # the dominant kernel class of the step
+            "rank_kernel_roofline": roof("locate", names["locate"]),     # the LF / bit-rank kernel the north star names
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(idx, queries, n_logical / max(n_queries, 1))

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes into profiles/pmc_traffic.json (HBM bytes per launch per kernel).
+
+usage: tools/pmc_summary.py <counter_collection.csv with FETCH_SIZE> <counter_collection.csv with WRITE_SIZE> [tag]
+FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3).  gfx950 caveat (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reads half
+the bytes of wide coalesced streaming reads; for the 64-byte random requests of this workload tools/k1_bench.py
+calibrates it at 1.0 (FETCH_SIZE = TCC_EA0_RDREQ x 64 B, one request per 32-byte block read).  Both raw and
+stream-corrected (x2) read figures are kept; `bytes_per_launch` uses the raw read figure + writes."""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+
+def load(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            name = re.sub(r"^void ", "", r["Kernel_Name"])
+            name = re.sub(r"\(anonymous namespace\)::", "", name).split("(")[0].split("<")[0]
+            agg[name].append(float(r["Counter_Value"]) * 1024.0)
+    return agg
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    tag = sys.argv[3] if len(sys.argv) > 3 else ""
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, []), write.get(k, [])
+        if not f and not w:
+            continue
+        rd = sum(f) / max(len(f), 1)
+        wr = sum(w) / max(len(w), 1)
+        out[k] = {"launches": max(len(f), len(w)), "read_bytes_per_launch_raw": rd, "read_bytes_per_launch_x2_if_streaming": 2 * rd,
+                  "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr, "tag": tag}
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
+    for k, v in out.items():
+        print("%-40s launches %5d  read %.3e  write %.3e" % (k, v["launches"], v["read_bytes_per_launch_raw"], v["write_bytes_per_launch"]))
+
+
+if __name__ == "__main__":
+    main()

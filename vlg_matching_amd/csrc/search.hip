@@ -1014,7 +1014,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         if (vlg_status s = scan_class(dist)) return s;
     }
     {
-        Timed t(ws, KS_JOIN_CHAIN, 0);
+        Timed t(ws, KS_JOIN_CHAIN, 8ull * (lvl0_end - lvl0_begin));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(runs_grid(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, d_segb, nlive, d_sm,
                            d_qm, lvl0_begin, lvl0_end, nf, endp, jump, d_qstart);
         uint2* xh = reinterpret_cast<uint2*>(fn);           // feas / nf are dead from here on
