@@ -248,7 +248,10 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
  * have the same SA interval; 0 = locate every sub-pattern of every query separately like the reference.
  * "sweep" (default 1): locate by the synchronous sorted LF sweep (coalesced super-block reads) when the batch has
  * at least "sweep_min" occurrences (default 2^22); the last "sweep_tail" (default 2^20) stragglers and smaller
- * batches use the one-lane-per-occurrence random-access kernel.  Results are identical either way. */
+ * batches use the one-lane-per-occurrence random-access kernel.
+ * "lazy_join" (default 0, experimental): follow the match chains lazily with tile speculation (queries of up to 8
+ * sub-patterns) instead of the dense passes that evaluate every list element; pays only for sparse lists.
+ * Results are identical whatever the options. */
 vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* name, int64_t value);
 vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n);
 

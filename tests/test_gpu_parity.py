@@ -258,14 +258,18 @@ def test_search_benchmark_dialect_and_bad_queries(V, oracle):
         assert res.tuples(i).tolist() == want.tolist() or (len(want) == 0 and int(res.counts[i]) == 0), q
 
 
-def test_search_chunked_equals_unchunked(V):
+@pytest.mark.parametrize("lazy,cap_mb", [(1, 24), (0, 48)])
+def test_search_chunked_equals_unchunked(V, lazy, cap_mb):
     """A tiny workspace forces many chunks; results must not change."""
     text = TEXTS["dna_50k"]()
     idx = V.VlgIndex.build(text)
     qs = random_queries(text, np.random.default_rng(9), 300, kmax=3, mmax=3)
     from vlg_matching_amd.index import Workspace
-    a = idx.search(qs)
-    b = idx.search(qs, workspace=Workspace(max_hbm_bytes=(48 << 20)))
+    wa, wb = Workspace(), Workspace(max_hbm_bytes=(cap_mb << 20))
+    wa.set_option("lazy_join", lazy)
+    wb.set_option("lazy_join", lazy)
+    a = idx.search(qs, workspace=wa)
+    b = idx.search(qs, workspace=wb)
     assert b.summary["n_chunks"] > a.summary["n_chunks"]
     for k in ("n_matches", "checksum", "n_tuple_values", "logical_occurrences"):
         assert a.summary[k] == b.summary[k], k
@@ -362,3 +366,40 @@ def test_cpp_driver_pipeline_matches_oracle(V, oracle, tmp_path):
     out1 = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt"), "-1"], check=True, capture_output=True, text=True).stdout
     kv1 = dict(l[2:].split(" = ") for l in out1.splitlines() if l.startswith("# ") and " = " in l)
     assert kv1["num_results"] == kv["num_results"] and kv1["checksum"] == kv["checksum"]
+
+
+@pytest.mark.parametrize("name,seed,kmax", [("dna_50k", 41, 5), ("dna_skew", 42, 8), ("zipf40", 43, 4), ("100a", 44, 3), ("dna_50k", 45, 11)])
+def test_lazy_join_equals_dense_join_and_oracle(V, oracle, name, seed, kmax):
+    """The lazy tile-speculative join and the dense passes are two evaluations of the same least fixed points."""
+    from vlg_matching_amd.index import Workspace
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    rng = np.random.default_rng(seed)
+    qs = random_queries(text, rng, 250, kmax=kmax, mmax=3, gapmax=40, gaplo=8)
+    qs += random_queries(text, rng, 60, kmax=2, mmax=1, gapmax=3, gaplo=2)          # dense lists, tight gaps: many tiles, many overlaps
+    ws_d, ws_l = Workspace(), Workspace()
+    ws_d.set_option("lazy_join", 0)
+    ws_l.set_option("lazy_join", 1)
+    a, b = idx.search(qs, workspace=ws_d), idx.search(qs, workspace=ws_l)
+    for k in ("n_matches", "checksum", "n_tuple_values", "logical_occurrences"):
+        assert a.summary[k] == b.summary[k], k
+    for x, y in zip(a.fetch(), b.fetch()):
+        assert (x == y).all()
+    for i in list(range(0, len(qs), 7)) + [len(qs) - 1]:
+        assert b.tuples(i).tolist() == o.search(qs[i]).tolist(), qs[i]
+
+
+def test_join_many_tiles_single_pattern(V, oracle):
+    """k = 1 and k = 2 on a list spanning many tiles (non-overlap chains cross tile borders all the time)."""
+    text = (b"ab" * 30000) + dna_text(5000, 3).tobytes() + (b"aab" * 9000)
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    from vlg_matching_amd.index import Workspace
+    qs = ["a", "ab", "aba", "a.{0,0}?b", "a.{1,3}?a", "b.{0,5}?a.{0,2}?b", "ab.{2,2}?ab", "a.{0,1}?a.{0,1}?a.{0,1}?a"]
+    for lazy in (0, 1):
+        ws = Workspace()
+        ws.set_option("lazy_join", lazy)
+        res = idx.search(qs, workspace=ws)
+        for i, qq in enumerate(qs):
+            assert res.tuples(i).tolist() == o.search(qq).tolist(), (qq, lazy)
