@@ -240,8 +240,8 @@ extern "C" void vlg_queries_destroy(vlg_queries* q)
 // =============================================================================================
 // Workspace
 // =============================================================================================
-enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_LOCATE_PART, KS_SORT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_COUNT };
-static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "locate_partition", "sort", "join_link", "join_scan", "join_chain", "gather"};
+enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_LOCATE_PART, KS_SORT, KS_JOIN_INIT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_COUNT };
+static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "locate_partition", "sort", "join_init", "join_link", "join_scan", "join_chain", "gather"};
 
 struct vlg_workspace {
     hipStream_t stream = nullptr;
@@ -500,6 +500,38 @@ __device__ __forceinline__ uint32_t gallop_lower_bound(const pos_t* __restrict__
     return lower_bound_dev(P, lo, hi, key);
 }
 
+// Lower bounds of 64 ascending keys in one sorted list, as a wave: the answers of a step lie just behind the last
+// answer of the previous step, so the wave loads consecutive 64-element windows of the list with ONE coalesced load
+// each and every lane ranks its key inside the window through cross-lane reads (6 steps) -- a merge of two sorted
+// runs, without the ~15 scattered probes per lane of an independent search.  `wb` (wave-uniform) must be a fence:
+// every element before it is smaller than every key.  Lanes still unresolved after kCoopWindows windows fall back
+// to galloping from the last window's end.
+constexpr uint32_t kCoopWindows = 4;
+template <typename pos_t>
+__device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P, uint32_t wb, uint32_t b, uint64_t key, bool need)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t res = b;
+    for (uint32_t it = 0; it < kCoopWindows; ++it) {
+        if (!__any(need)) break;
+        const uint32_t idx = wb + lane;
+        const uint64_t w = idx < b ? (uint64_t)P[idx] : ~0ull;       // +inf behind the list
+        const uint64_t wlast = __shfl(w, 63);
+        const bool can = need && key <= wlast;
+        uint32_t lo = 0, hi = 63;                                    // for `can` lanes w[63] >= key, so the answer is in [0,63]
+#pragma unroll
+        for (uint32_t st = 0; st < 6; ++st) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint64_t v = __shfl(w, (int)mid);
+            if (v < key) lo = mid + 1; else hi = mid;
+        }
+        if (can) { res = wb + lo; need = false; }
+        wb += 64;
+    }
+    if (need) res = gallop_lower_bound(P, wb < b ? wb : b, b, key);
+    return res < b ? res : b;
+}
+
 // Slots are dealt to waves in contiguous runs so a wave can carry the segment it is in and the last answer
 // of its searches from one 64-slot step to the next.
 constexpr uint32_t kRun = 2048;
@@ -537,7 +569,9 @@ __global__ void __launch_bounds__(256) join_init_kernel(const pos_t* __restrict_
     }
 }
 
-// link pass over the class [r0,r1) of slots that have `dist` sub-patterns after them
+// link pass over the class [r0,r1) of slots that have `dist` sub-patterns after them.
+// Steps that lie inside one segment (almost all of them: lists are long) keep the segment's metadata in registers,
+// search as a wave behind the previous step's answer and have the next step's positions already in flight.
 template <typename pos_t>
 __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
                                                         const SegMeta* __restrict__ sm, uint64_t r0, uint64_t r1, uint32_t dist,
@@ -549,35 +583,67 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
     const uint64_t run_begin = r0 + wave * kRun;
     if (run_begin >= r1) return;
     const uint64_t run_end = run_begin + kRun < r1 ? run_begin + kRun : r1;
-    uint32_t s_w = seg_find(seg_begin, nseg, run_begin);
-    uint32_t hint_seg = kNone, hint = 0;               // answer of the last lane of the previous step and its segment
+    uint32_t s_w = seg_find(seg_begin, nseg, run_begin);          // wave-uniform: segment of `base`
+    uint64_t seg_end = seg_begin[s_w + 1];
+    SegMeta m = sm[s_w], nx = sm[m.next];
+    uint32_t hint_seg = kNone, hint = 0;                           // answer of the last lane of the previous step and its segment
+    uint64_t x_pre = 0;
+    bool have_pre = false;
     for (uint64_t base = run_begin; base < run_end; base += 64) {
+        if (base >= seg_end) {                                     // entered a new segment (skips empty ones)
+            while (seg_begin[s_w + 1] <= base) ++s_w;
+            seg_end = seg_begin[s_w + 1];
+            m = sm[s_w]; nx = sm[m.next];
+            have_pre = false;
+        }
         const uint64_t e = base + lane;
         const bool active = e < run_end;
-        uint32_t s = s_w, j = 0;
-        if (active) {
-            while (seg_begin[s + 1] <= e) ++s;
-            const SegMeta m = sm[s];
-            const SegMeta nx = sm[m.next];
-            const uint64_t x = P[phys_of(m, (uint32_t)e)];
+        const uint64_t step_last = base + 63 < run_end ? base + 63 : run_end - 1;
+        uint32_t j = 0, s_last = s_w;
+        if (step_last < seg_end) {
+            // ---- fast path: one segment ---------------------------------------------------------------
+            uint64_t x = have_pre ? x_pre : (active ? (uint64_t)P[phys_of(m, (uint32_t)e)] : 0);
+            const uint64_t en = e + 64;                            // next step's position, in flight during the search
+            have_pre = base + 64 < run_end && (base + 127 < run_end ? base + 127 : run_end - 1) < seg_end;
+            if (have_pre) x_pre = en < run_end ? (uint64_t)P[phys_of(m, (uint32_t)en)] : 0;
             const uint64_t tlo = sat_add(x, nx.lo), thi = sat_add(x, nx.hi);
-            const uint32_t fence = (s == hint_seg) ? hint : nx.pbegin;
-            j = gallop_lower_bound(P, fence, nx.pend, tlo);           // physical index in the next list
-            bool ok = false;
-            if (dist == 1) {                                          // next list is the last one: every element is feasible
-                ok = j < nx.pend && (uint64_t)P[j] <= thi;
-                if (ok) { link[e] = j; endp[e] = P[j]; }
-            } else if (j < nx.pend) {
-                uint32_t ej = nf_in[nx.begin + (j - nx.pbegin)];      // nearest feasible logical element at or after it
-                if (ej < nx.end && (uint64_t)P[phys_of(nx, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+            if (hint_seg == s_w) j = wave_lower_bound(P, hint, nx.pend, tlo, active);
+            else if (active) j = gallop_lower_bound(P, nx.pbegin, nx.pend, tlo);
+            if (active) {
+                bool ok = false;
+                if (dist == 1) {                                   // next list is the last one: every element is feasible
+                    if (j < nx.pend) { const uint64_t v = P[j]; ok = v <= thi; if (ok) { link[e] = j; endp[e] = (pos_t)v; } }
+                } else if (j < nx.pend) {
+                    uint32_t ej = nf_in[nx.begin + (j - nx.pbegin)];      // nearest feasible logical element at or after it
+                    if (ej < nx.end && (uint64_t)P[phys_of(nx, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+                }
+                feas_out[e] = ok ? (uint32_t)e : kNone;
             }
-            feas_out[e] = ok ? (uint32_t)e : kNone;
+        } else {
+            // ---- a segment border inside the step: every lane looks its own segment up ------------------
+            have_pre = false;
+            uint32_t s = s_w;
+            if (active) {
+                while (seg_begin[s + 1] <= e) ++s;
+                const SegMeta ml = sm[s];
+                const SegMeta nl = sm[ml.next];
+                const uint64_t x = P[phys_of(ml, (uint32_t)e)];
+                const uint64_t tlo = sat_add(x, nl.lo), thi = sat_add(x, nl.hi);
+                j = gallop_lower_bound(P, (s == hint_seg) ? hint : nl.pbegin, nl.pend, tlo);
+                bool ok = false;
+                if (dist == 1) {
+                    ok = j < nl.pend && (uint64_t)P[j] <= thi;
+                    if (ok) { link[e] = j; endp[e] = P[j]; }
+                } else if (j < nl.pend) {
+                    uint32_t ej = nf_in[nl.begin + (j - nl.pbegin)];
+                    if (ej < nl.end && (uint64_t)P[phys_of(nl, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+                }
+                feas_out[e] = ok ? (uint32_t)e : kNone;
+            }
+            s_last = __shfl(s, (int)(step_last - base));
         }
-        const unsigned long long act = __ballot(active);
-        const int last = 63 - __clzll((long long)act);
-        hint_seg = __shfl(s, last);
-        hint = __shfl(j, last);
-        s_w = __shfl(s, 0);
+        hint_seg = s_last;
+        hint = __shfl(j, (int)(step_last - base));
     }
 }
 
@@ -599,34 +665,43 @@ __global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict_
     for (uint64_t base = run_begin; base < run_end; base += 64) {
         const uint64_t e = base + lane;
         const bool inr = e < run_end;
-        uint32_t s = s_w, jp = 0;
+        uint32_t s = s_w, jp = 0, fence = 0, mbegin = 0, mend = 0, mpbegin = 0, mpend = 0;
+        uint64_t lim = 0;
         bool searched = false;
         if (inr) {
             while (seg_begin[s + 1] <= e) ++s;
             const SegMeta m = sm[s];
-            uint32_t out = kNone;
             if (m.level == 0) {
                 const uint32_t me = nf[e];
                 if (me == (uint32_t)e) {                              // feasible start
-                    const uint64_t lim = sat_add((uint64_t)endp[e], qm[m.query].end_len);
-                    uint32_t fence = phys_of(m, (uint32_t)e) + 1;
-                    if (s == hint_seg && hint > fence) fence = hint;
-                    jp = gallop_lower_bound(P, fence, m.pend, lim);
+                    lim = sat_add((uint64_t)endp[e], qm[m.query].end_len);
+                    fence = phys_of(m, (uint32_t)e) + 1;
                     searched = true;
-                    if (jp < m.pend) {
-                        uint32_t ej = nf[m.begin + (jp - m.pbegin)];
-                        if (ej < m.end) out = ej;
-                    }
                 }
                 if ((uint32_t)e == m.begin) qstart[m.query] = me < m.end ? me : kNone;
             }
-            jump[e] = out;
+            mbegin = m.begin; mend = m.end; mpbegin = m.pbegin; mpend = m.pend;
         }
         const unsigned long long act = __ballot(searched);
         if (act) {
-            const int last = 63 - __clzll((long long)act);
-            hint_seg = __shfl(s, last);
+            const int first = __ffsll((long long)act) - 1, last = 63 - __clzll((long long)act);
+            const uint32_t s_first = __shfl(s, first), s_last = __shfl(s, last);
+            if (s_first == s_last && s_first == hint_seg && hint >= __shfl(fence, first)) {
+                jp = wave_lower_bound(P, hint, __shfl(mpend, first), lim, searched);
+            } else if (searched) {
+                if (s == hint_seg && hint > fence) fence = hint;
+                jp = gallop_lower_bound(P, fence, mpend, lim);
+            }
+            hint_seg = s_last;
             hint = __shfl(jp, last);
+        }
+        if (inr) {
+            uint32_t out = kNone;
+            if (searched && jp < mpend) {
+                uint32_t ej = nf[mbegin + (jp - mpbegin)];
+                if (ej < mend) out = ej;
+            }
+            jump[e] = out;
         }
         s_w = __shfl(s, 0);
     }
@@ -990,9 +1065,8 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     VLG_HIP_TRY(hipMemcpyAsync(d_sm, sm.data(), (nlive + 1) * sizeof(SegMeta), hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_segb, seg_begin.data(), (nlive + 2) * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
-    {
-        Timed t(ws, KS_JOIN_LINK, 0);
-        if (cls_slot_end[0] > cls_slot_begin[0])
+    if (cls_slot_end[0] > cls_slot_begin[0]) {
+        Timed t(ws, KS_JOIN_INIT, 0);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(join_init_kernel<pos_t>), dim3(runs_grid(cls_slot_end[0] - cls_slot_begin[0])), dim3(256), 0, st, P,
                                d_segb, nlive, d_sm, cls_slot_begin[0], cls_slot_end[0], feas, endp);
     }
