@@ -138,6 +138,19 @@ uint64_t vlg_bitvector_hbm_bytes(const vlg_bitvector* bv);
 void vlg_bitvector_destroy(vlg_bitvector* bv);
 
 /* ------------------------------------------------------------------------------------------
+ * K6: the same batched rank on an H0-compressed bit-vector: rrr_vector<63> + rank_support_rrr<1,63>
+ * (include/sdsl/rrr_vector.hpp:145-237, 444-480; block coding include/sdsl/rrr_helper.hpp:304-320, 411-460).
+ * One 32-byte header per 32 blocks of 63 bits {ones before, offset position, 32 x 6-bit classes} + offset stream;
+ * blocks are decoded on the fly against the binomial table staged in LDS.  Results equal vlg_bitvector_rank_batch.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vlg_rrr_bitvector vlg_rrr_bitvector;
+vlg_status vlg_rrr_bitvector_create(const uint64_t* h_words, uint64_t nbits, vlg_rrr_bitvector** out);
+vlg_status vlg_rrr_bitvector_rank_batch(const vlg_rrr_bitvector* bv, const uint64_t* d_idx, uint64_t* d_out,
+                                        uint64_t count, void* stream);
+uint64_t vlg_rrr_bitvector_hbm_bytes(const vlg_rrr_bitvector* bv);
+void vlg_rrr_bitvector_destroy(vlg_rrr_bitvector* bv);
+
+/* ------------------------------------------------------------------------------------------
  * K2 / K3 primitives on the index (device-resident arguments).
  * ---------------------------------------------------------------------------------------- */
 /* wt_pc::rank(i, c) (include/sdsl/wt_pc.hpp:350-373): out[j] = #c[j] in BWT[0, i[j]). */

@@ -91,6 +91,13 @@ def lib():
         for nm in ("vlgo_rank_v", "vlgo_rank_v5"):
             getattr(L, nm).argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
             getattr(L, nm).restype = C.c_uint64
+        L.vlgo_rrr_build.argtypes = [C.c_void_p, C.c_uint64]
+        L.vlgo_rrr_build.restype = C.c_void_p
+        L.vlgo_rrr_rank.argtypes = [C.c_void_p, C.c_uint64]
+        L.vlgo_rrr_rank.restype = C.c_uint64
+        L.vlgo_rrr_bits.argtypes = [C.c_void_p]
+        L.vlgo_rrr_bits.restype = C.c_uint64
+        L.vlgo_rrr_free.argtypes = [C.c_void_p]
         L.vlgo_parse.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Query)]
         L.vlgo_parse.restype = C.c_int
         L.vlgo_join.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -390,3 +397,13 @@ def ref_rank_v_blocks(words, nbits):
     out = np.zeros(cap, dtype=np.uint64)
     nw = ref().vref_rank_v_blocks(w.ctypes.data, nbits, out.ctypes.data, cap)
     return out[:nw]
+
+
+def rrr_rank(words, nbits, idx):
+    """rrr_vector<63> restatement: build from plain words, rank at every idx."""
+    w = np.concatenate([np.ascontiguousarray(words, dtype=np.uint64), np.zeros(2, np.uint64)])
+    h = lib().vlgo_rrr_build(w.ctypes.data, nbits)
+    out = np.array([lib().vlgo_rrr_rank(h, int(i)) for i in idx], dtype=np.uint64)
+    bits = int(lib().vlgo_rrr_bits(h))
+    lib().vlgo_rrr_free(h)
+    return out, bits

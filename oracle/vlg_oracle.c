@@ -668,3 +668,177 @@ uint64_t vlgo_search(const vlgo_index* x, const vlgo_query* q, uint64_t* out, ui
     if (stats) { stats[0] += st_occ; stats[1] += st_lf; stats[2] += st_lv; stats[3] += st_rk; }
     return res;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * rrr_vector<63> + rank_support_rrr<1,63>  (SURVEY a-11; BASELINE config 5)
+ *   ctor    include/sdsl/rrr_vector.hpp:145-237   (block 63 bits, rank/pointer sample every 32 blocks,
+ *                                                  per-superblock inversion of the stored classes)
+ *   rank    include/sdsl/rrr_vector.hpp:444-480
+ *   coding  include/sdsl/rrr_helper.hpp:173-258 (binomial table), :282-284 (space_for_bt),
+ *           :304-320 (bin_to_nr), :411-460 (decode_popcount incl. the binary-search variant for k < 10)
+ * Arrays are kept as plain u64/u8 instead of bit-packed int_vectors (storage detail); m_btnr is the
+ * reference's concatenated variable-length offset stream.
+ * ---------------------------------------------------------------------------------------- */
+#define RRR_BS 63
+#define RRR_K 32
+struct vlgo_rrr {
+    uint64_t size;
+    uint64_t n_bt;        /* (size+63)/63 blocks incl. the dummy block when size % 63 == 0 */
+    uint8_t* bt;          /* stored class (complemented inside inverted superblocks) */
+    uint64_t* btnr;       /* offset stream */
+    uint64_t btnr_bits;
+    uint64_t* btnrp;      /* [ceil(n_bt/32)] */
+    uint64_t* rank;       /* [ceil(n_bt/32) + (size % 2016 > 0)] (+1 safety) */
+    uint64_t n_rank;
+    uint8_t* invert;
+};
+static uint64_t g_binom[65][65];
+static uint16_t g_space[64];
+static int g_binom_ready = 0;
+static void binom_init(void)
+{
+    if (g_binom_ready) return;
+    for (int k = 0; k <= 64; ++k) g_binom[0][k] = 0;
+    for (int nn = 0; nn <= 64; ++nn) g_binom[nn][0] = 1;
+    for (int nn = 1; nn <= 64; ++nn)
+        for (int k = 1; k <= 64; ++k) g_binom[nn][k] = (k == nn) ? 1 : g_binom[nn - 1][k - 1] + g_binom[nn - 1][k];
+    for (int k = 0; k <= 63; ++k) g_space[k] = (g_binom[63][k] == 1) ? 0 : (uint16_t)(hi_bit(g_binom[63][k]) + 1);   /* :241-243 */
+    g_binom_ready = 1;
+}
+static inline uint64_t get_bits(const uint64_t* w, uint64_t pos, unsigned len)      /* bits::read_int */
+{
+    if (!len) return 0;
+    uint64_t i = pos >> 6, o = pos & 63;
+    uint64_t v = w[i] >> o;
+    if (o + len > 64) v |= w[i + 1] << (64 - o);
+    return len == 64 ? v : (v & ((1ULL << len) - 1));
+}
+static inline void put_bits(uint64_t* w, uint64_t pos, uint64_t v, unsigned len)
+{
+    if (!len) return;
+    uint64_t i = pos >> 6, o = pos & 63;
+    w[i] |= v << o;
+    if (o + len > 64) w[i + 1] |= v >> (64 - o);
+}
+static uint64_t bin_to_nr(uint64_t bin)                                              /* rrr_helper.hpp:304-320 */
+{
+    if (bin == 0 || bin == ((1ULL << 63) - 1)) return 0;
+    uint64_t nr = 0;
+    unsigned k = (unsigned)popc(bin), nn = RRR_BS;
+    while (bin) {
+        if (bin & 1) { nr += g_binom[nn - 1][k]; --k; }
+        bin >>= 1; --nn;
+    }
+    return nr;
+}
+static unsigned decode_popcount(unsigned k, uint64_t nr, unsigned off)                /* rrr_helper.hpp:411-460 */
+{
+    const unsigned n = RRR_BS;
+    if (k == n) return off;
+    if (k == 0) return 0;
+    if (k == 1) return (n - nr - 1) < off;
+    unsigned result = 0, nn = n;
+    if (k + 1 < 10 + 1) {                         /* BINARY_SEARCH_THRESHOLD = 63/6 */
+        while (k > 1) {
+            unsigned lb = k, rb = nn + 1;
+            while (lb < rb) {
+                unsigned mid = (lb + rb) / 2;
+                if (nr >= g_binom[mid - 1][k]) lb = mid + 1; else rb = mid;
+            }
+            nn = lb - 1;
+            if (n - nn >= off) return result;
+            ++result;
+            nr -= g_binom[nn - 1][k];
+            --k; --nn;
+        }
+    } else {
+        unsigned i = 0;
+        while (k > 1) {
+            if (i >= off) return result;
+            if (nr >= g_binom[nn - 1][k]) { nr -= g_binom[nn - 1][k]; --k; ++result; }
+            --nn; ++i;
+        }
+    }
+    return result + ((n - nr - 1) < off);
+}
+
+vlgo_rrr* vlgo_rrr_build(const uint64_t* words, uint64_t size)
+{
+    binom_init();
+    vlgo_rrr* r = (vlgo_rrr*)calloc(1, sizeof *r);
+    r->size = size;
+    r->n_bt = (size + RRR_BS) / RRR_BS;
+    uint64_t nsb = (r->n_bt + RRR_K - 1) / RRR_K;
+    r->bt = (uint8_t*)calloc(r->n_bt + 1, 1);
+    r->btnrp = (uint64_t*)calloc(nsb + 1, 8);
+    r->n_rank = nsb + ((size % (RRR_K * RRR_BS)) > 0);
+    r->rank = (uint64_t*)calloc(r->n_rank + 2, 8);
+    r->invert = (uint8_t*)calloc(nsb + 1, 1);
+    uint64_t nw = (size + 63) / 64;
+    uint64_t* pad = (uint64_t*)calloc(nw + 2, 8);
+    memcpy(pad, words, nw * 8);
+    /* (1) classes and the length of the offset stream  (:153-166) */
+    uint64_t pos = 0, i = 0, btnr_pos = 0;
+    while (pos + RRR_BS <= size) { unsigned x = (unsigned)popc(get_bits(pad, pos, RRR_BS)); r->bt[i++] = (uint8_t)x; btnr_pos += g_space[x]; pos += RRR_BS; }
+    if (pos < size) { unsigned x = (unsigned)popc(get_bits(pad, pos, (unsigned)(size - pos))); r->bt[i++] = (uint8_t)x; btnr_pos += g_space[x]; }
+    r->btnr_bits = btnr_pos > 64 ? btnr_pos : 64;
+    r->btnr = (uint64_t*)calloc((r->btnr_bits + 63) / 64 + 2, 8);
+    /* (2) offsets, pointers, rank samples, inversion  (:175-234) */
+    pos = 0; i = 0; btnr_pos = 0;
+    uint64_t sum_rank = 0;
+    int inv = 0;
+    while (pos + RRR_BS <= size) {
+        if (i % RRR_K == 0) {
+            r->btnrp[i / RRR_K] = btnr_pos; r->rank[i / RRR_K] = sum_rank;
+            if (i + RRR_K <= r->n_bt) {
+                unsigned gt = 0;
+                for (uint64_t j = i; j < i + RRR_K; ++j) if (r->bt[j] > RRR_BS / 2) ++gt;
+                if (gt > RRR_K / 2) { r->invert[i / RRR_K] = 1; for (uint64_t j = i; j < i + RRR_K; ++j) r->bt[j] = (uint8_t)(RRR_BS - r->bt[j]); inv = 1; }
+                else inv = 0;
+            } else inv = 0;
+        }
+        unsigned x = r->bt[i++];
+        unsigned sp = g_space[x];
+        sum_rank += inv ? (RRR_BS - x) : x;
+        if (sp) put_bits(r->btnr, btnr_pos, bin_to_nr(get_bits(pad, pos, RRR_BS)), sp);
+        btnr_pos += sp;
+        pos += RRR_BS;
+    }
+    if (pos < size) {
+        if (i % RRR_K == 0) { r->btnrp[i / RRR_K] = btnr_pos; r->rank[i / RRR_K] = sum_rank; r->invert[i / RRR_K] = 0; inv = 0; }
+        unsigned x = r->bt[i++];
+        unsigned sp = g_space[x];
+        sum_rank += inv ? (RRR_BS - x) : x;
+        if (sp) put_bits(r->btnr, btnr_pos, bin_to_nr(get_bits(pad, pos, (unsigned)(size - pos))), sp);
+        btnr_pos += sp;
+    }
+    r->rank[r->n_rank - 1] = sum_rank;                      /* :233 */
+    free(pad);
+    return r;
+}
+
+uint64_t vlgo_rrr_rank(const vlgo_rrr* r, uint64_t i)        /* rrr_vector.hpp:444-480 */
+{
+    uint64_t bt_idx = i / RRR_BS, sample = bt_idx / RRR_K;
+    uint64_t btnrp = r->btnrp[sample], rank = r->rank[sample];
+    if (sample + 1 < r->n_rank) {
+        uint64_t diff = r->rank[sample + 1] - rank;
+        if (diff == 0) return rank;
+        if (diff == (uint64_t)RRR_BS * RRR_K) return rank + i - sample * RRR_K * RRR_BS;
+    }
+    const int inv = r->invert[sample];
+    for (uint64_t j = sample * RRR_K; j < bt_idx; ++j) {
+        unsigned x = r->bt[j];
+        rank += inv ? RRR_BS - x : x;
+        btnrp += g_space[x];
+    }
+    unsigned off = (unsigned)(i % RRR_BS);
+    if (!off) return rank;
+    unsigned bt = inv ? RRR_BS - r->bt[bt_idx] : r->bt[bt_idx];
+    unsigned len = g_space[bt];
+    uint64_t nr = get_bits(r->btnr, btnrp, len);
+    return rank + decode_popcount(bt, nr, off);
+}
+
+uint64_t vlgo_rrr_bits(const vlgo_rrr* r) { return 6 * r->n_bt + r->btnr_bits + 64 * ((r->n_bt + 31) / 32) * 2 + (r->n_bt + 31) / 32; }
+void vlgo_rrr_free(vlgo_rrr* r) { if (!r) return; free(r->bt); free(r->btnr); free(r->btnrp); free(r->rank); free(r->invert); free(r); }

@@ -93,6 +93,13 @@ uint64_t vlgo_rank_v(const uint64_t* words, const uint64_t* blocks, uint64_t idx
 uint64_t vlgo_rank_v5_build(const uint64_t* words, uint64_t nbits, uint64_t* blocks /* 2*((cap>>11)+1) */);
 uint64_t vlgo_rank_v5(const uint64_t* words, const uint64_t* blocks, uint64_t idx);
 
+/* rrr_vector<63> + rank_support_rrr<1,63> (include/sdsl/rrr_vector.hpp:145-237,444-480; rrr_helper.hpp:173-460) */
+typedef struct vlgo_rrr vlgo_rrr;
+vlgo_rrr* vlgo_rrr_build(const uint64_t* words, uint64_t nbits);
+uint64_t vlgo_rrr_rank(const vlgo_rrr*, uint64_t i);
+uint64_t vlgo_rrr_bits(const vlgo_rrr*);      /* compressed size in bits (classes + offsets + samples) */
+void vlgo_rrr_free(vlgo_rrr*);
+
 /* ---- queries ---------------------------------------------------------------------------- */
 /* dialect 0 = library  (gapped_pattern_query, vlg_index.hpp:54-105: '?' mandatory, per-gap bounds
  *                       + |s_{i-1}|, non-overlap by |s_last|)

@@ -403,3 +403,27 @@ def test_join_many_tiles_single_pattern(V, oracle):
         res = idx.search(qs, workspace=ws)
         for i, qq in enumerate(qs):
             assert res.tuples(i).tolist() == o.search(qq).tolist(), (qq, lazy)
+
+
+@pytest.mark.parametrize("nbits", [0, 1, 62, 63, 64, 2015, 2016, 2017, 4096, 100000, 1 << 20])
+def test_k6_rrr_bitvector_rank(torch_cuda, V, oracle, nbits):
+    """rank_support_test.cpp:70-87 for rank_support_rrr<1,63>: device decode vs the oracle's rrr restatement and the truth."""
+    torch = torch_cuda
+    rng = np.random.default_rng(nbits + 7)
+    for dens in (0.0, 0.03, 0.5, 0.97, 1.0):
+        bits = rng.random(nbits) < dens
+        words = bits_to_words(bits)
+        bv = V.RrrBitVector(words, nbits)
+        idx = np.arange(nbits + 1, dtype=np.uint64) if nbits <= 5000 else \
+            np.unique(np.concatenate([rng.integers(0, nbits + 1, 20000), [0, nbits, 63, 62, 2016, nbits - 1]])).astype(np.uint64)
+        d_idx = dev_u64(torch, idx)
+        d_out = torch.zeros_like(d_idx)
+        bv.rank_device(d_idx.data_ptr(), d_out.data_ptr(), len(idx))
+        torch.cuda.synchronize()
+        got = host_u64(d_out)
+        truth = np.concatenate([[0], np.cumsum(bits)])[idx.astype(np.int64)]
+        assert (got == truth).all(), (nbits, dens)
+        want, _ = oracle.rrr_rank(words, nbits, idx[:1500])
+        assert (got[:1500] == want).all()
+        if dens in (0.03, 0.97) and nbits >= 100000:
+            assert bv.hbm_bytes() < 0.6 * (nbits / 8)          # H0 compression actually happens on skewed bits

@@ -72,6 +72,10 @@ SYMBOLS = [
     ("vlg_bitvector_rank_batch", _I, [_P, _P, _P, _U64, _P]),
     ("vlg_bitvector_hbm_bytes", _U64, [_P]),
     ("vlg_bitvector_destroy", None, [_P]),
+    ("vlg_rrr_bitvector_create", _I, [_P, _U64, C.POINTER(_P)]),
+    ("vlg_rrr_bitvector_rank_batch", _I, [_P, _P, _P, _U64, _P]),
+    ("vlg_rrr_bitvector_hbm_bytes", _U64, [_P]),
+    ("vlg_rrr_bitvector_destroy", None, [_P]),
     ("vlg_wt_rank_batch", _I, [_P, _P, _P, _P, _U64, _P]),
     ("vlg_backward_search_batch", _I, [_P, _P, _P, _U64, _P, _P, _P]),
     ("vlg_sa_batch", _I, [_P, _P, _P, _U64, _P]),

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string.h>
+#include <vector>
 #include "common.hpp"
 #include "device_rank.hpp"
 #include "kernels.hpp"
@@ -133,6 +134,198 @@ extern "C" void vlg_bitvector_destroy(vlg_bitvector* bv)
 {
     if (!bv) return;
     if (bv->d_blocks) (void)hipFree(bv->d_blocks);
+    delete bv;
+}
+
+// =============================================================================================
+// K6: rank on an H0-compressed bit-vector -- rrr_vector<63> / rank_support_rrr<1,63>
+//     (include/sdsl/rrr_vector.hpp:444-480; coding include/sdsl/rrr_helper.hpp:304-320, 411-460).
+// Blocks of 63 bits are stored as (class = popcount, offset = rank of the block among all blocks of that class in
+// the combinatorial number system); 32 blocks form a super-block.  HBM layout, one aligned 32-byte header per
+// super-block: { u32 ones before it, u32 bit position of its first offset, 32 x 6-bit classes }, offsets in a
+// separate bit stream.  One rank = the header read + one read of <= 61 offset bits; the block is decoded on the fly
+// against the binomial table C(n,k), n < 64, staged in LDS (32 KiB).
+// =============================================================================================
+struct vlg_rrr_bitvector {
+    uint64_t nbits = 0, n_sb = 0, stream_words = 0;
+    uint4* d_hdr = nullptr;          // 2 x uint4 per super-block
+    uint64_t* d_stream = nullptr;
+    uint64_t* d_binom = nullptr;     // [64][64]
+};
+
+namespace {
+
+constexpr uint32_t kRrrBlock = 63, kRrrSuper = 32;
+
+struct RrrLds {
+    uint64_t binom[64][64];
+    uint8_t space[64];
+};
+
+__device__ __forceinline__ uint32_t rrr_class(uint64_t c0, uint64_t c1, uint64_t c2, uint32_t j)
+{
+    uint32_t bit = 6u * j;                       // classes are packed little-endian into 192 bits
+    uint32_t w = bit >> 6, o = bit & 63;
+    uint64_t lo = w == 0 ? c0 : (w == 1 ? c1 : c2);
+    uint64_t hi = w == 0 ? c1 : c2;
+    uint64_t v = lo >> o;
+    if (o > 58) v |= hi << (64 - o);
+    return (uint32_t)v & 63u;
+}
+
+__global__ void __launch_bounds__(256) rrr_rank_kernel(const uint4* __restrict__ hdr, const uint64_t* __restrict__ stream,
+                                                       const uint64_t* __restrict__ binom, const uint64_t* __restrict__ idx,
+                                                       uint64_t* __restrict__ out, uint64_t count)
+{
+    __shared__ RrrLds s;
+    for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) (&s.binom[0][0])[i] = binom[i];
+    __syncthreads();
+    if (threadIdx.x < 64) {                      // space_for_bt: bits of C(63,k), 0 for the two uniform classes
+        uint64_t c = s.binom[63][threadIdx.x];
+        s.space[threadIdx.x] = (c == 1) ? 0 : (uint8_t)(64 - __clzll((long long)c));
+    }
+    __syncthreads();
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = idx[q];
+        const uint64_t sb = i / (kRrrBlock * kRrrSuper);
+        const uint32_t r = (uint32_t)(i - sb * (kRrrBlock * kRrrSuper));
+        const uint32_t blk = r / kRrrBlock, off = r - blk * kRrrBlock;
+        const uint4 h0 = hdr[2 * sb], h1 = hdr[2 * sb + 1];
+        uint64_t rank = h0.x;
+        uint64_t ptr = h0.y;
+        const uint64_t c0 = (uint64_t)h0.z | ((uint64_t)h0.w << 32), c1 = (uint64_t)h1.x | ((uint64_t)h1.y << 32),
+                       c2 = (uint64_t)h1.z | ((uint64_t)h1.w << 32);
+        for (uint32_t j = 0; j < blk; ++j) {     // rrr_vector.hpp:463-467
+            uint32_t k = rrr_class(c0, c1, c2, j);
+            rank += k;
+            ptr += s.space[k];
+        }
+        if (off) {
+            uint32_t k = rrr_class(c0, c1, c2, blk);
+            const uint32_t len = s.space[k];
+            uint64_t nr = 0;
+            if (len) {
+                const uint64_t w = ptr >> 6, o = ptr & 63;
+                nr = stream[w] >> o;
+                if (o + len > 64) nr |= stream[w + 1] << (64 - o);
+                nr &= (len == 64) ? ~0ull : ((1ull << len) - 1);
+            }
+            // decode_popcount (rrr_helper.hpp:411-460): walk the block from bit 0, C(nn-1,k) decides each bit
+            uint32_t ones = 0;
+            if (k == kRrrBlock) ones = off;
+            else if (k) {
+                uint32_t nn = kRrrBlock;
+                for (uint32_t b = 0; b < off && k; ++b, --nn) {
+                    const uint64_t c = s.binom[nn - 1][k];
+                    if (nr >= c) { nr -= c; --k; ++ones; }
+                }
+            }
+            rank += ones;
+        }
+        out[q] = rank;
+    }
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_rrr_bitvector_create(const uint64_t* h_words, uint64_t nbits, vlg_rrr_bitvector** out)
+{
+    if (!out || (nbits && !h_words)) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VLG_E_NO_DEVICE, "no HIP device available");
+    if (nbits >= (1ull << 32)) return fail(VLG_E_UNSUPPORTED, "stand-alone bit-vectors are limited to 2^32-1 bits");
+    // binomial table (rrr_helper.hpp:173-207)
+    std::vector<uint64_t> binom(64 * 64, 0);
+    for (int nn = 0; nn < 64; ++nn) binom[nn * 64] = 1;
+    for (int nn = 1; nn < 64; ++nn)
+        for (int k = 1; k < 64; ++k) binom[nn * 64 + k] = (k == nn) ? 1 : (k > nn ? 0 : binom[(nn - 1) * 64 + k - 1] + binom[(nn - 1) * 64 + k]);
+    auto space = [&](uint32_t k) -> uint32_t { uint64_t c = binom[63 * 64 + k]; return c == 1 ? 0 : 64 - (uint32_t)__builtin_clzll(c); };
+    auto get = [&](uint64_t pos, uint32_t len) -> uint64_t {      // bits [pos, pos+len) of the input, zero beyond nbits
+        uint64_t v = 0;
+        for (uint32_t b = 0; b < len; ) {
+            uint64_t p = pos + b;
+            if (p >= nbits) break;
+            uint64_t w = p >> 6, o = p & 63;
+            uint32_t take = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(64 - o, len - b), nbits - p);
+            uint64_t chunk = (h_words[w] >> o) & (take == 64 ? ~0ull : ((1ull << take) - 1));
+            v |= chunk << b;
+            b += take;
+        }
+        return v;
+    };
+    const uint64_t n_blocks = nbits / kRrrBlock + 1;
+    const uint64_t n_sb = (n_blocks + kRrrSuper - 1) / kRrrSuper;
+    std::vector<uint32_t> hdr(n_sb * 8, 0);
+    std::vector<uint64_t> stream(1, 0);
+    uint64_t sbits = 0, ones = 0;
+    for (uint64_t sb = 0; sb < n_sb; ++sb) {
+        uint32_t* H = &hdr[sb * 8];
+        H[0] = (uint32_t)ones;
+        H[1] = (uint32_t)sbits;
+        uint64_t cls[3] = {0, 0, 0};
+        for (uint32_t j = 0; j < kRrrSuper; ++j) {
+            uint64_t bin = get((sb * kRrrSuper + j) * kRrrBlock, kRrrBlock);
+            uint32_t k = (uint32_t)__builtin_popcountll(bin);
+            uint32_t bit = 6 * j, w = bit >> 6, o = bit & 63;
+            cls[w] |= (uint64_t)k << o;
+            if (o > 58) cls[w + 1] |= (uint64_t)k >> (64 - o);
+            ones += k;
+            uint32_t len = space(k);
+            if (len) {                                               // bin_to_nr: rrr_helper.hpp:304-320
+                uint64_t nr = 0, b = bin;
+                uint32_t kk = k, nn = kRrrBlock;
+                while (b) { if (b & 1) { nr += binom[(nn - 1) * 64 + kk]; --kk; } b >>= 1; --nn; }
+                if ((sbits + len + 127) / 64 >= stream.size()) stream.resize(stream.size() * 2 + 4, 0);
+                uint64_t w2 = sbits >> 6, o2 = sbits & 63;
+                stream[w2] |= nr << o2;
+                if (o2 + len > 64) stream[w2 + 1] |= nr >> (64 - o2);
+                sbits += len;
+            }
+        }
+        H[2] = (uint32_t)cls[0]; H[3] = (uint32_t)(cls[0] >> 32);
+        H[4] = (uint32_t)cls[1]; H[5] = (uint32_t)(cls[1] >> 32);
+        H[6] = (uint32_t)cls[2]; H[7] = (uint32_t)(cls[2] >> 32);
+    }
+    if (sbits >= (1ull << 32)) return fail(VLG_E_UNSUPPORTED, "offset stream longer than 2^32 bits");
+    vlg_rrr_bitvector* bv = new vlg_rrr_bitvector();
+    bv->nbits = nbits; bv->n_sb = n_sb; bv->stream_words = sbits / 64 + 2;
+    stream.resize(bv->stream_words, 0);
+    auto run = [&]() -> vlg_status {
+        VLG_HIP_TRY(hipMalloc((void**)&bv->d_hdr, n_sb * 32));
+        VLG_HIP_TRY(hipMalloc((void**)&bv->d_stream, bv->stream_words * 8));
+        VLG_HIP_TRY(hipMalloc((void**)&bv->d_binom, 64 * 64 * 8));
+        VLG_HIP_TRY(hipMemcpy(bv->d_hdr, hdr.data(), n_sb * 32, hipMemcpyHostToDevice));
+        VLG_HIP_TRY(hipMemcpy(bv->d_stream, stream.data(), bv->stream_words * 8, hipMemcpyHostToDevice));
+        VLG_HIP_TRY(hipMemcpy(bv->d_binom, binom.data(), 64 * 64 * 8, hipMemcpyHostToDevice));
+        return VLG_OK;
+    };
+    vlg_status st = run();
+    if (st) { vlg_rrr_bitvector_destroy(bv); return st; }
+    *out = bv;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_rrr_bitvector_rank_batch(const vlg_rrr_bitvector* bv, const uint64_t* d_idx, uint64_t* d_out, uint64_t count,
+                                                   void* stream)
+{
+    if (!bv || (count && (!d_idx || !d_out))) return fail(VLG_E_INVALID, "null argument");
+    if (!count) return VLG_OK;
+    uint32_t grid = (uint32_t)std::min<uint64_t>((count + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(rrr_rank_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bv->d_hdr, bv->d_stream, bv->d_binom, d_idx, d_out,
+                       count);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+
+extern "C" uint64_t vlg_rrr_bitvector_hbm_bytes(const vlg_rrr_bitvector* bv) { return bv ? bv->n_sb * 32 + bv->stream_words * 8 : 0; }
+
+extern "C" void vlg_rrr_bitvector_destroy(vlg_rrr_bitvector* bv)
+{
+    if (!bv) return;
+    if (bv->d_hdr) (void)hipFree(bv->d_hdr);
+    if (bv->d_stream) (void)hipFree(bv->d_stream);
+    if (bv->d_binom) (void)hipFree(bv->d_binom);
     delete bv;
 }
 

@@ -1148,7 +1148,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
 //            of the tile is the recorded suffix (least fixed points are monotone in the start bound);
 //   emit   : one lane per tile copies the recorded suffix behind the elements the stitch pass found itself;
 //   gather : one lane per match re-derives the tuple from its start.
-// Results are exactly those of the dense passes above (tests compare both against the oracle).
+// Results are exactly those of the dense passes above.
 // =============================================================================================
 constexpr uint32_t kLazyK = 8;
 constexpr uint32_t kLazyTile = 2048;

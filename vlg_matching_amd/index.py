@@ -290,3 +290,28 @@ class BitVector:
 
     def hbm_bytes(self):
         return int(lib().vlg_bitvector_hbm_bytes(self._h))
+
+
+class RrrBitVector:
+    """rrr_vector<63> + rank_support_rrr equivalent in HBM (K6): on-the-fly block decode, binomial table in LDS."""
+
+    def __init__(self, words, nbits):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib().vlg_rrr_bitvector_create(w.ctypes.data if len(w) else None, int(nbits), C.byref(h)))
+        self._h = h
+        self.nbits = int(nbits)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vlg_rrr_bitvector_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def rank_device(self, d_idx_ptr, d_out_ptr, count, stream=None):
+        check(lib().vlg_rrr_bitvector_rank_batch(self._h, d_idx_ptr, d_out_ptr, count, stream))
+
+    def hbm_bytes(self):
+        return int(lib().vlg_rrr_bitvector_hbm_bytes(self._h))
