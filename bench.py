@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink text and batch (development only)")
     ap.add_argument("--workspace-gb", type=float, default=160.0)
+    ap.add_argument("--bv", choices=["plain", "rrr"], default=None, help="wavelet-tree bit-vectors (default: rrr for C5, else plain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -117,6 +118,12 @@ def main():
         del d_text
         torch.cuda.empty_cache()
         log("index built on device in %.2f s: %s" % (t_build, idx.info()))
+        if (args.bv or ("rrr" if args.config == "C5" else "plain")) == "rrr":
+            t0 = time.perf_counter()
+            plain_idx, idx = idx, idx.compress()
+            log("rrr-63 re-encoding on device in %.2f s: %s" % (time.perf_counter() - t0, idx.info()))
+            if args.no_cpu_baseline:
+                del plain_idx
     if world > 1:
         nb = torch.tensor([idx.blob_bytes() if rank == 0 else 0], dtype=torch.int64, device="cuda")
         dist.broadcast(nb, 0)
@@ -207,6 +214,7 @@ def main():
             "config": {"workload": "%s%s: %s text n=%d (seed %d), %d queries/GPU x k=%d, m=%d, gap .{%d,%d}?, t_dens=32"
                                    % (args.config, "" if args.scale == 1.0 else " x%g" % args.scale, cfg["kind"], cfg["n"],
                                       cfg["seed"], cfg["nq"], cfg["k"], cfg["m"], cfg["gap"][0], cfg["gap"][1]),
+                       "bit_vectors": "rrr_vector<63>" if info["bv_kind"] else "plain (256-bit super-blocks)",
                        "sigma": info["sigma"], "mean_code_len_bits": info["wt_bits"] / info["n"],
                        "index_hbm_bytes": info["hbm_bytes"]},
             "located_occ_per_sec": n_occ * args.steps / dt,
@@ -225,7 +233,7 @@ def main():
             "rank_kernel_roofline": roof("locate", names["locate"]),     # the LF / bit-rank kernel the north star names
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(idx, queries, n_logical / max(n_queries, 1))
+            out["cpu_baseline"] = cpu_baseline(plain_idx if info["bv_kind"] else idx, queries, n_logical / max(n_queries, 1))
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -89,7 +89,7 @@ typedef struct {
     uint64_t n_samples;
     uint64_t hbm_bytes;           /* total device bytes of the index                           */
     uint32_t pos_bytes;           /* 4 (n <= 2^32) or 8: width of positions inside kernels      */
-    uint32_t reserved;
+    uint32_t bv_kind;             /* VLG_BV_PLAIN or VLG_BV_RRR63                               */
 } vlg_index_info;
 
 /* Build on the device from raw text (no 0 byte; the sentinel is appended like
@@ -114,6 +114,12 @@ typedef struct {
     uint64_t* sa_samples;         /* [n_samples]                                               */
 } vlg_index_parts_out;
 vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_parts* sizes, vlg_index_parts_out* out);
+/* A second index over the same text whose wavelet-tree bit-vectors are H0-compressed -- csa_wt<wt_huff<rrr_vector<63>>>
+ * (BASELINE config 5; include/sdsl/rrr_vector.hpp).  Every search entry point accepts it and returns identical results;
+ * ranks decode 63-bit blocks on the fly against a binomial table staged in LDS.  `src` must be a plain index. */
+#define VLG_BV_PLAIN 0
+#define VLG_BV_RRR63 1
+vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out);
 vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* info);
 void vlg_index_destroy(vlg_index* idx);
 

@@ -427,3 +427,57 @@ def test_k6_rrr_bitvector_rank(torch_cuda, V, oracle, nbits):
         assert (got[:1500] == want).all()
         if dens in (0.03, 0.97) and nbits >= 100000:
             assert bv.hbm_bytes() < 0.6 * (nbits / 8)          # H0 compression actually happens on skewed bits
+
+
+@pytest.mark.parametrize("name,seed", [("dna_50k", 61), ("zipf40", 62), ("100a", 63), ("all_symbols", 64), ("abracadabra", 65)])
+def test_rrr_index_variant_equals_plain_and_oracle(torch_cuda, V, oracle, name, seed):
+    """BASELINE config 5 shape: csa_wt<wt_huff<rrr_vector<63>>>.  Same answers from compressed bit-vectors (K6 inside K2/K3)."""
+    torch = torch_cuda
+    from vlg_matching_amd.index import Workspace
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    plain = V.VlgIndex.build(text)
+    rrr = plain.compress()
+    assert rrr.info()["bv_kind"] == 1 and plain.info()["bv_kind"] == 0
+    n = o.n
+    rng = np.random.default_rng(seed)
+    L = V.lib()
+    # wt_pc::rank and csa[i] through the rrr bit-vectors
+    m = 3000
+    pos = rng.integers(0, n + 1, m).astype(np.uint64)
+    syms = rng.choice(np.unique(np.concatenate([np.frombuffer(text, np.uint8), [0, 254]])), m).astype(np.uint8)
+    d_pos, d_sym = dev_u64(torch, pos), torch.from_numpy(syms).cuda()
+    d_out = torch.zeros_like(d_pos)
+    V.capi.check(L.vlg_wt_rank_batch(rrr._h, d_pos.data_ptr(), d_sym.data_ptr(), d_out.data_ptr(), m, None))
+    torch.cuda.synchronize()
+    assert (host_u64(d_out) == np.array([o.wt_rank(int(p), int(c)) for p, c in zip(pos, syms)], dtype=np.uint64)).all()
+    ii = np.arange(n, dtype=np.uint64) if n <= 60000 else rng.integers(0, n, 60000).astype(np.uint64)
+    d_i = dev_u64(torch, ii)
+    d_o = torch.zeros_like(d_i)
+    V.capi.check(L.vlg_sa_batch(rrr._h, d_i.data_ptr(), d_o.data_ptr(), len(ii), None))
+    torch.cuda.synchronize()
+    sa = oracle.suffix_array(np.frombuffer(text + b"\0", np.uint8))
+    assert (host_u64(d_o) == sa[ii.astype(np.int64)]).all()
+    # whole searches, both locate kernels
+    qs = random_queries(text, rng, 200, kmax=4, mmax=4) if len(text) > 30 else ["a.{0,10}?a.{0,10}?a", "ac.{2,5}?a.{4,8}?b", "abra"]
+    a = plain.search(qs)
+    for opts in ({}, {"sweep_min": 1, "sweep_tail": 50}):
+        ws = Workspace()
+        for k_, v_ in opts.items():
+            ws.set_option(k_, v_)
+        b = rrr.search(qs, workspace=ws)
+        for k in ("n_matches", "checksum", "located_occurrences", "lf_steps", "wt_levels_locate", "wt_levels_bsearch"):
+            assert a.summary[k] == b.summary[k], (k, opts)
+        for x, y in zip(a.fetch(), b.fetch()):
+            assert (x == y).all()
+    for i in range(0, len(qs), 9):
+        assert a.tuples(i).tolist() == o.search(qs[i]).tolist()
+
+
+def test_rrr_index_is_smaller_on_skewed_text(V):
+    text = (b"a" * 2000000) + dna_text(3000, 1).tobytes() + (b"b" * 1000000)
+    plain = V.VlgIndex.build(text)
+    rrr = plain.compress()
+    pi, ri = plain.info(), rrr.info()
+    assert pi["hbm_bytes"] - ri["hbm_bytes"] > 0.5 * pi["n_blocks"] * 32      # the bit-vector part shrinks by more than half
+    assert V.count(rrr, "aaaa.{0,5}?ab") == V.count(plain, "aaaa.{0,5}?ab")

@@ -54,7 +54,9 @@ struct BlobHeader {
     uint32_t sample_bytes;
     uint32_t pad0;
     uint64_t off_blocks, off_nodes, off_C, off_paths, off_c2c, off_samples, off_refnodes;
-    uint64_t reserved[7];
+    uint64_t bv_kind;             // 0 = plain 256-bit super-blocks, 1 = rrr-63 (K6 layout)
+    uint64_t off_rrr_hdr, off_rrr_stream, off_binom, n_rrr_sb, rrr_stream_words;
+    uint64_t reserved[1];
 };
 
 // What kernels receive (by value).
@@ -71,7 +73,16 @@ struct IndexView {
     uint32_t sigma;
     uint32_t dens;
     uint32_t sample_bytes;
+    // rrr-63 variant of the wavelet-tree bit-vectors (bv_kind == 1): DNode.base counts 32-byte headers
+    uint32_t bv_kind;
+    uint32_t pad;
+    const uint4* rrr_hdr;
+    const uint64_t* rrr_stream;
+    const uint64_t* binom;        // [64][64]
 };
+
+constexpr uint32_t kBvPlain = 0, kBvRrr63 = 1;
+constexpr uint32_t kRrrBlockBits = 63, kRrrBlocksPerSuper = 32, kRrrSuperBits = 63 * 32;
 
 void set_error(const std::string& msg);
 vlg_status fail(vlg_status st, const std::string& msg);

@@ -58,16 +58,118 @@ __device__ __forceinline__ uint64_t node_rank1(const Block* blocks, uint32_t bas
     return block_rank(r, off);
 }
 
-// Node table + C + paths staged in LDS by every workgroup that walks the tree.
-struct TreeLds {
-    DNode nodes[kMaxNodes];
-    uint64_t C[257];
+// ---- bit-vector policies: how one node-relative (rank1, bit) pair is obtained -----------------------------------
+// Plain: one 256-bit super-block read (K1).
+struct PlainBV {
+    struct Shared {};
+    static __device__ __forceinline__ void stage(Shared&, const IndexView&) {}
+    static __device__ __forceinline__ void rank_bit(const IndexView& iv, const Shared&, uint32_t base, uint64_t i, uint64_t& r1, uint32_t& bit)
+    {
+        uint32_t blk, off;
+        split224(i, blk, off);
+        BlockRegs r = load_block(iv.blocks, base + blk);
+        bit = block_bit(r, off);
+        r1 = block_rank(r, off);
+    }
+    static __device__ __forceinline__ uint64_t rank(const IndexView& iv, const Shared&, uint32_t base, uint64_t i)
+    {
+        return node_rank1(iv.blocks, base, i);
+    }
 };
 
-__device__ __forceinline__ void stage_tree(TreeLds& s, const IndexView& iv)
+// rrr-63 (K6): 32-byte header {ones before, offset word position, 32 x 6-bit classes} per 32 blocks of 63 bits, offsets in
+// a bit stream (each super-block's offsets start on a word), decoded against the binomial table staged in LDS
+// (rank_support_rrr::rank, include/sdsl/rrr_vector.hpp:444-480; decode include/sdsl/rrr_helper.hpp:411-460).
+struct RrrBV {
+    struct Shared {
+        uint64_t binom[64][64];
+        uint8_t space[64];
+    };
+    static __device__ __forceinline__ void stage(Shared& s, const IndexView& iv)
+    {
+        for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) (&s.binom[0][0])[i] = iv.binom[i];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            uint64_t c = s.binom[63][threadIdx.x];
+            s.space[threadIdx.x] = (c == 1) ? 0 : (uint8_t)(64 - __clzll((long long)c));
+        }
+    }
+    static __device__ __forceinline__ uint32_t cls(uint64_t c0, uint64_t c1, uint64_t c2, uint32_t j)
+    {
+        uint32_t b = 6u * j, w = b >> 6, o = b & 63;
+        uint64_t lo = w == 0 ? c0 : (w == 1 ? c1 : c2);
+        uint64_t hi = w == 0 ? c1 : c2;
+        uint64_t v = lo >> o;
+        if (o > 58) v |= hi << (64 - o);
+        return (uint32_t)v & 63u;
+    }
+    // ones in the first `want` bits of the addressed block, plus bit number `want` when asked for
+    template <bool kBit>
+    static __device__ __forceinline__ void decode(const IndexView& iv, const Shared& s, uint32_t base, uint64_t i, uint64_t& r1, uint32_t& bit)
+    {
+        const uint64_t sb = i / kRrrSuperBits;
+        const uint32_t r = (uint32_t)(i - sb * kRrrSuperBits);
+        const uint32_t blk = r / kRrrBlockBits, off = r - blk * kRrrBlockBits;
+        const uint4 h0 = iv.rrr_hdr[2 * ((uint64_t)base + sb)], h1 = iv.rrr_hdr[2 * ((uint64_t)base + sb) + 1];
+        uint64_t rank = h0.x;
+        uint64_t ptr = (uint64_t)h0.y << 6;
+        const uint64_t c0 = (uint64_t)h0.z | ((uint64_t)h0.w << 32), c1 = (uint64_t)h1.x | ((uint64_t)h1.y << 32),
+                       c2 = (uint64_t)h1.z | ((uint64_t)h1.w << 32);
+        for (uint32_t j = 0; j < blk; ++j) {
+            uint32_t k = cls(c0, c1, c2, j);
+            rank += k;
+            ptr += s.space[k];
+        }
+        bit = 0;
+        if (kBit || off) {
+            uint32_t k = cls(c0, c1, c2, blk);
+            const uint32_t len = s.space[k];
+            uint64_t nr = 0;
+            if (len) {
+                const uint64_t w = ptr >> 6, o = ptr & 63;
+                nr = iv.rrr_stream[w] >> o;
+                if (o + len > 64) nr |= iv.rrr_stream[w + 1] << (64 - o);
+                nr &= (len == 64) ? ~0ull : ((1ull << len) - 1);
+            }
+            uint32_t ones = 0, nn = kRrrBlockBits;
+            if (k == kRrrBlockBits) { ones = off; bit = 1; }
+            else if (k) {
+                for (uint32_t b = 0; b < off && k; ++b, --nn) {
+                    const uint64_t c = s.binom[nn - 1][k];
+                    if (nr >= c) { nr -= c; --k; ++ones; }
+                }
+                if (kBit && k) bit = nr >= s.binom[kRrrBlockBits - off - 1][k];     // nn == 63 - off here unless k ran out
+            }
+            rank += ones;
+        }
+        r1 = rank;
+    }
+    static __device__ __forceinline__ void rank_bit(const IndexView& iv, const Shared& s, uint32_t base, uint64_t i, uint64_t& r1, uint32_t& bit)
+    {
+        decode<true>(iv, s, base, i, r1, bit);
+    }
+    static __device__ __forceinline__ uint64_t rank(const IndexView& iv, const Shared& s, uint32_t base, uint64_t i)
+    {
+        uint64_t r1; uint32_t bit;
+        decode<false>(iv, s, base, i, r1, bit);
+        return r1;
+    }
+};
+
+// Node table + C (+ whatever the bit-vector policy needs) staged in LDS by every workgroup that walks the tree.
+template <class BV>
+struct WalkLds {
+    DNode nodes[kMaxNodes];
+    uint64_t C[257];
+    typename BV::Shared sh;
+};
+
+template <class BV>
+__device__ __forceinline__ void stage_walk(WalkLds<BV>& s, const IndexView& iv)
 {
     for (uint32_t i = threadIdx.x; i < iv.n_nodes; i += blockDim.x) s.nodes[i] = iv.nodes[i];
     for (uint32_t i = threadIdx.x; i <= iv.sigma; i += blockDim.x) s.C[i] = iv.C[i];
+    BV::stage(s.sh, iv);
     __syncthreads();
 }
 

@@ -147,10 +147,15 @@ void bind_view(vlg_index* idx)
     idx->view.sigma = h.sigma;
     idx->view.dens = h.dens;
     idx->view.sample_bytes = h.sample_bytes;
+    idx->view.bv_kind = (uint32_t)h.bv_kind;
+    idx->view.pad = 0;
+    idx->view.rrr_hdr = reinterpret_cast<const uint4*>(b + h.off_rrr_hdr);
+    idx->view.rrr_stream = reinterpret_cast<const uint64_t*>(b + h.off_rrr_stream);
+    idx->view.binom = reinterpret_cast<const uint64_t*>(b + h.off_binom);
 }
 
 // Plan the blob from the host tree, allocate it, upload the small tables. Blocks + samples stay to be filled.
-vlg_status alloc_blob(vlg_index* idx, uint64_t n, uint32_t dens, hipStream_t stream)
+vlg_status alloc_blob(vlg_index* idx, uint64_t n, uint32_t dens, hipStream_t stream, uint64_t n_rrr_sb = 0, uint64_t rrr_words = 0)
 {
     HostTree& t = idx->tree;
     BlobHeader& h = idx->hdr;
@@ -158,7 +163,10 @@ vlg_status alloc_blob(vlg_index* idx, uint64_t n, uint32_t dens, hipStream_t str
     h.magic = kBlobMagic;
     h.n = n;
     h.wt_bits = t.wt_bits;
-    h.n_blocks = t.n_blocks;
+    h.n_blocks = n_rrr_sb ? 0 : t.n_blocks;
+    h.bv_kind = n_rrr_sb ? kBvRrr63 : kBvPlain;
+    h.n_rrr_sb = n_rrr_sb;
+    h.rrr_stream_words = rrr_words;
     h.sigma = t.sigma;
     h.dens = dens;
     h.n_nodes = t.n_nodes;
@@ -173,6 +181,9 @@ vlg_status alloc_blob(vlg_index* idx, uint64_t n, uint32_t dens, hipStream_t str
     h.off_c2c = off;     off = align_up(off + 256, 256);
     h.off_samples = off; off = align_up(off + h.n_samples * h.sample_bytes, 256);
     h.off_refnodes = off; off = align_up(off + (uint64_t)kMaxNodes * sizeof(vlg_wt_node), 256);
+    h.off_rrr_hdr = off; off = align_up(off + n_rrr_sb * 32, 256);
+    h.off_rrr_stream = off; off = align_up(off + (rrr_words + 2) * 8, 256);
+    h.off_binom = off; off = align_up(off + (n_rrr_sb ? 64 * 64 * 8 : 0), 256);
     h.total_bytes = off;
     VLG_HIP_TRY(hipMalloc(&idx->d_blob, h.total_bytes));
     idx->owns_blob = true;
@@ -294,6 +305,8 @@ extern "C" vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_par
 {
     if (!idx || !sizes) return fail(VLG_E_INVALID, "null argument");
     const BlobHeader& h = idx->hdr;
+    if (h.bv_kind != kBvPlain && out && (out->bv_words || out->nodes))
+        return fail(VLG_E_UNSUPPORTED, "exporting the bit-vector of an rrr-compressed index is not supported; export the plain index");
     memset(sizes, 0, sizeof *sizes);
     sizes->n = h.n;
     sizes->sigma = h.sigma;
@@ -366,7 +379,7 @@ extern "C" vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* i
     info->n_samples = h.n_samples;
     info->hbm_bytes = h.total_bytes;
     info->pos_bytes = h.sample_bytes;
-    info->reserved = 0;
+    info->bv_kind = (uint32_t)h.bv_kind;
     return VLG_OK;
 }
 
@@ -423,6 +436,183 @@ extern "C" vlg_status vlg_index_attach_blob(const void* d_blob, uint64_t bytes, 
     };
     vlg_status st = run();
     if (st) { delete idx; return st; }
+    *out = idx;
+    return VLG_OK;
+}
+
+// =============================================================================================
+// rrr-63 variant of an index (BASELINE config 5: csa_wt<wt_huff<rrr_vector<63>>>): every node's bit-vector is re-encoded
+// on the device as 32-byte headers + an offset stream (layout of K6, node-relative counts, each super-block's offsets
+// word-aligned).  The tree, C, samples are shared with the plain index; search results are identical.
+// =============================================================================================
+namespace {
+
+struct RrrTable {            // inner nodes, as InnerTable plus the first rrr super-block of each node
+    uint32_t count;
+    uint32_t pbase[256];     // first plain block
+    uint32_t rbase[256];     // first rrr super-block
+    uint64_t size[256];
+};
+
+// 63 bits of a node starting at node-relative position pos (zero beyond the node)
+__device__ __forceinline__ uint64_t plain_bits63(const Block* __restrict__ blocks, uint32_t pbase, uint64_t pos, uint64_t size)
+{
+    uint64_t v = 0;
+    if (pos >= size) return 0;
+    uint32_t len = (uint32_t)(size - pos < 63 ? size - pos : 63);
+    uint32_t got = 0;
+    while (got < len) {
+        uint64_t p = pos + got;
+        uint64_t blk = p / kBlockBits;
+        uint32_t off = (uint32_t)(p - blk * kBlockBits);
+        uint32_t w = off >> 5, o = off & 31;
+        uint32_t take = 32 - o;
+        if (take > len - got) take = len - got;
+        uint32_t word = blocks[pbase + blk].w[w] >> o;
+        if (take < 32) word &= (1u << take) - 1u;
+        v |= (uint64_t)word << got;
+        got += take;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t rrr_find(const RrrTable& t, uint32_t sb)
+{
+    uint32_t lo = 0, hi = t.count;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (t.rbase[mid] <= sb) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t rrr_space(const uint64_t* binom_lds, uint32_t k)
+{
+    uint64_t c = binom_lds[63 * 64 + k];
+    return c == 1 ? 0u : (uint32_t)(64 - __clzll((long long)c));
+}
+
+// pass 1: ones and offset words of every super-block;  pass 2 (hdr != nullptr): headers + offsets
+__global__ void __launch_bounds__(256) rrr_encode_kernel(const Block* __restrict__ blocks, const RrrTable* __restrict__ tab, uint64_t n_sb,
+                                                         const uint64_t* __restrict__ binom, uint64_t* __restrict__ ones_out,
+                                                         uint64_t* __restrict__ words_out, const uint64_t* __restrict__ ones_scan,
+                                                         const uint64_t* __restrict__ words_scan, uint4* __restrict__ hdr,
+                                                         uint64_t* __restrict__ stream)
+{
+    __shared__ RrrTable t;
+    __shared__ uint64_t bn[64 * 64];
+    for (uint32_t i = threadIdx.x; i < sizeof(RrrTable) / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tab)[i];
+    for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) bn[i] = binom[i];
+    __syncthreads();
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_sb; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k_node = rrr_find(t, (uint32_t)g);
+        const uint64_t sb = g - t.rbase[k_node];
+        uint64_t ones = 0, bits = 0;
+        uint64_t cls[3] = {0, 0, 0};
+        uint64_t wpos = hdr ? words_scan[g] * 64 : 0;          // bit position in the stream
+        for (uint32_t j = 0; j < kRrrBlocksPerSuper; ++j) {
+            const uint64_t bin = plain_bits63(blocks, t.pbase[k_node], sb * kRrrSuperBits + (uint64_t)j * kRrrBlockBits, t.size[k_node]);
+            const uint32_t k = (uint32_t)__popcll(bin);
+            const uint32_t len = rrr_space(bn, k);
+            ones += k;
+            if (hdr) {
+                const uint32_t b = 6 * j, w = b >> 6, o = b & 63;
+                cls[w] |= (uint64_t)k << o;
+                if (o > 58) cls[w + 1] |= (uint64_t)k >> (64 - o);
+                if (len) {                                       // bin_to_nr (rrr_helper.hpp:304-320)
+                    uint64_t nr = 0, bb = bin;
+                    uint32_t kk = k, nn = kRrrBlockBits;
+                    while (bb) { if (bb & 1) { nr += bn[(nn - 1) * 64 + kk]; --kk; } bb >>= 1; --nn; }
+                    const uint64_t p = wpos + bits, w2 = p >> 6, o2 = p & 63;
+                    stream[w2] |= nr << o2;                      // the region of a super-block is word-aligned and private
+                    if (o2 + len > 64) stream[w2 + 1] |= nr >> (64 - o2);
+                }
+            }
+            bits += len;
+        }
+        if (!hdr) { ones_out[g] = ones; words_out[g] = (bits + 63) / 64; }
+        else {
+            const uint32_t rel = (uint32_t)(ones_scan[g] - ones_scan[t.rbase[k_node]]);
+            hdr[2 * g] = make_uint4(rel, (uint32_t)words_scan[g], (uint32_t)cls[0], (uint32_t)(cls[0] >> 32));
+            hdr[2 * g + 1] = make_uint4((uint32_t)cls[1], (uint32_t)(cls[1] >> 32), (uint32_t)cls[2], (uint32_t)(cls[2] >> 32));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_index_compress(const vlg_index* src, int kind, vlg_index** out)
+{
+    if (!src || !out) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    if (kind != VLG_BV_RRR63) return fail(VLG_E_INVALID, "unknown bit-vector kind");
+    if (src->hdr.bv_kind != kBvPlain) return fail(VLG_E_INVALID, "source index must use plain bit-vectors");
+    vlg_index* idx = new vlg_index();
+    idx->tree = src->tree;
+    HostTree& t = idx->tree;
+    RrrTable tab;
+    memset(&tab, 0, sizeof tab);
+    uint64_t n_sb = 0;
+    for (uint32_t v = 0; v < t.n_nodes; ++v)
+        if (t.nodes[v].child[0] != 0xFFFF) {
+            uint32_t k = tab.count++;
+            tab.pbase[k] = src->tree.dnodes[v].base;
+            tab.rbase[k] = (uint32_t)n_sb;
+            tab.size[k] = t.node_size[v];
+            t.dnodes[v].base = (uint32_t)n_sb;
+            n_sb += t.node_size[v] / kRrrSuperBits + 1;
+        }
+    if (n_sb > 0xFFFFFFF0ull) { delete idx; return fail(VLG_E_UNSUPPORTED, "too many rrr super-blocks"); }
+    hipStream_t stream = nullptr;
+    auto run = [&]() -> vlg_status {
+        std::vector<uint64_t> binom(64 * 64, 0);
+        for (int nn = 0; nn < 64; ++nn) binom[nn * 64] = 1;
+        for (int nn = 1; nn < 64; ++nn)
+            for (int k = 1; k < 64; ++k) binom[nn * 64 + k] = (k == nn) ? 1 : (k > nn ? 0 : binom[(nn - 1) * 64 + k - 1] + binom[(nn - 1) * 64 + k]);
+        uint64_t total_words = 0;
+        DevBuf d_tab, d_binom, d_ones, d_words, d_tmp;
+        VLG_HIP_TRY(d_tab.alloc(sizeof tab));
+        VLG_HIP_TRY(d_binom.alloc(64 * 64 * 8));
+        VLG_HIP_TRY(hipMemcpy(d_tab.p, &tab, sizeof tab, hipMemcpyHostToDevice));
+        VLG_HIP_TRY(hipMemcpy(d_binom.p, binom.data(), 64 * 64 * 8, hipMemcpyHostToDevice));
+        if (n_sb) {
+            VLG_HIP_TRY(d_ones.alloc((n_sb + 1) * 8));
+            VLG_HIP_TRY(d_words.alloc((n_sb + 1) * 8));
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((n_sb + 255) / 256, 4096);
+            hipLaunchKernelGGL(rrr_encode_kernel, dim3(grid), dim3(256), 0, stream, src->view.blocks, d_tab.as<RrrTable>(), n_sb, d_binom.as<uint64_t>(),
+                               d_ones.as<uint64_t>(), d_words.as<uint64_t>(), nullptr, nullptr, nullptr, nullptr);
+            VLG_HIP_TRY(hipGetLastError());
+            uint64_t last_words = 0;
+            VLG_HIP_TRY(hipMemcpyAsync(&last_words, d_words.as<uint64_t>() + (n_sb - 1), 8, hipMemcpyDeviceToHost, stream));
+            size_t tb = 0;
+            VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_ones.as<uint64_t>(), d_ones.as<uint64_t>(), (uint64_t)0, n_sb, rocprim::plus<uint64_t>(), stream));
+            VLG_HIP_TRY(d_tmp.alloc(tb));
+            VLG_HIP_TRY(rocprim::exclusive_scan(d_tmp.p, tb, d_ones.as<uint64_t>(), d_ones.as<uint64_t>(), (uint64_t)0, n_sb, rocprim::plus<uint64_t>(), stream));
+            VLG_HIP_TRY(rocprim::exclusive_scan(d_tmp.p, tb, d_words.as<uint64_t>(), d_words.as<uint64_t>(), (uint64_t)0, n_sb, rocprim::plus<uint64_t>(), stream));
+            uint64_t last_off = 0;
+            VLG_HIP_TRY(hipMemcpyAsync(&last_off, d_words.as<uint64_t>() + (n_sb - 1), 8, hipMemcpyDeviceToHost, stream));
+            VLG_HIP_TRY(hipStreamSynchronize(stream));
+            total_words = last_off + last_words;
+            if (total_words > 0xFFFFFFF0ull) return fail(VLG_E_UNSUPPORTED, "rrr offset stream too long");
+        }
+        if (vlg_status st = alloc_blob(idx, src->hdr.n, src->hdr.dens, stream, std::max<uint64_t>(n_sb, 1), total_words)) return st;
+        const BlobHeader& h = idx->hdr;
+        uint8_t* b = reinterpret_cast<uint8_t*>(idx->d_blob);
+        const uint8_t* sb = reinterpret_cast<const uint8_t*>(src->d_blob);
+        VLG_HIP_TRY(hipMemcpyAsync(b + h.off_samples, sb + src->hdr.off_samples, h.n_samples * h.sample_bytes, hipMemcpyDeviceToDevice, stream));
+        VLG_HIP_TRY(hipMemcpyAsync(b + h.off_binom, d_binom.p, 64 * 64 * 8, hipMemcpyDeviceToDevice, stream));
+        VLG_HIP_TRY(hipMemsetAsync(b + h.off_rrr_stream, 0, (total_words + 2) * 8, stream));
+        VLG_HIP_TRY(hipMemsetAsync(b + h.off_rrr_hdr, 0, std::max<uint64_t>(n_sb, 1) * 32, stream));
+        if (n_sb) {
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((n_sb + 255) / 256, 4096);
+            hipLaunchKernelGGL(rrr_encode_kernel, dim3(grid), dim3(256), 0, stream, src->view.blocks, d_tab.as<RrrTable>(), n_sb, d_binom.as<uint64_t>(),
+                               nullptr, nullptr, d_ones.as<uint64_t>(), d_words.as<uint64_t>(), reinterpret_cast<uint4*>(b + h.off_rrr_hdr),
+                               reinterpret_cast<uint64_t*>(b + h.off_rrr_stream));
+            VLG_HIP_TRY(hipGetLastError());
+        }
+        VLG_HIP_TRY(hipStreamSynchronize(stream));
+        return VLG_OK;
+    };
+    vlg_status st = run();
+    if (st) { vlg_index_destroy(idx); return st; }
     *out = idx;
     return VLG_OK;
 }

@@ -336,7 +336,8 @@ extern "C" void vlg_rrr_bitvector_destroy(vlg_rrr_bitvector* bv)
 namespace vlg {
 
 // #c in BWT[0,i): walk the code of c from the root; one super-block read per level.
-__device__ __forceinline__ uint64_t wt_rank_dev(const IndexView& iv, const TreeLds& s, uint64_t path, uint64_t i, uint32_t& levels)
+template <class BV>
+__device__ __forceinline__ uint64_t wt_rank_dev(const IndexView& iv, const WalkLds<BV>& s, uint64_t path, uint64_t i, uint32_t& levels)
 {
     uint32_t len = (uint32_t)(path >> 56);
     if (len == 0) return (iv.sigma == 1) ? i : 0;       // sigma==1: wt_pc.hpp:355-357 (the only symbol has an empty code)
@@ -344,7 +345,7 @@ __device__ __forceinline__ uint64_t wt_rank_dev(const IndexView& iv, const TreeL
     uint32_t v = 0;
     for (uint32_t l = 0; l < len && res; ++l, path >>= 1) {       // "and result": wt_pc.hpp:361
         uint32_t bit = (uint32_t)(path & 1);
-        uint64_t r1 = node_rank1(iv.blocks, s.nodes[v].base, res);
+        uint64_t r1 = BV::rank(iv, s.sh, s.nodes[v].base, res);
         ++levels;
         res = bit ? r1 : res - r1;
         v = s.nodes[v].child[bit] & ~kLeafFlag;
@@ -356,11 +357,12 @@ __device__ __forceinline__ uint64_t wt_rank_dev(const IndexView& iv, const TreeL
 
 namespace {
 
+template <class BV>
 __global__ void __launch_bounds__(256) wt_rank_kernel(IndexView iv, const uint64_t* __restrict__ pos, const uint8_t* __restrict__ sym,
                                                       uint64_t* __restrict__ out, uint64_t count)
 {
-    __shared__ TreeLds s;
-    stage_tree(s, iv);
+    __shared__ WalkLds<BV> s;
+    stage_walk(s, iv);
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) {
         uint8_t c = sym[j];
         uint64_t path = iv.paths[c];
@@ -371,12 +373,13 @@ __global__ void __launch_bounds__(256) wt_rank_kernel(IndexView iv, const uint64
 }
 
 // one lane per pattern; the two ranks of a step are independent loads
+template <class BV>
 __global__ void __launch_bounds__(256) backward_search_kernel(IndexView iv, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
                                                               uint64_t n_pat, uint64_t* __restrict__ out_l, uint64_t* __restrict__ out_r,
                                                               unsigned long long* __restrict__ stat_levels)
 {
-    __shared__ TreeLds s;
-    stage_tree(s, iv);
+    __shared__ WalkLds<BV> s;
+    stage_walk(s, iv);
     uint32_t levels = 0;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pat; p += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t b = off[p], e = off[p + 1];
@@ -417,12 +420,12 @@ __global__ void __launch_bounds__(256) backward_search_kernel(IndexView iv, cons
 // all 64 lanes issue one 32-byte super-block read per iteration whatever the (geometric) number
 // of LF steps and whatever the code lengths.
 // =============================================================================================
-template <typename pos_t>
+template <typename pos_t, class BV>
 __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __restrict__ io, uint64_t total, uint32_t per_wave,
                                                      unsigned long long* __restrict__ stats /* [2]: lf steps, levels */)
 {
-    __shared__ TreeLds s;
-    stage_tree(s, iv);
+    __shared__ WalkLds<BV> s;
+    stage_walk(s, iv);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint64_t next = wave * per_wave;                       // wave-uniform cursor into the slice
@@ -466,11 +469,9 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
             } else {
                 // one level of inverse_select: the bit and the rank come from the same block
                 const DNode nd = s.nodes[v];
-                uint32_t blk, o;
-                split224(i, blk, o);
-                BlockRegs R = load_block(iv.blocks, nd.base + blk);
-                uint32_t bit = block_bit(R, o);
-                uint64_t r1 = block_rank(R, o);
+                uint32_t bit;
+                uint64_t r1;
+                BV::rank_bit(iv, s.sh, nd.base, i, r1, bit);
                 ++n_lv;
                 uint64_t ni = bit ? r1 : i - r1;
                 uint32_t ch = nd.child[bit];
@@ -551,13 +552,14 @@ __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t
     }
 }
 
+template <class BV>
 __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count,
                                                          uint32_t step, uint32_t* __restrict__ out,
                                                          unsigned long long* __restrict__ stats /* lf, levels */,
                                                          unsigned long long* __restrict__ n_done)
 {
-    __shared__ TreeLds s;
-    stage_tree(s, iv);
+    __shared__ WalkLds<BV> s;
+    stage_walk(s, iv);
     const uint32_t dens = iv.dens;
     const bool pow2 = (dens & (dens - 1)) == 0;
     const uint32_t dmask = dens - 1;
@@ -580,11 +582,9 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
             uint64_t pos = i;
             for (;;) {                                       // inverse_select: wt_pc.hpp:385-402
                 const DNode nd = s.nodes[v];
-                uint32_t blk, o;
-                split224(pos, blk, o);
-                BlockRegs R = load_block(iv.blocks, nd.base + blk);
-                uint32_t bit = block_bit(R, o);
-                uint64_t r1 = block_rank(R, o);
+                uint32_t bit;
+                uint64_t r1;
+                BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
                 ++n_lv;
                 pos = bit ? r1 : pos - r1;
                 uint32_t ch = nd.child[bit];
@@ -606,11 +606,12 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
 }
 
 // stragglers: finish the few elements still alive after the sweep, one lane each
+template <class BV>
 __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uint64_t* __restrict__ val, uint64_t count, uint32_t step,
                                                          uint32_t* __restrict__ out, unsigned long long* __restrict__ stats)
 {
-    __shared__ TreeLds s;
-    stage_tree(s, iv);
+    __shared__ WalkLds<BV> s;
+    stage_walk(s, iv);
     const uint32_t dens = iv.dens;
     const uint32_t* samples = reinterpret_cast<const uint32_t*>(iv.samples);
     uint32_t n_lv = 0, n_lf = 0;
@@ -623,11 +624,9 @@ __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uin
             uint64_t pos = i;
             for (;;) {
                 const DNode nd = s.nodes[v];
-                uint32_t blk, o;
-                split224(pos, blk, o);
-                BlockRegs R = load_block(iv.blocks, nd.base + blk);
-                uint32_t bit = block_bit(R, o);
-                uint64_t r1 = block_rank(R, o);
+                uint32_t bit;
+                uint64_t r1;
+                BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
                 ++n_lv;
                 pos = bit ? r1 : pos - r1;
                 uint32_t ch = nd.child[bit];
@@ -666,8 +665,12 @@ vlg_status launch_backward_search(const IndexView& iv, const uint8_t* d_blob, co
                                   uint64_t* d_r, unsigned long long* d_stat_levels, hipStream_t stream)
 {
     if (!n_pat) return VLG_OK;
-    hipLaunchKernelGGL(backward_search_kernel, dim3(grid_for(n_pat, 4096)), dim3(256), 0, stream, iv, d_blob, d_off, n_pat, d_l, d_r,
-                       d_stat_levels);
+    if (iv.bv_kind == kBvRrr63)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(backward_search_kernel<RrrBV>), dim3(grid_for(n_pat, 4096)), dim3(256), 0, stream, iv, d_blob, d_off,
+                           n_pat, d_l, d_r, d_stat_levels);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(backward_search_kernel<PlainBV>), dim3(grid_for(n_pat, 4096)), dim3(256), 0, stream, iv, d_blob, d_off,
+                           n_pat, d_l, d_r, d_stat_levels);
     VLG_HIP_TRY(hipGetLastError());
     return VLG_OK;
 }
@@ -697,8 +700,12 @@ vlg_status launch_locate(const IndexView& iv, pos_t* d_io, uint64_t total, unsig
     per_wave = std::min<uint64_t>(per_wave, 1u << 20);
     uint64_t waves = (total + per_wave - 1) / per_wave;
     uint64_t wgs = (waves + 3) / 4;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t>), dim3((uint32_t)wgs), dim3(256), 0, stream, iv, d_io, total,
-                       (uint32_t)per_wave, d_stats);
+    if (iv.bv_kind == kBvRrr63)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, RrrBV>), dim3((uint32_t)wgs), dim3(256), 0, stream, iv, d_io, total,
+                           (uint32_t)per_wave, d_stats);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, PlainBV>), dim3((uint32_t)wgs), dim3(256), 0, stream, iv, d_io, total,
+                           (uint32_t)per_wave, d_stats);
     VLG_HIP_TRY(hipGetLastError());
     return VLG_OK;
 }
@@ -732,8 +739,12 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     while (alive > tail_threshold) {
         VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
         if (timer) timer->begin(0);
-        hipLaunchKernelGGL(sweep_step_kernel, dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, key_a, alive, step, d_out,
-                           d_stats, d_counter);
+        if (iv.bv_kind == kBvRrr63)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, key_a, alive,
+                               step, d_out, d_stats, d_counter);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, key_a,
+                               alive, step, d_out, d_stats, d_counter);
         if (timer) timer->end(0);
         VLG_HIP_TRY(hipGetLastError());
         size_t tb = temp_bytes;
@@ -752,7 +763,12 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     }
     if (alive) {
         if (timer) timer->begin(0);
-        hipLaunchKernelGGL(sweep_tail_kernel, dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, alive, step, d_out, d_stats);
+        if (iv.bv_kind == kBvRrr63)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<RrrBV>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, alive, step,
+                               d_out, d_stats);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<PlainBV>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, alive, step,
+                               d_out, d_stats);
         if (timer) timer->end(0);
         VLG_HIP_TRY(hipGetLastError());
     }
@@ -766,7 +782,12 @@ extern "C" vlg_status vlg_wt_rank_batch(const vlg_index* idx, const uint64_t* d_
 {
     if (!idx || (count && (!d_i || !d_c || !d_out))) return fail(VLG_E_INVALID, "null argument");
     if (!count) return VLG_OK;
-    hipLaunchKernelGGL(wt_rank_kernel, dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream, idx->view, d_i, d_c, d_out, count);
+    if (idx->view.bv_kind == kBvRrr63)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wt_rank_kernel<RrrBV>), dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream, idx->view, d_i, d_c,
+                           d_out, count);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wt_rank_kernel<PlainBV>), dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream, idx->view, d_i,
+                           d_c, d_out, count);
     VLG_HIP_TRY(hipGetLastError());
     return VLG_OK;
 }

@@ -217,7 +217,13 @@ class VlgIndex:
     def info(self):
         i = capi.IndexInfo()
         check(lib().vlg_index_get_info(self._h, C.byref(i)))
-        return {k: int(getattr(i, k)) for k, _ in capi.IndexInfo._fields_ if k != "reserved"}
+        return {k: int(getattr(i, k)) for k, _ in capi.IndexInfo._fields_}
+
+    def compress(self, bv_kind=1):
+        """A csa_wt<wt_huff<rrr_vector<63>>>-equivalent of this (plain) index; same answers, compressed bit-vectors."""
+        h = C.c_void_p()
+        check(lib().vlg_index_compress(self._h, bv_kind, C.byref(h)))
+        return VlgIndex(h)
 
     def export_parts(self):
         sz = capi.IndexParts()
