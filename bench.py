@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--workspace-gb", type=float, default=160.0)
     ap.add_argument("--bv", choices=["plain", "rrr"], default=None, help="wavelet-tree bit-vectors (default: rrr for C5, else plain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,11 +91,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
 
     import vlg_matching_amd as V
     from vlg_matching_amd import workload

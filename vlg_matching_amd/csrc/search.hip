@@ -32,7 +32,7 @@ struct vlg_queries {
     std::vector<uint8_t> blob;
     std::vector<uint64_t> lo, hi;    // [nsub]
     std::vector<uint64_t> end_len;   // [nq]
-    uint32_t kmax = 0;
+    uint32_t kmax = 0, kmin = 0;     // over queries with at least one sub-pattern
     uint8_t* d_blob = nullptr;
     uint64_t* d_suboff = nullptr;
 };
@@ -121,8 +121,13 @@ vlg_status parse_one(const char* re, uint64_t len, int dialect, Parsed& out, std
 
 vlg_status upload_queries(vlg_queries* q)
 {
-    q->kmax = 0;
-    for (uint64_t i = 0; i < q->nq; ++i) q->kmax = std::max<uint32_t>(q->kmax, (uint32_t)(q->qsub[i + 1] - q->qsub[i]));
+    q->kmax = 0; q->kmin = 0xFFFFFFFFu;
+    for (uint64_t i = 0; i < q->nq; ++i) {
+        uint32_t k = (uint32_t)(q->qsub[i + 1] - q->qsub[i]);
+        q->kmax = std::max<uint32_t>(q->kmax, k);
+        if (k) q->kmin = std::min<uint32_t>(q->kmin, k);
+    }
+    if (q->kmin == 0xFFFFFFFFu) q->kmin = 0;
     VLG_HIP_TRY(hipMalloc((void**)&q->d_blob, q->blob.size() + 16));
     VLG_HIP_TRY(hipMalloc((void**)&q->d_suboff, (q->nsub + 1) * 8));
     if (!q->blob.empty()) VLG_HIP_TRY(hipMemcpy(q->d_blob, q->blob.data(), q->blob.size(), hipMemcpyHostToDevice));
@@ -543,10 +548,62 @@ __device__ __forceinline__ uint32_t seg_find(const uint32_t* __restrict__ seg_be
     return lo;
 }
 
+// Feasibility of every slot is ONE BIT; "nearest feasible slot at or after j" is a successor query on a hierarchical
+// bitset: level 0 = the feasibility bits, bit i of level l+1 = (word i of level l != 0).  A query reads one word per
+// level it has to climb (almost always just level 0), so the per-level reverse scans of a 4-byte-per-slot array are gone.
+constexpr uint32_t kBitLevels = 6;          // 64^6 slots > 2^32
+struct FeasBits { const uint64_t* lvl[kBitLevels]; uint64_t words[kBitLevels]; };
+
+// Kernels get level 0 as a plain pointer (the fast path) and the level table through device memory (the rare climb).
+struct FeasRef { const uint64_t* lvl0; const FeasBits* table; };
+
+__device__ __noinline__ uint32_t next_feasible_slow(const FeasBits* __restrict__ fb, uint64_t w0)
+{
+    // no set bit in word w0 behind the position: climb until a set bit is found, then descend to the lowest such bit
+    uint64_t pos = w0 + 1;
+    uint32_t l = 1;
+    for (;; ++l) {
+        if (l == kBitLevels) return kNone;
+        const uint64_t w = pos >> 6;
+        if (w >= fb->words[l]) return kNone;
+        const uint64_t bits = fb->lvl[l][w] >> (pos & 63);
+        if (bits) { pos += (uint64_t)__ffsll((long long)bits) - 1; break; }
+        pos = w + 1;
+    }
+    while (l) {                                         // pos = index of a non-zero word of level l-1
+        --l;
+        const uint64_t bits = fb->lvl[l][pos];
+        pos = pos * 64 + (uint64_t)__ffsll((long long)bits) - 1;
+    }
+    return pos < 0xFFFFFFFFull ? (uint32_t)pos : kNone;
+}
+__device__ __forceinline__ uint32_t next_feasible(const FeasRef& fb, uint64_t j)
+{
+    const uint64_t w0 = j >> 6;
+    const uint64_t bits = fb.lvl0[w0] >> (j & 63);                   // almost always answers the query
+    if (bits) return (uint32_t)(j + (uint64_t)__ffsll((long long)bits) - 1);
+    return next_feasible_slow(fb.table, w0);
+}
+__device__ __forceinline__ bool is_feasible(const FeasRef& fb, uint64_t e) { return (fb.lvl0[e >> 6] >> (e & 63)) & 1; }
+
+// one level of the summary: out word i = bitmap of (in[64 i + b] != 0)
+__global__ void bits_summary_kernel(const uint64_t* __restrict__ in, uint64_t in_words, uint64_t w0, uint64_t w1 /* output word range */,
+                                    uint64_t* __restrict__ out)
+{
+    for (uint64_t i = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < w1; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v = 0;
+        for (uint32_t b = 0; b < 64; ++b) {
+            const uint64_t idx = i * 64 + b;
+            if (idx < in_words && in[idx]) v |= 1ull << b;
+        }
+        out[i] = v;
+    }
+}
+
 // single-sub-pattern queries (class dist 0): every element is a feasible chain that ends at itself
 template <typename pos_t>
 __global__ void __launch_bounds__(256) join_init_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
-                                                        const SegMeta* __restrict__ sm, uint64_t r0, uint64_t r1, uint32_t* __restrict__ feas,
+                                                        const SegMeta* __restrict__ sm, uint64_t r0, uint64_t r1, uint64_t* __restrict__ fbits,
                                                         pos_t* __restrict__ endp)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -561,10 +618,11 @@ __global__ void __launch_bounds__(256) join_init_kernel(const pos_t* __restrict_
             uint32_t s = s_w;
             while (seg_begin[s + 1] <= e) ++s;
             const SegMeta m = sm[s];
-            feas[e] = (uint32_t)e;
             endp[e] = P[phys_of(m, (uint32_t)e)];
             s_w = s;
         }
+        const unsigned long long act = __ballot(e < run_end);
+        if (lane == 0) fbits[base >> 6] = act;         // class ranges and runs are 64-aligned: one word per step
         s_w = __shfl(s_w, 0);                          // lane 0 is always in range and holds the smallest segment
     }
 }
@@ -575,7 +633,7 @@ __global__ void __launch_bounds__(256) join_init_kernel(const pos_t* __restrict_
 template <typename pos_t>
 __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
                                                         const SegMeta* __restrict__ sm, uint64_t r0, uint64_t r1, uint32_t dist,
-                                                        const uint32_t* __restrict__ nf_in, uint32_t* __restrict__ feas_out,
+                                                        FeasRef fb, uint64_t* __restrict__ fbits_out,
                                                         pos_t* __restrict__ endp, uint32_t* __restrict__ link)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -609,20 +667,22 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
             const uint64_t tlo = sat_add(x, nx.lo), thi = sat_add(x, nx.hi);
             if (hint_seg == s_w) j = wave_lower_bound(P, hint, nx.pend, tlo, active);
             else if (active) j = gallop_lower_bound(P, nx.pbegin, nx.pend, tlo);
+            bool ok = false;
             if (active) {
-                bool ok = false;
                 if (dist == 1) {                                   // next list is the last one: every element is feasible
                     if (j < nx.pend) { const uint64_t v = P[j]; ok = v <= thi; if (ok) { link[e] = j; endp[e] = (pos_t)v; } }
                 } else if (j < nx.pend) {
-                    uint32_t ej = nf_in[nx.begin + (j - nx.pbegin)];      // nearest feasible logical element at or after it
+                    uint32_t ej = next_feasible(fb, (uint64_t)nx.begin + (j - nx.pbegin));   // nearest feasible logical element at or after it
                     if (ej < nx.end && (uint64_t)P[phys_of(nx, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
                 }
-                feas_out[e] = ok ? (uint32_t)e : kNone;
             }
+            const unsigned long long okm = __ballot(ok);
+            if (lane == 0) fbits_out[base >> 6] = okm;
         } else {
             // ---- a segment border inside the step: every lane looks its own segment up ------------------
             have_pre = false;
             uint32_t s = s_w;
+            bool ok = false;
             if (active) {
                 while (seg_begin[s + 1] <= e) ++s;
                 const SegMeta ml = sm[s];
@@ -630,16 +690,18 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
                 const uint64_t x = P[phys_of(ml, (uint32_t)e)];
                 const uint64_t tlo = sat_add(x, nl.lo), thi = sat_add(x, nl.hi);
                 j = gallop_lower_bound(P, (s == hint_seg) ? hint : nl.pbegin, nl.pend, tlo);
-                bool ok = false;
-                if (dist == 1) {
-                    ok = j < nl.pend && (uint64_t)P[j] <= thi;
-                    if (ok) { link[e] = j; endp[e] = P[j]; }
-                } else if (j < nl.pend) {
-                    uint32_t ej = nf_in[nl.begin + (j - nl.pbegin)];
-                    if (ej < nl.end && (uint64_t)P[phys_of(nl, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+                if (e < ml.end) {                                  // padding slots between classes belong to no segment
+                    if (dist == 1) {
+                        ok = j < nl.pend && (uint64_t)P[j] <= thi;
+                        if (ok) { link[e] = j; endp[e] = P[j]; }
+                    } else if (j < nl.pend) {
+                        uint32_t ej = next_feasible(fb, (uint64_t)nl.begin + (j - nl.pbegin));
+                        if (ej < nl.end && (uint64_t)P[phys_of(nl, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+                    }
                 }
-                feas_out[e] = ok ? (uint32_t)e : kNone;
             }
+            const unsigned long long okm = __ballot(ok);
+            if (lane == 0) fbits_out[base >> 6] = okm;
             s_last = __shfl(s, (int)(step_last - base));
         }
         hint_seg = s_last;
@@ -652,7 +714,7 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
 template <typename pos_t>
 __global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
                                                         const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint64_t r0,
-                                                        uint64_t r1, const uint32_t* __restrict__ nf, const pos_t* __restrict__ endp,
+                                                        uint64_t r1, FeasRef fb, const pos_t* __restrict__ endp,
                                                         uint32_t* __restrict__ jump, uint32_t* __restrict__ qstart)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -671,14 +733,13 @@ __global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict_
         if (inr) {
             while (seg_begin[s + 1] <= e) ++s;
             const SegMeta m = sm[s];
-            if (m.level == 0) {
-                const uint32_t me = nf[e];
-                if (me == (uint32_t)e) {                              // feasible start
+            if (m.level == 0 && e < m.end) {
+                if (is_feasible(fb, e)) {                             // feasible start
                     lim = sat_add((uint64_t)endp[e], qm[m.query].end_len);
                     fence = phys_of(m, (uint32_t)e) + 1;
                     searched = true;
                 }
-                if ((uint32_t)e == m.begin) qstart[m.query] = me < m.end ? me : kNone;
+                if ((uint32_t)e == m.begin) { const uint32_t me = next_feasible(fb, e); qstart[m.query] = me < m.end ? me : kNone; }
             }
             mbegin = m.begin; mend = m.end; mpbegin = m.pbegin; mpend = m.pend;
         }
@@ -698,7 +759,7 @@ __global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict_
         if (inr) {
             uint32_t out = kNone;
             if (searched && jp < mpend) {
-                uint32_t ej = nf[mbegin + (jp - mpbegin)];
+                uint32_t ej = next_feasible(fb, (uint64_t)mbegin + (jp - mpbegin));
                 if (ej < mend) out = ej;
             }
             jump[e] = out;
@@ -871,7 +932,8 @@ struct Plan {                       // host view of the batch after backward sea
 };
 
 template <typename pos_t> constexpr uint64_t kPhysScratchPerElem() { return sizeof(pos_t) == 4 ? 20 : sizeof(pos_t); }
-constexpr uint64_t kJoinBytesPerSlot = 6 * 4 + 8 + 1; // link, nf, feas, jump, mlist, endp(<=8), chain records
+constexpr uint64_t kJoinBytesPerSlot = 4 + 8 + 1;      // link, endp(<=8), feasibility bits + summaries (any slot)
+constexpr uint64_t kJoinBytesPerSlot0 = 4 + 4 + 8 + 1; // jump, mlist, (exit,hops), chain records (slots of list 0)
 
 // ---- physical pass: locate + sort every distinct interval used by queries [Q0,Q1) -------------------
 template <typename pos_t>
@@ -998,6 +1060,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     uint64_t acc = 0;
     std::vector<uint64_t> cls_slot_begin(kmax + 1, 0), cls_slot_end(kmax + 1, 0);
     for (int d = (int)kmax - 1; d >= 0; --d) {
+        acc = align_up(acc, 64);                                             // a wave step of a class owns whole words of the feasibility bitmap
         cls_slot_begin[d] = acc;
         for (uint32_t j = 0; j < cls_count[d]; ++j) {
             SegMeta& m = sm[cls_first[d] + j];
@@ -1022,20 +1085,33 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         }
     if (lvl0_end <= lvl0_begin) { res->pieces.push_back(piece); return VLG_OK; }
     // ---- carve the arena ---------------------------------------------------------------------------
-    size_t scan_tmp = 0;
-    {
-        uint32_t* nu = nullptr;
-        auto rin = rocprim::make_reverse_iterator(nu);
-        VLG_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_tmp, rin, rin, T, rocprim::minimum<uint32_t>(), st));
-    }
     uint32_t* link = A.take<uint32_t>(T);
     pos_t* endp = A.take<pos_t>(T);
-    const uint64_t Tal = align_up(T, 64);
-    uint32_t* fn = A.take<uint32_t>(2 * Tal);            // feas | nf; reused as the (exit, hops) pairs of the chain tiles
-    uint32_t* feas = fn;
-    uint32_t* nf = fn ? fn + Tal : nullptr;
-    uint32_t* jump = A.take<uint32_t>(T);
-    uint32_t* mlist = A.take<uint32_t>(T);
+    // feasibility bitset + summaries
+    FeasBits fb;
+    uint64_t* lvl_ptr[kBitLevels];
+    {
+        uint64_t words = (T + 63) / 64 + 1;
+        for (uint32_t l = 0; l < kBitLevels; ++l) {
+            lvl_ptr[l] = A.take<uint64_t>(words);
+            fb.lvl[l] = lvl_ptr[l];
+            fb.words[l] = words;
+            if (lvl_ptr[l]) VLG_HIP_TRY(hipMemsetAsync(lvl_ptr[l], 0, words * 8, st));
+            words = (words + 63) / 64 + 1;
+        }
+    }
+    FeasBits* d_fb = A.take<FeasBits>(1);
+    if (d_fb) VLG_HIP_TRY(hipMemcpyAsync(d_fb, &fb, sizeof fb, hipMemcpyHostToDevice, st));
+    const FeasRef fref{lvl_ptr[0], d_fb};
+    // arrays that exist for the slots of list 0 only (indexed by absolute slot through an offset pointer)
+    const uint64_t t0 = lvl0_begin / kTile * kTile;
+    const uint64_t n0 = lvl0_end - t0;
+    uint32_t* jump_a = A.take<uint32_t>(n0);
+    uint32_t* mlist_a = A.take<uint32_t>(n0);
+    uint2* xh_a = A.take<uint2>(n0);
+    uint32_t* jump = jump_a ? jump_a - t0 : nullptr;
+    uint32_t* mlist = mlist_a ? mlist_a - t0 : nullptr;
+    uint2* xh = xh_a ? xh_a - t0 : nullptr;
     SegMeta* d_sm = A.take<SegMeta>(nlive + 1);
     QueryMeta* d_qm = A.take<QueryMeta>(nq);
     uint32_t* d_segb = A.take<uint32_t>(nlive + 2);
@@ -1057,47 +1133,45 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     uint32_t* d_recc = A.take<uint32_t>(nq);
     uint32_t* d_recq = A.take<uint32_t>(n_rec + 1);
     uint2* d_rec = A.take<uint2>(n_rec + 1);
-    void* d_tmp = A.take<uint8_t>(scan_tmp + 256);
-    if (!d_tmp) return fail(VLG_E_INTERNAL, "arena carve failed (join)");
+    if (!d_rec || !xh_a || !lvl_ptr[kBitLevels - 1]) return fail(VLG_E_INTERNAL, "arena carve failed (join)");
     VLG_HIP_TRY(hipMemcpyAsync(d_recb, rec_begin.data(), (nq + 1) * 4, hipMemcpyHostToDevice, st));
     if (n_rec) VLG_HIP_TRY(hipMemcpyAsync(d_recq, rec_query.data(), n_rec * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemsetAsync(d_qstart, 0xFF, nq * 4, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_sm, sm.data(), (nlive + 1) * sizeof(SegMeta), hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_segb, seg_begin.data(), (nlive + 2) * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
-    if (cls_slot_end[0] > cls_slot_begin[0]) {
-        Timed t(ws, KS_JOIN_INIT, 0);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_init_kernel<pos_t>), dim3(runs_grid(cls_slot_end[0] - cls_slot_begin[0])), dim3(256), 0, st, P,
-                               d_segb, nlive, d_sm, cls_slot_begin[0], cls_slot_end[0], feas, endp);
-    }
-    // nf is only ever read at slots of classes that are complete, so it is scanned class by class
-    auto scan_class = [&](uint32_t d) -> vlg_status {
+    // after a class's pass wrote its words of level 0, refresh the summary words above them
+    auto summarize_class = [&](uint32_t d) -> vlg_status {
         uint64_t b0 = cls_slot_begin[d], b1 = cls_slot_end[d];
         if (b1 <= b0) return VLG_OK;
-        Timed t(ws, KS_JOIN_SCAN, 8ull * (b1 - b0));
-        // nf[j] = nearest feasible element at or after j (reverse running minimum of feas inside the class)
-        auto rin = rocprim::make_reverse_iterator(feas + b1);
-        auto rout = rocprim::make_reverse_iterator(nf + b1);
-        size_t tb = scan_tmp;
-        VLG_HIP_TRY(rocprim::inclusive_scan(d_tmp, tb, rin, rout, b1 - b0, rocprim::minimum<uint32_t>(), st));
+        Timed t(ws, KS_JOIN_SCAN, (b1 - b0) / 8);
+        uint64_t w0 = b0 >> 6, w1 = (b1 + 63) >> 6;                          // word range written at the level below
+        for (uint32_t l = 1; l < kBitLevels; ++l) {
+            w0 >>= 6; w1 = (w1 + 63) >> 6;
+            hipLaunchKernelGGL(bits_summary_kernel, dim3(grid_for(w1 - w0, 4096)), dim3(256), 0, st, fb.lvl[l - 1], fb.words[l - 1], w0, w1, lvl_ptr[l]);
+        }
+        VLG_HIP_TRY(hipGetLastError());
         return VLG_OK;
     };
-    if (vlg_status s = scan_class(0)) return s;
+    if (cls_slot_end[0] > cls_slot_begin[0]) {
+        Timed t(ws, KS_JOIN_INIT, 0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_init_kernel<pos_t>), dim3(runs_grid(cls_slot_end[0] - cls_slot_begin[0])), dim3(256), 0, st, P,
+                           d_segb, nlive, d_sm, cls_slot_begin[0], cls_slot_end[0], lvl_ptr[0], endp);
+    }
+    if (vlg_status s = summarize_class(0)) return s;
     for (uint32_t dist = 1; dist < kmax; ++dist) {
         uint64_t b0 = cls_slot_begin[dist], b1 = cls_slot_end[dist];
         if (b1 > b0) {
             Timed t(ws, KS_JOIN_LINK, 8ull * (b1 - b0));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, d_segb, nlive, d_sm, b0, b1,
-                               dist, nf, feas, endp, link);
+                               dist, fref, lvl_ptr[0], endp, link);
         }
-        if (vlg_status s = scan_class(dist)) return s;
+        if (vlg_status s = summarize_class(dist)) return s;
     }
     {
         Timed t(ws, KS_JOIN_CHAIN, 8ull * (lvl0_end - lvl0_begin));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(runs_grid(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, d_segb, nlive, d_sm,
-                           d_qm, lvl0_begin, lvl0_end, nf, endp, jump, d_qstart);
-        uint2* xh = reinterpret_cast<uint2*>(fn);           // feas / nf are dead from here on
-        const uint64_t t0 = lvl0_begin / kTile * kTile;
+                           d_qm, lvl0_begin, lvl0_end, fref, endp, jump, d_qstart);
         if (t0 < lvl0_begin) VLG_HIP_TRY(hipMemsetAsync(jump + t0, 0xFF, (lvl0_begin - t0) * 4, st));   // slots of the first tile before the range
         hipLaunchKernelGGL(chain_tiles_kernel, dim3((uint32_t)((lvl0_end - t0 + kTile - 1) / kTile)), dim3(256), 0, st, jump, t0, lvl0_end, xh);
         hipLaunchKernelGGL(chain_walk_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, d_sm, d_qm, nq, d_qstart, xh, d_recb, d_rec, d_recc,
@@ -1499,11 +1573,22 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         ++epoch;
         // ---- arena: physical lists first, join scratch behind them -----------------------------------
         const bool lazy = ws->lazy_join && q->kmax <= kLazyK;
-        const uint64_t per_slot = lazy ? kLazyBytesPerSlot : kJoinBytesPerSlot;
+        // cost of a query in bytes of join scratch
+        const uint64_t per_slot = 1;
+        const bool uniform_k = q->kmin == q->kmax;
         auto slots_of = [&](uint64_t qi) -> uint64_t {
             uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
-            if (lazy) return k ? (pl.occ[q->qsub[qi]] + kLazyTile - 1) / kLazyTile * kLazyTile : 0;    // whole tiles of list 0
+            if (lazy) return (k ? (pl.occ[q->qsub[qi]] + kLazyTile - 1) / kLazyTile * kLazyTile : 0) * kLazyBytesPerSlot;   // whole tiles of list 0
             uint64_t t = 0;
+            for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += pl.occ[q->qsub[qi] + i];
+            // list-0 arrays cover the slot range of all lists 0, which is exactly those slots when every query has the same k
+            uint64_t t0s = k ? (uniform_k ? pl.occ[q->qsub[qi]] : t) : 0;
+            return t * kJoinBytesPerSlot + t0s * kJoinBytesPerSlot0;
+        };
+        auto nslots_of = [&](uint64_t qi) -> uint64_t {                      // slot indices are 32-bit inside a chunk
+            uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
+            if (lazy) return k ? (pl.occ[q->qsub[qi]] + kLazyTile - 1) / kLazyTile * kLazyTile : 0;
+            uint64_t t = 64ull * k;                                           // class alignment slack
             for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += pl.occ[q->qsub[qi] + i];
             return t;
         };
@@ -1523,14 +1608,14 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         }
         const uint64_t phys_bytes = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20);
         uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
-        uint64_t cap_slots = std::min<uint64_t>(join_budget / per_slot, 0xFFFFFF00ull);
-        if (lazy) cap_slots = cap_slots / kLazyTile * kLazyTile;
+        uint64_t cap_slots = join_budget / per_slot;                          // bytes
+        const uint64_t max_chunk_slots = 0xF0000000ull;
         if (logical_max_query > cap_slots)
-            return fail(VLG_E_WORKSPACE, "a query needs " + std::to_string(logical_max_query) + " join slots; workspace cap allows " +
+            return fail(VLG_E_WORKSPACE, "a query needs " + std::to_string(logical_max_query) + " bytes of join scratch; workspace cap allows " +
                                              std::to_string(cap_slots));
         uint64_t want_slots = std::min<uint64_t>(logical_total, cap_slots);
         uint64_t meta = (q->qsub[Q1] - q->qsub[Q0] + 4) * (sizeof(SegMeta) + 16) + (Q1 - Q0 + 4) * (sizeof(QueryMeta) + sizeof(LQuery) + 32) +
-                        (want_slots / kLazyTile + (Q1 - Q0) + 8) * 48;
+                        (want_slots / (kLazyTile * 8) + (Q1 - Q0) + 8) * 48 + (1ull << 20);
         if (vlg_status s = ws_reserve(ws, phys_bytes + want_slots * per_slot + meta + fixed)) return s;
         Arena A{ws->arena, ws->arena_bytes};
         pos_t* P = nullptr;
@@ -1539,11 +1624,12 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         // ---- join chunks ----------------------------------------------------------------------------
         uint64_t q0 = Q0;
         while (q0 < Q1) {
-            uint64_t T = 0, q1 = q0;
+            uint64_t T = 0, S = 0, q1 = q0;
             while (q1 < Q1) {
-                uint64_t t = slots_of(q1);
-                if ((T + t > want_slots && q1 > q0) || (q1 - q0) >= (1u << 22)) break;
-                T += t;
+                uint64_t t = slots_of(q1), sl = nslots_of(q1);
+                if (sl > max_chunk_slots) return fail(VLG_E_WORKSPACE, "a query has more than 2^32 join slots");
+                if (((T + t > want_slots || S + sl > max_chunk_slots) && q1 > q0) || (q1 - q0) >= (1u << 22)) break;
+                T += t; S += sl;
                 ++q1;
             }
             vlg_status s = lazy ? run_lazy_chunk<pos_t>(q, ws, res, q0, q1, pl, poff, P, A, d_stats)
