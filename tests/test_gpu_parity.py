@@ -481,3 +481,32 @@ def test_rrr_index_is_smaller_on_skewed_text(V):
     pi, ri = plain.info(), rrr.info()
     assert pi["hbm_bytes"] - ri["hbm_bytes"] > 0.5 * pi["n_blocks"] * 32      # the bit-vector part shrinks by more than half
     assert V.count(rrr, "aaaa.{0,5}?ab") == V.count(plain, "aaaa.{0,5}?ab")
+
+
+def test_edge_cases_empty_inputs_and_long_queries(V, oracle):
+    """Empty text, empty batch, all-dead batch, patterns longer than the text, 40 and 64 sub-patterns, 65 rejected."""
+    # empty text: nothing ever matches
+    e = V.VlgIndex.build(b"")
+    r = e.search(["a", "a.{0,3}?b"])
+    assert r.summary["n_matches"] == 0 and r.counts.tolist() == [0, 0]
+    # empty batch and a batch in which every query dies in backward search
+    idx = V.VlgIndex.build(b"a" * 100)
+    assert idx.search([]).summary["n_queries"] == 0
+    r = idx.search(["b", "a.{0,5}?b", "b.{0,5}?a", "a" * 101, "a" * 101 + ".{0,1}?a"])
+    assert r.summary["n_matches"] == 0 and r.summary["located_occurrences"] == 0
+    r = idx.search(["a" * 100 + ".{0,1}?a"])                     # both lists exist (1 and 100 occurrences) but no match fits
+    assert r.summary["n_matches"] == 0 and r.summary["located_occurrences"] == 101
+    # many sub-patterns (dense join path: k > 8)
+    o = oracle.Index.from_text(b"a" * 100)
+    for k in (40, 64):
+        q = ".{0,1}?".join(["a"] * k)
+        assert idx.search([q]).tuples(0).tolist() == o.search(q).tolist()
+        assert V.count(idx, q) == len(o.search(q)) >= 1
+    with pytest.raises(V.VlgError) as ex:
+        idx.search([".{0,1}?".join(["a"] * 65)])
+    assert ex.value.status == V.capi.E_INVALID
+    # whole text as a pattern, and patterns running over the end
+    t = b"abracadabrasimsalabim"
+    idx2, o2 = V.VlgIndex.build(t), oracle.Index.from_text(t)
+    for q in [t.decode(), t.decode() + "x", "bim", "bimx", "m.{0,0}?x", "abra.{3,3}?abra", "a.{0,100000}?m", "a.{100000,200000}?m"]:
+        assert idx2.search([q]).tuples(0).tolist() == o2.search(q).tolist(), q
