@@ -123,6 +123,18 @@ vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out
 vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* info);
 void vlg_index_destroy(vlg_index* idx);
 
+/* Load an index stored by stock sdsl: the file written by `store_to_file(csa, file)` / `csa.serialize(out)` for
+ * csa_wt<wt_huff<>, t_dens, t_inv_dens> with the default sampling strategies and byte_alphabet
+ * (include/sdsl/csa_wt.hpp:374-393; member formats: wt_pc.hpp:638-652, int_vector.hpp:584-600, rank_support_v.hpp:134-148,
+ * select_support_mcl.hpp:424-494, wt_helper.hpp:112-131,275-301, lib/csa_alphabet_strategy.cpp:103-121).
+ * t_dens is a template parameter of the reference type and is not stored: pass it (0 = 32, the reference default).
+ * vlg_sdsl_file_* parse on the host only (no GPU needed); vlg_index_load_sdsl = open + parts + vlg_index_from_parts. */
+typedef struct vlg_sdsl_file vlg_sdsl_file;
+vlg_status vlg_sdsl_file_open(const char* path, uint32_t sa_sample_dens, vlg_sdsl_file** out);
+vlg_status vlg_sdsl_file_parts(const vlg_sdsl_file* f, vlg_index_parts* parts);   /* pointers stay valid until close */
+void vlg_sdsl_file_close(vlg_sdsl_file* f);
+vlg_status vlg_index_load_sdsl(const char* path, uint32_t sa_sample_dens, vlg_index** out);
+
 /* One contiguous device image of the read-only index, for replication across the GPUs of a node
  * (SURVEY.md 8e): the owner exports it into caller-provided HBM, the caller moves it with RCCL
  * (ncclBroadcast, or torch.distributed.broadcast on a uint8 tensor), every other rank attaches.

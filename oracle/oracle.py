@@ -138,6 +138,8 @@ def ref():
         R.vref_sa.restype = C.c_uint64
         R.vref_lf.argtypes = [C.c_void_p, C.c_uint64]
         R.vref_lf.restype = C.c_uint64
+        R.vref_write_csa_image.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        R.vref_write_csa_image.restype = C.c_int
         R.vref_bitrank.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         R.vref_rank_v_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         R.vref_rank_v_blocks.restype = C.c_uint64
@@ -381,6 +383,12 @@ class RefIndex:
 
     def lf(self, i):
         return int(ref().vref_lf(self.h, int(i)))
+
+    def write_csa_image(self, path, sa):
+        """The file stock sdsl would store for this csa_wt<wt_huff<>,32,64> (members serialised by the reference itself)."""
+        s = np.ascontiguousarray(sa, dtype=np.uint64)
+        rc = ref().vref_write_csa_image(self.h, str(path).encode(), s.ctypes.data, len(s))
+        assert rc == 0
 
 
 def ref_bitrank(words, nbits, variant, idx):

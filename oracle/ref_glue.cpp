@@ -34,6 +34,7 @@
 #include <vector>
 #include <string>
 #include <atomic>
+#include <fstream>
 #include <cstring>
 
 using namespace sdsl;
@@ -55,6 +56,7 @@ struct ref_base {
     virtual void alphabet(uint8_t* c2c, uint64_t* C, uint32_t* sigma) const = 0;
     virtual uint64_t sa(uint64_t i) const = 0;
     virtual uint64_t lf_at(uint64_t i) const = 0;
+    virtual int write_csa_image(const char* path, const uint64_t* sa, uint64_t n) const = 0;
 };
 
 // Minimal csa_tag model for the reference's generic algorithms.
@@ -159,6 +161,25 @@ struct ref_csa : ref_base {
     }
     uint64_t sa(uint64_t i) const { return (*this)[i]; }
     uint64_t lf_at(uint64_t i) const { return lf[i]; }
+
+    // The byte image csa_wt::serialize writes (csa_wt.hpp:374-393): wavelet tree, SA samples, ISA samples, alphabet --
+    // every member through the reference's own serialize(); the ISA samples are filled as _isa_sampling's ctor does
+    // (csa_sampling_strategy.hpp:626-648, density 64 = csa_wt's default t_inv_dens).
+    int write_csa_image(const char* path, const uint64_t* sa_in, uint64_t n) const
+    {
+        std::ofstream out(path, std::ios::binary);
+        if (!out) return -1;
+        wavelet_tree.serialize(out);
+        sa_sample.serialize(out);
+        int_vector<> isa;
+        const uint64_t inv_dens = 64;
+        if (n >= 1) { isa.width(bits::hi(n) + 1); isa.resize((n - 1) / inv_dens + 1); }
+        for (uint64_t i = 0; i < isa.size(); ++i) isa[i] = 0;
+        for (uint64_t i = 0; i < n; ++i) if (sa_in[i] % inv_dens == 0) isa[sa_in[i] / inv_dens] = i;
+        isa.serialize(out);
+        m_alphabet.serialize(out);
+        return out ? 0 : -1;
+    }
 };
 
 typedef wt_huff<bit_vector, rank_support_v<>>  wt_v;
@@ -202,6 +223,7 @@ void vref_node(void* h, uint64_t v, uint64_t* bv_pos, uint64_t* sz, int* leaf, i
 void vref_alphabet(void* h, uint8_t* c2c, uint64_t* C, uint32_t* sigma) { ((ref_base*)h)->alphabet(c2c, C, sigma); }
 uint64_t vref_sa(void* h, uint64_t i) { return ((ref_base*)h)->sa(i); }
 uint64_t vref_lf(void* h, uint64_t i) { return ((ref_base*)h)->lf_at(i); }
+int vref_write_csa_image(void* h, const char* path, const uint64_t* sa, uint64_t n) { return ((ref_base*)h)->write_csa_image(path, sa, n); }
 
 // Stand-alone bit-vector rank: variant 0 = rank_support_v<1,1>, 1 = rank_support_v5<1,1>, 2 = rrr_vector<63>.
 void vref_bitrank(const uint64_t* words, uint64_t nbits, int variant,

@@ -96,3 +96,34 @@ def test_cpp_host_binaries_fail_loudly_without_gpu(V):
         V.build_library()
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode != 0 and "no HIP device" in r.stderr
+
+
+def test_sdsl_file_reader_on_reference_written_image(V, refmod, tmp_path):
+    """a csa_wt<wt_huff<>> file whose members were serialised by the reference's own code parses into exactly
+    the parts the oracle builds (host-only logic, no GPU)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import bwt_from_sa, dna_text, skewed_text
+    O = refmod
+    for name, text in [("abra", b"abracadabrasimsalabim"), ("dna", dna_text(20000, 3).tobytes()), ("zipf", skewed_text(30000, 4).tobytes()),
+                       ("allsym", bytes(range(1, 256)) * 3), ("one", b"a")]:
+        tz = np.frombuffer(text + b"\0", dtype=np.uint8)
+        sa = O.suffix_array(tz)
+        R = O.RefIndex(bwt_from_sa(tz, sa), sa, 0)
+        path = tmp_path / (name + ".sdsl")
+        R.write_csa_image(path, sa)
+        got = V.index.read_sdsl_file(path)
+        want = O.Index.from_text(text).parts()
+        assert got["n"] == want["n"] and got["sigma"] == want["sigma"] and got["bv_bits"] == want["bv_bits"]
+        assert (got["char2comp"] == want["char2comp"]).all() and (got["C"] == want["C"]).all()
+        assert (got["bv_words"] == want["bv_words"]).all() and (got["samples"] == want["samples"]).all()
+        for f in ("bv_pos", "bv_pos_rank", "parent", "child"):
+            assert (got["nodes"][f] == want["nodes"][f]).all(), f
+        # the CPU algorithm runs on the parsed parts
+        o2 = O.Index.from_parts(got)
+        assert o2.search("a.{0,10}?a").tolist() == O.Index.from_text(text).search("a.{0,10}?a").tolist()
+    (tmp_path / "junk.sdsl").write_bytes(b"not an index at all" * 10)
+    with pytest.raises(V.VlgError):
+        V.index.read_sdsl_file(tmp_path / "junk.sdsl")
+    with pytest.raises(V.VlgError):
+        V.index.read_sdsl_file(tmp_path / "dna.sdsl", dens=16)     # wrong density for this file

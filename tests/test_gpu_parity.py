@@ -510,3 +510,22 @@ def test_edge_cases_empty_inputs_and_long_queries(V, oracle):
     idx2, o2 = V.VlgIndex.build(t), oracle.Index.from_text(t)
     for q in [t.decode(), t.decode() + "x", "bim", "bimx", "m.{0,0}?x", "abra.{3,3}?abra", "a.{0,100000}?m", "a.{100000,200000}?m"]:
         assert idx2.search([q]).tuples(0).tolist() == o2.search(q).tolist(), q
+
+
+def test_load_index_stored_by_stock_sdsl(V, refmod, tmp_path):
+    """SURVEY 8f-2 end to end: reference-serialised csa_wt<wt_huff<>> file -> vlg_index_load_sdsl -> same answers."""
+    O = refmod
+    from util import bwt_from_sa
+    text = skewed_text(60000, 12).tobytes()
+    tz = np.frombuffer(text + b"\0", dtype=np.uint8)
+    sa = O.suffix_array(tz)
+    path = tmp_path / "idx.sdsl"
+    O.RefIndex(bwt_from_sa(tz, sa), sa, 0).write_csa_image(path, sa)
+    idx = V.VlgIndex.load_sdsl(path)
+    built = V.VlgIndex.build(text)
+    assert_parts_equal(idx.export_parts(), built.export_parts())
+    o = O.Index.from_text(text)
+    qs = random_queries(text, np.random.default_rng(2), 120, kmax=3, mmax=3)
+    res = idx.search(qs)
+    for i, q in enumerate(qs):
+        assert res.tuples(i).tolist() == o.search(q).tolist(), q

@@ -69,6 +69,25 @@ class SearchResult:
         return tup[toff[q]: toff[q + 1]].reshape(-1, max(k, 1)) if k else np.zeros((0, 0), np.uint64)
 
 
+def read_sdsl_file(path, dens=32):
+    """Host-only parse of a stock sdsl csa_wt<wt_huff<>> file -> parts dict (same keys as VlgIndex.export_parts())."""
+    f = C.c_void_p()
+    check(lib().vlg_sdsl_file_open(str(path).encode(), dens, C.byref(f)))
+    try:
+        p = capi.IndexParts()
+        check(lib().vlg_sdsl_file_parts(f, C.byref(p)))
+        nw = (p.bv_bits + 63) // 64
+        return {"n": int(p.n), "sigma": int(p.sigma), "dens": int(p.sa_sample_dens),
+                "char2comp": np.ctypeslib.as_array(C.cast(p.char2comp, C.POINTER(C.c_uint8)), shape=(256,)).copy(),
+                "C": np.ctypeslib.as_array(C.cast(p.C, C.POINTER(C.c_uint64)), shape=(p.sigma + 1,)).copy(),
+                "bv_bits": int(p.bv_bits),
+                "bv_words": np.ctypeslib.as_array(C.cast(p.bv_words, C.POINTER(C.c_uint64)), shape=(max(nw, 1),))[:nw].copy(),
+                "nodes": np.frombuffer(C.string_at(p.nodes, p.n_nodes * C.sizeof(capi.WtNode)), dtype=NODE_DTYPE).copy(),
+                "samples": np.ctypeslib.as_array(C.cast(p.sa_samples, C.POINTER(C.c_uint64)), shape=(max(p.n_samples, 1),))[: p.n_samples].copy()}
+    finally:
+        lib().vlg_sdsl_file_close(f)
+
+
 class Workspace:
     def __init__(self, max_hbm_bytes=0, stream=None):
         h = C.c_void_p()
@@ -197,6 +216,13 @@ class VlgIndex:
                                 smp.ctypes.data, len(smp))
         h = C.c_void_p()
         check(lib().vlg_index_from_parts(C.byref(parts), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load_sdsl(cls, path, dens=32):
+        """An index stored by stock sdsl (csa_wt<wt_huff<>> file)."""
+        h = C.c_void_p()
+        check(lib().vlg_index_load_sdsl(str(path).encode(), dens, C.byref(h)))
         return cls(h)
 
     @classmethod
