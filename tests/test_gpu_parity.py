@@ -529,3 +529,38 @@ def test_load_index_stored_by_stock_sdsl(V, refmod, tmp_path):
     res = idx.search(qs)
     for i, q in enumerate(qs):
         assert res.tuples(i).tolist() == o.search(q).tolist(), q
+
+
+def test_64bit_position_kernels(torch_cuda, V, oracle, monkeypatch):
+    """Texts beyond 4 GiB run on the pos_t = uint64_t instantiations (locate, expand, sort, join, gather, samples).
+    VLG_FORCE_POS64=1 selects them on a small text so that they are exercised bit for bit against the oracle."""
+    torch = torch_cuda
+    from vlg_matching_amd.index import Workspace
+    monkeypatch.setenv("VLG_FORCE_POS64", "1")
+    text = TEXTS["zipf40"]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    assert idx.info()["pos_bytes"] == 8
+    assert_parts_equal(idx.export_parts(), o.parts())
+    idx2 = V.VlgIndex.from_parts(o.parts())
+    assert idx2.info()["pos_bytes"] == 8
+    rng = np.random.default_rng(77)
+    qs = random_queries(text, rng, 250, kmax=5, mmax=4)
+    for lazy in (0, 1):
+        ws = Workspace()
+        ws.set_option("lazy_join", lazy)
+        res = idx.search(qs, workspace=ws)
+        occ = np.zeros(4, dtype=np.uint64)
+        for i, q in enumerate(qs):
+            assert res.tuples(i).tolist() == o.search(q, stats=occ).tolist(), (q, lazy)
+        assert res.summary["logical_occurrences"] == int(occ[0])
+    # csa[i] through the 64-bit locate kernel, and the rrr variant on top of it
+    L = V.lib()
+    ii = rng.integers(0, o.n, 20000).astype(np.uint64)
+    sa = oracle.suffix_array(np.frombuffer(text + b"\0", np.uint8))
+    for h in (idx, idx.compress()):
+        d_i = dev_u64(torch, ii)
+        d_o = torch.zeros_like(d_i)
+        V.capi.check(L.vlg_sa_batch(h._h, d_i.data_ptr(), d_o.data_ptr(), len(ii), None))
+        torch.cuda.synchronize()
+        assert (host_u64(d_o) == sa[ii.astype(np.int64)]).all()

@@ -1,6 +1,7 @@
 // Index objects in HBM: creation from reference-layout parts, export, blob replication, and the
 // on-device builder (suffix sort by prefix doubling -> BWT -> wavelet-tree super-blocks -> SA samples).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string.h>
 #include "common.hpp"
@@ -172,7 +173,10 @@ vlg_status alloc_blob(vlg_index* idx, uint64_t n, uint32_t dens, hipStream_t str
     h.n_nodes = t.n_nodes;
     h.max_code_len = t.max_code_len;
     h.n_samples = (n + dens - 1) / dens;
-    h.sample_bytes = (n <= 0x100000000ull) ? 4 : 8;
+    // positions inside kernels are 32-bit up to n = 2^32; VLG_FORCE_POS64=1 selects the 64-bit instantiations on any text
+    // (they are what a text beyond 4 GiB runs on; tests use the switch to exercise them on small inputs)
+    const char* f64 = getenv("VLG_FORCE_POS64");
+    h.sample_bytes = (n <= 0x100000000ull && !(f64 && f64[0] == '1')) ? 4 : 8;
     uint64_t off = align_up(sizeof(BlobHeader), 256);
     h.off_blocks = off;  off = align_up(off + h.n_blocks * sizeof(Block), 256);
     h.off_nodes = off;   off = align_up(off + (uint64_t)kMaxNodes * sizeof(DNode), 256);
