@@ -642,7 +642,7 @@ __global__ void sa_init_keys(const uint8_t* __restrict__ text, uint64_t n, uint6
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint64_t p = i + j;
-            uint64_t c = (p + 1 < n) ? text[p] : 0;      // position n-1 is the sentinel
+            uint64_t c = (p < n) ? text[p] : 0;          // the sentinel and everything behind it
             k = (k << 8) | c;
         }
         keys[i] = k;
@@ -650,14 +650,15 @@ __global__ void sa_init_keys(const uint8_t* __restrict__ text, uint64_t n, uint6
     }
 }
 
-// head[j] = j if sorted key j starts a new group else 0;  *n_groups += #group heads
+// head[j] = 1 if sorted key j starts a new group else 0;  *n_groups += #group heads.  The running sum of the flags minus one
+// is the dense rank of the group, which stays below 2^32 - 1 while any group still has two members.
 __global__ void sa_group_heads(const uint64_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ head,
                                unsigned long long* __restrict__ n_groups)
 {
     unsigned long long local = 0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
         bool h = (j == 0) || keys[j] != keys[j - 1];
-        head[j] = h ? (uint32_t)j : 0u;
+        head[j] = h ? 1u : 0u;
         local += h;
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
@@ -668,17 +669,19 @@ __global__ void sa_scatter_rank(const uint32_t* __restrict__ sa, const uint32_t*
                                 uint32_t* __restrict__ rank_of)
 {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
-        rank_of[sa[j]] = head[j];
+        rank_of[sa[j]] = head[j] - 1u;          // head[] holds the inclusive running count of group heads
 }
 
+// Second key: rank of the suffix h further on, +1, or 0 when that is the sentinel suffix or beyond.  Ranks are dense
+// group numbers, at most n_groups - 1 <= ns - 2 while the loop runs, so both halves of the key fit 32 bits up to ns = 2^32.
 __global__ void sa_next_keys(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ rank_of, uint64_t n, uint64_t h,
-                             uint32_t shift, uint64_t* __restrict__ keys)
+                             uint64_t* __restrict__ keys)
 {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t s = sa[j];
         uint64_t r1 = rank_of[s];
         uint64_t r2 = (s + h < n) ? (uint64_t)rank_of[s + h] + 1 : 0;
-        keys[j] = (r1 << shift) | r2;
+        keys[j] = (r1 << 32) | r2;
     }
 }
 
@@ -690,8 +693,10 @@ __global__ void bwt_kernel(const uint8_t* __restrict__ text, const uint32_t* __r
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) h[i] = 0;
     __syncthreads();
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t s = sa[j];
-        uint8_t c = s ? text[s - 1] : 0;
+        // SA[0] = n-1 (the sentinel suffix), SA[j] = sa[j-1] otherwise
+        uint8_t c;
+        if (j == 0) c = n > 1 ? text[n - 2] : 0;
+        else { uint32_t s = sa[j - 1]; c = s ? text[s - 1] : 0; }
         bwt[j] = c;
         atomicAdd(&h[c], 1u);
     }
@@ -700,12 +705,12 @@ __global__ void bwt_kernel(const uint8_t* __restrict__ text, const uint32_t* __r
         if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
-__global__ void sample_kernel(const uint32_t* __restrict__ sa, uint64_t n_samples, uint32_t dens, void* __restrict__ out,
+__global__ void sample_kernel(const uint32_t* __restrict__ sa, uint64_t n_text, uint64_t n_samples, uint32_t dens, void* __restrict__ out,
                               uint32_t sample_bytes)
 {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_samples; j += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t v = sa[j * dens];                          // csa_sampling_strategy.hpp:92-98
-        if (sample_bytes == 4) reinterpret_cast<uint32_t*>(out)[j] = v;
+        uint64_t v = j ? (uint64_t)sa[j * dens - 1] : n_text;   // csa_sampling_strategy.hpp:92-98; SA[0] = n-1
+        if (sample_bytes == 4) reinterpret_cast<uint32_t*>(out)[j] = (uint32_t)v;
         else reinterpret_cast<uint64_t*>(out)[j] = v;
     }
 }
@@ -777,17 +782,20 @@ inline uint32_t grid_for(uint64_t n) { return (uint32_t)std::min<uint64_t>((n + 
 vlg_status build_on_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens, hipStream_t stream, vlg_index** out)
 {
     const uint64_t n = n_text + 1;
-    if (n > 0xFFFFFFF0ull) return fail(VLG_E_UNSUPPORTED, "device builder handles texts shorter than 2^32-16 bytes in this version");
+    // The sentinel suffix is the smallest one by definition (SA[0] = n-1), so only the n_text proper suffixes are sorted:
+    // their ids and ranks fit 32 bits for texts up to 2^32 bytes (BASELINE config 4).
+    const uint64_t ns = n_text;
+    if (n_text > 0x100000000ull) return fail(VLG_E_UNSUPPORTED, "device builder handles texts of up to 2^32 bytes");
     vlg_index* idx = new vlg_index();
     auto run = [&]() -> vlg_status {
         DevBuf keys_a, keys_b, sa_a, sa_b, rank_of, head, temp, counter, bwt;
         size_t temp_cap = 0;
-        VLG_HIP_TRY(keys_a.alloc(n * 8));
-        VLG_HIP_TRY(keys_b.alloc(n * 8));
-        VLG_HIP_TRY(sa_a.alloc(n * 4));
-        VLG_HIP_TRY(sa_b.alloc(n * 4));
-        VLG_HIP_TRY(rank_of.alloc(n * 4));
-        VLG_HIP_TRY(head.alloc(n * 4));
+        VLG_HIP_TRY(keys_a.alloc(ns * 8));
+        VLG_HIP_TRY(keys_b.alloc(ns * 8));
+        VLG_HIP_TRY(sa_a.alloc(ns * 4));
+        VLG_HIP_TRY(sa_b.alloc(ns * 4));
+        VLG_HIP_TRY(rank_of.alloc(ns * 4));
+        VLG_HIP_TRY(head.alloc(ns * 4));
         VLG_HIP_TRY(counter.alloc(8 + 256 * 8));
         unsigned long long* d_groups = counter.as<unsigned long long>();
         unsigned long long* d_hist = d_groups + 1;
@@ -801,33 +809,34 @@ vlg_status build_on_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens
             if (zeros) return fail(VLG_E_ZERO_BYTE, "text contains a zero byte (sdsl::construct throws std::logic_error)");
         }
         // --- suffix array by prefix doubling (8 characters first, then h = 8, 16, ...) ------------
-        hipLaunchKernelGGL(sa_init_keys, dim3(g), dim3(256), 0, stream, d_text, n, keys_a.as<uint64_t>(), sa_a.as<uint32_t>());
-        VLG_HIP_TRY(hipGetLastError());
-        if (vlg_status st = sort_pairs(temp, temp_cap, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), sa_a.as<uint32_t>(),
-                                       sa_b.as<uint32_t>(), n, 0, 64, stream)) return st;
-        uint64_t* keys_sorted = keys_b.as<uint64_t>();
-        uint64_t* keys_other = keys_a.as<uint64_t>();
         uint32_t* sa_cur = sa_b.as<uint32_t>();
-        uint32_t* sa_other = sa_a.as<uint32_t>();
-        const uint32_t shift = bit_width64(n);            // r2 <= n needs bit_width(n) bits
-        for (uint64_t h = 8;; h <<= 1) {
-            VLG_HIP_TRY(hipMemsetAsync(d_groups, 0, 8, stream));
-            hipLaunchKernelGGL(sa_group_heads, dim3(g), dim3(256), 0, stream, keys_sorted, n, head.as<uint32_t>(), d_groups);
+        if (ns) {
+            hipLaunchKernelGGL(sa_init_keys, dim3(g), dim3(256), 0, stream, d_text, ns, keys_a.as<uint64_t>(), sa_a.as<uint32_t>());
             VLG_HIP_TRY(hipGetLastError());
-            unsigned long long groups = 0;
-            VLG_HIP_TRY(hipMemcpyAsync(&groups, d_groups, 8, hipMemcpyDeviceToHost, stream));
-            VLG_HIP_TRY(hipStreamSynchronize(stream));
-            if (groups == n) break;
-            if (h > 2 * n) return fail(VLG_E_INTERNAL, "suffix sort did not converge");
-            size_t tb = 0;
-            VLG_HIP_TRY(rocprim::inclusive_scan(nullptr, tb, head.as<uint32_t>(), head.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), stream));
-            if (tb > temp_cap) { if (temp.p) { (void)hipFree(temp.p); temp.p = nullptr; } VLG_HIP_TRY(temp.alloc(tb)); temp_cap = tb; }
-            VLG_HIP_TRY(rocprim::inclusive_scan(temp.p, tb, head.as<uint32_t>(), head.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), stream));
-            hipLaunchKernelGGL(sa_scatter_rank, dim3(g), dim3(256), 0, stream, sa_cur, head.as<uint32_t>(), n, rank_of.as<uint32_t>());
-            hipLaunchKernelGGL(sa_next_keys, dim3(g), dim3(256), 0, stream, sa_cur, rank_of.as<uint32_t>(), n, h, shift, keys_other);
-            VLG_HIP_TRY(hipGetLastError());
-            if (vlg_status st = sort_pairs(temp, temp_cap, keys_other, keys_sorted, sa_cur, sa_other, n, 0, 2 * shift, stream)) return st;
-            std::swap(sa_cur, sa_other);                   // keys_sorted now holds the sorted keys again
+            if (vlg_status st = sort_pairs(temp, temp_cap, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), sa_a.as<uint32_t>(),
+                                           sa_b.as<uint32_t>(), ns, 0, 64, stream)) return st;
+            uint64_t* keys_sorted = keys_b.as<uint64_t>();
+            uint64_t* keys_other = keys_a.as<uint64_t>();
+            uint32_t* sa_other = sa_a.as<uint32_t>();
+            for (uint64_t h = 8;; h <<= 1) {
+                VLG_HIP_TRY(hipMemsetAsync(d_groups, 0, 8, stream));
+                hipLaunchKernelGGL(sa_group_heads, dim3(g), dim3(256), 0, stream, keys_sorted, ns, head.as<uint32_t>(), d_groups);
+                VLG_HIP_TRY(hipGetLastError());
+                unsigned long long groups = 0;
+                VLG_HIP_TRY(hipMemcpyAsync(&groups, d_groups, 8, hipMemcpyDeviceToHost, stream));
+                VLG_HIP_TRY(hipStreamSynchronize(stream));
+                if (groups == ns) break;
+                if (h > 2 * n) return fail(VLG_E_INTERNAL, "suffix sort did not converge");
+                size_t tb = 0;
+                VLG_HIP_TRY(rocprim::inclusive_scan(nullptr, tb, head.as<uint32_t>(), head.as<uint32_t>(), ns, rocprim::plus<uint32_t>(), stream));
+                if (tb > temp_cap) { if (temp.p) { (void)hipFree(temp.p); temp.p = nullptr; } VLG_HIP_TRY(temp.alloc(tb)); temp_cap = tb; }
+                VLG_HIP_TRY(rocprim::inclusive_scan(temp.p, tb, head.as<uint32_t>(), head.as<uint32_t>(), ns, rocprim::plus<uint32_t>(), stream));
+                hipLaunchKernelGGL(sa_scatter_rank, dim3(g), dim3(256), 0, stream, sa_cur, head.as<uint32_t>(), ns, rank_of.as<uint32_t>());
+                hipLaunchKernelGGL(sa_next_keys, dim3(g), dim3(256), 0, stream, sa_cur, rank_of.as<uint32_t>(), ns, h, keys_other);
+                VLG_HIP_TRY(hipGetLastError());
+                if (vlg_status st = sort_pairs(temp, temp_cap, keys_other, keys_sorted, sa_cur, sa_other, ns, 0, 64, stream)) return st;
+                std::swap(sa_cur, sa_other);                   // keys_sorted now holds the sorted keys again
+            }
         }
         // free the big sort buffers we no longer need
         (void)hipFree(keys_a.p); keys_a.p = nullptr;
@@ -848,7 +857,7 @@ vlg_status build_on_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens
         const BlobHeader& hd = idx->hdr;
         uint8_t* blob = reinterpret_cast<uint8_t*>(idx->d_blob);
         // --- SA samples ----------------------------------------------------------------------------
-        hipLaunchKernelGGL(sample_kernel, dim3(grid_for(hd.n_samples)), dim3(256), 0, stream, sa_cur, hd.n_samples, dens,
+        hipLaunchKernelGGL(sample_kernel, dim3(grid_for(hd.n_samples)), dim3(256), 0, stream, sa_cur, n_text, hd.n_samples, dens,
                            blob + hd.off_samples, hd.sample_bytes);
         VLG_HIP_TRY(hipGetLastError());
         VLG_HIP_TRY(hipStreamSynchronize(stream));

@@ -16,11 +16,20 @@ static inline uint64_t splitmix64(uint64_t* s)
 /* iid symbols: symbol j is drawn when the 32 high bits of the stream fall below cum[j] (cum[nsym-1] = 2^32). */
 void vlgw_gen_iid(uint8_t* out, uint64_t n, uint64_t seed, const uint8_t* alphabet, const uint64_t* cum, uint32_t nsym)
 {
+    /* table on the top 16 bits of the draw: the symbol when the whole bucket maps to one symbol, 0xFF otherwise */
+    static uint8_t table[65536];
+    for (uint32_t b = 0; b < 65536; ++b) {
+        uint64_t lo = (uint64_t)b << 16, hi = lo + 0xFFFF;
+        uint32_t jl = 0, jh = 0;
+        while (jl + 1 < nsym && lo >= cum[jl]) ++jl;
+        while (jh + 1 < nsym && hi >= cum[jh]) ++jh;
+        table[b] = (jl == jh) ? (uint8_t)jl : 0xFF;
+    }
     uint64_t s = seed;
     for (uint64_t i = 0; i < n; ++i) {
         uint64_t u = splitmix64(&s) >> 32;
-        uint32_t j = 0;
-        while (j + 1 < nsym && u >= cum[j]) ++j;
+        uint32_t j = table[u >> 16];
+        if (j == 0xFF) { j = 0; while (j + 1 < nsym && u >= cum[j]) ++j; }
         out[i] = alphabet[j];
     }
 }
