@@ -25,3 +25,16 @@ def refmod(oracle):
     if oracle.ref() is None:
         pytest.skip("oracle/_ref/libvlgref.so not built (needs /root/reference)")
     return oracle
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_initialises_the_gpu_first():
+    """torch.cuda.is_available() must be asked before any other library in the process has brought the HIP runtime up
+    (asked afterwards it can report False on this image), so do it once at session start."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+    yield

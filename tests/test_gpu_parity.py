@@ -546,14 +546,18 @@ def test_64bit_position_kernels(torch_cuda, V, oracle, monkeypatch):
     assert idx2.info()["pos_bytes"] == 8
     rng = np.random.default_rng(77)
     qs = random_queries(text, rng, 250, kmax=5, mmax=4)
-    for lazy in (0, 1):
+    for lazy, sweep_min in ((0, 1 << 22), (1, 1 << 22), (0, 1)):            # dense / lazy join; random-access / sorted-sweep locate
         ws = Workspace()
         ws.set_option("lazy_join", lazy)
+        ws.set_option("sweep_min", sweep_min)
+        ws.set_option("sweep_tail", 64)
+        ws.set_option("dedup", 0)
         res = idx.search(qs, workspace=ws)
         occ = np.zeros(4, dtype=np.uint64)
         for i, q in enumerate(qs):
-            assert res.tuples(i).tolist() == o.search(q, stats=occ).tolist(), (q, lazy)
-        assert res.summary["logical_occurrences"] == int(occ[0])
+            assert res.tuples(i).tolist() == o.search(q, stats=occ).tolist(), (q, lazy, sweep_min)
+        assert res.summary["logical_occurrences"] == int(occ[0]) == res.summary["located_occurrences"]
+        assert res.summary["lf_steps"] == int(occ[1]) and res.summary["wt_levels_locate"] == int(occ[2])
     # csa[i] through the 64-bit locate kernel, and the rrr variant on top of it
     L = V.lib()
     ii = rng.integers(0, o.n, 20000).astype(np.uint64)

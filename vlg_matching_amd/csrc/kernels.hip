@@ -531,11 +531,14 @@ __global__ void expand_kernel(const uint64_t* __restrict__ l, const uint64_t* __
 // An element leaves the sweep when it reaches a sampled SA index (csa_sampling_strategy.hpp:102-111).
 // val = slot << 32 | position;  key = comp of the symbol read, or sigma for "finished".
 // =============================================================================================
-__global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t total,
+// val = slot << kShift | position: 32 + 32 bits for n <= 2^32, 31 + 33 bits beyond (then a sweep covers at most 2^31 occurrences
+// [t0, t1) at a time and slots are relative to t0).
+template <uint32_t kShift>
+__global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t t0, uint64_t total,
                                   uint64_t* __restrict__ val)
 {
     __shared__ uint64_t s_first;
-    for (uint64_t base = (uint64_t)blockIdx.x * 256; base < total; base += (uint64_t)gridDim.x * 256) {
+    for (uint64_t base = t0 + (uint64_t)blockIdx.x * 256; base < total; base += (uint64_t)gridDim.x * 256) {
         if (threadIdx.x == 0) {
             uint64_t lo = 0, hi = n_pat;
             while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (out_off[mid] <= base) lo = mid; else hi = mid; }
@@ -546,15 +549,15 @@ __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t
         if (t < total) {
             uint64_t p = s_first;
             while (out_off[p + 1] <= t) ++p;
-            val[t] = (t << 32) | (uint32_t)(l[p] + (t - out_off[p]));
+            val[t - t0] = ((t - t0) << kShift) | (l[p] + (t - out_off[p]));
         }
         __syncthreads();
     }
 }
 
-template <class BV>
+template <class BV, typename pos_t>
 __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count,
-                                                         uint32_t step, uint32_t* __restrict__ out,
+                                                         uint32_t step, pos_t* __restrict__ out,
                                                          unsigned long long* __restrict__ stats /* lf, levels */,
                                                          unsigned long long* __restrict__ n_done)
 {
@@ -564,17 +567,19 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
     const bool pow2 = (dens & (dens - 1)) == 0;
     const uint32_t dmask = dens - 1;
     const uint32_t dshift = 31 - __clz(dens);
-    const uint32_t* samples = reinterpret_cast<const uint32_t*>(iv.samples);
+    const pos_t* samples = reinterpret_cast<const pos_t*>(iv.samples);
+    constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
+    constexpr uint64_t kPosMask = (1ull << kShift) - 1;
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t v64 = val[e];
-        uint32_t i = (uint32_t)v64;
+        uint64_t i = v64 & kPosMask;
         bool sampled = pow2 ? ((i & dmask) == 0) : (i % dens == 0);
         if (sampled) {
-            uint32_t q = pow2 ? (i >> dshift) : (i / dens);
+            uint64_t q = pow2 ? (i >> dshift) : (i / dens);
             uint64_t r = (uint64_t)samples[q] + step;
             if (r >= iv.n) r -= iv.n;                        // csa_wt.hpp:343-347
-            out[(uint32_t)(v64 >> 32)] = (uint32_t)r;
+            out[v64 >> kShift] = (pos_t)r;
             key[e] = (uint16_t)iv.sigma;
             ++n_fin;
         } else {
@@ -592,7 +597,7 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
                 v = ch;
             }
             ++n_lf;
-            val[e] = (v64 & 0xFFFFFFFF00000000ull) | (uint32_t)(s.C[c] + pos);    // LF: suffix_array_helper.hpp:341-348
+            val[e] = (v64 & ~kPosMask) | (s.C[c] + pos);                          // LF: suffix_array_helper.hpp:341-348
             key[e] = (uint16_t)c;
         }
     }
@@ -606,18 +611,20 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
 }
 
 // stragglers: finish the few elements still alive after the sweep, one lane each
-template <class BV>
+template <class BV, typename pos_t>
 __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uint64_t* __restrict__ val, uint64_t count, uint32_t step,
-                                                         uint32_t* __restrict__ out, unsigned long long* __restrict__ stats)
+                                                         pos_t* __restrict__ out, unsigned long long* __restrict__ stats)
 {
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
     const uint32_t dens = iv.dens;
-    const uint32_t* samples = reinterpret_cast<const uint32_t*>(iv.samples);
+    const pos_t* samples = reinterpret_cast<const pos_t*>(iv.samples);
+    constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
+    constexpr uint64_t kPosMask = (1ull << kShift) - 1;
     uint32_t n_lv = 0, n_lf = 0;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t v64 = val[e];
-        uint64_t i = (uint32_t)v64;
+        uint64_t i = v64 & kPosMask;
         uint64_t off = step;
         while (i % dens) {
             uint32_t v = 0;
@@ -637,7 +644,7 @@ __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uin
         }
         uint64_t r = (uint64_t)samples[i / dens] + off;
         if (r >= iv.n) r -= iv.n;
-        out[(uint32_t)(v64 >> 32)] = (uint32_t)r;
+        out[v64 >> kShift] = (pos_t)r;
     }
     unsigned long long a = n_lf, b = n_lv;
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
@@ -722,58 +729,71 @@ size_t sweep_temp_bytes(uint64_t total, uint32_t sigma, hipStream_t stream)
 }
 
 // d_l / d_out_off: SA interval starts and output offsets of the n_pat lists; d_out receives SA values (unsorted, SA order).
-// Scratch (caller-provided): val_a, val_b (total u64 each), key_a, key_b (total u16 each), temp (sweep_temp_bytes), counter (8 B, zeroed here).
+// Scratch (caller-provided): val_a, val_b (u64 each), key_a, key_b (u16 each) for min(total, sweep_batch_max<pos_t>()) elements,
+// temp (sweep_temp_bytes), counter (8 B, zeroed here).
+template <typename pos_t>
 vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
-                               uint32_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
+                               pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
                                hipStream_t stream, LaunchTimer* timer)
 {
-    if (!total) return VLG_OK;
-    hipLaunchKernelGGL(sweep_init_kernel, dim3(grid_for(total, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat, total, val_a);
-    VLG_HIP_TRY(hipGetLastError());
+    constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
+    if (iv.n > (1ull << kShift)) return fail(VLG_E_UNSUPPORTED, "sorted sweep: text too long for the packed position");
     const unsigned bits = bit_width64(iv.sigma);            // keys 0..sigma (sigma = finished, sorts last)
-    uint64_t alive = total;
-    uint32_t step = 0;
-    unsigned long long scratch_stats[2];
-    (void)scratch_stats;
-    while (alive > tail_threshold) {
-        VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
-        if (timer) timer->begin(0);
-        if (iv.bv_kind == kBvRrr63)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, key_a, alive,
-                               step, d_out, d_stats, d_counter);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, key_a,
-                               alive, step, d_out, d_stats, d_counter);
-        if (timer) timer->end(0);
+    const uint64_t batch_max = sweep_batch_max<pos_t>();
+    for (uint64_t t0 = 0; t0 < total; t0 += batch_max) {
+        const uint64_t t1 = std::min(total, t0 + batch_max);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for(t1 - t0, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
+                           t0, t1, val_a);
         VLG_HIP_TRY(hipGetLastError());
-        size_t tb = temp_bytes;
-        if (timer) timer->begin(1);
-        hipError_t se = rocprim::radix_sort_pairs(temp, tb, key_a, key_b, val_a, val_b, alive, 0, bits, stream);
-        if (timer) timer->end(1);
-        VLG_HIP_TRY(se);
-        unsigned long long done = 0;
-        VLG_HIP_TRY(hipMemcpyAsync(&done, d_counter, 8, hipMemcpyDeviceToHost, stream));
-        VLG_HIP_TRY(hipStreamSynchronize(stream));
-        std::swap(val_a, val_b);
-        std::swap(key_a, key_b);
-        alive -= done;
-        ++step;
-        if (step > 1u << 20) return fail(VLG_E_INTERNAL, "locate sweep did not converge");
-    }
-    if (alive) {
-        if (timer) timer->begin(0);
-        if (iv.bv_kind == kBvRrr63)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<RrrBV>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, alive, step,
-                               d_out, d_stats);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<PlainBV>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, alive, step,
-                               d_out, d_stats);
-        if (timer) timer->end(0);
-        VLG_HIP_TRY(hipGetLastError());
+        uint64_t alive = t1 - t0;
+        uint32_t step = 0;
+        pos_t* out = d_out + t0;
+        while (alive > tail_threshold) {
+            VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
+            if (timer) timer->begin(0);
+            if (iv.bv_kind == kBvRrr63)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, key_a,
+                                   alive, step, out, d_stats, d_counter);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a,
+                                   key_a, alive, step, out, d_stats, d_counter);
+            if (timer) timer->end(0);
+            VLG_HIP_TRY(hipGetLastError());
+            size_t tb = temp_bytes;
+            if (timer) timer->begin(1);
+            hipError_t se = rocprim::radix_sort_pairs(temp, tb, key_a, key_b, val_a, val_b, alive, 0, bits, stream);
+            if (timer) timer->end(1);
+            VLG_HIP_TRY(se);
+            unsigned long long done = 0;
+            VLG_HIP_TRY(hipMemcpyAsync(&done, d_counter, 8, hipMemcpyDeviceToHost, stream));
+            VLG_HIP_TRY(hipStreamSynchronize(stream));
+            std::swap(val_a, val_b);
+            std::swap(key_a, key_b);
+            alive -= done;
+            ++step;
+            if (step > 1u << 20) return fail(VLG_E_INTERNAL, "locate sweep did not converge");
+        }
+        if (alive) {
+            if (timer) timer->begin(0);
+            if (iv.bv_kind == kBvRrr63)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<RrrBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, alive,
+                                   step, out, d_stats);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<PlainBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a,
+                                   alive, step, out, d_stats);
+            if (timer) timer->end(0);
+            VLG_HIP_TRY(hipGetLastError());
+        }
     }
     return VLG_OK;
 }
+template vlg_status launch_locate_sweep<uint32_t>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint32_t*, uint64_t*,
+                                                  uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, uint64_t,
+                                                  hipStream_t, LaunchTimer*);
+template vlg_status launch_locate_sweep<uint64_t>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint64_t*, uint64_t*,
+                                                  uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, uint64_t,
+                                                  hipStream_t, LaunchTimer*);
 
 }  // namespace vlg
 

@@ -20,8 +20,11 @@ struct LaunchTimer {
 };
 
 size_t sweep_temp_bytes(uint64_t total, uint32_t sigma, hipStream_t stream);
+// occurrences one sweep can cover: slots share a 64-bit word with the position (32+32 bits, or 31+33 for n > 2^32)
+template <typename pos_t> constexpr uint64_t sweep_batch_max() { return sizeof(pos_t) == 4 ? 0xFFFFFF00ull : (1ull << 31); }
+template <typename pos_t>
 vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
-                               uint32_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
+                               pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
                                hipStream_t stream, LaunchTimer* timer);
 

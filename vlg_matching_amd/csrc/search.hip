@@ -931,7 +931,7 @@ struct Plan {                       // host view of the batch after backward sea
     std::vector<uint64_t> dl, docc; // per distinct interval: left border, size
 };
 
-template <typename pos_t> constexpr uint64_t kPhysScratchPerElem() { return sizeof(pos_t) == 4 ? 20 : sizeof(pos_t); }
+template <typename pos_t> constexpr uint64_t kPhysScratchPerElem() { return 20; }   // sweep scratch; the sorted lists reuse it
 constexpr uint64_t kJoinBytesPerSlot = 4 + 8 + 1;      // link, endp(<=8), feasibility bits + summaries (any slot)
 constexpr uint64_t kJoinBytesPerSlot0 = 4 + 4 + 8 + 1; // jump, mlist, (exit,hops), chain records (slots of list 0)
 
@@ -956,7 +956,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     P_out = nullptr;
     if (!acc) return VLG_OK;
     const unsigned bits = bit_width64(idx->hdr.n);
-    const bool use_sweep = ws->sweep && sizeof(pos_t) == 4 && acc >= ws->sweep_min;
+    const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (sizeof(pos_t) == 4 ? 32 : 33));
     pos_t* Pa = A.take<pos_t>(acc);
     // scratch of the sweep (20 B per element); the sorted lists Pb reuse it once locate is done
     uint8_t* scratch = A.take<uint8_t>(acc * kPhysScratchPerElem<pos_t>());
@@ -971,12 +971,13 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     VLG_HIP_TRY(hipMemcpyAsync(d_off32, off32.data(), (nd + 1) * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_lh, lh.data(), nd * 8, hipMemcpyHostToDevice, st));
     if (use_sweep) {
+        const uint64_t cap = std::min<uint64_t>(acc, sweep_batch_max<pos_t>());
         uint64_t* val_a = reinterpret_cast<uint64_t*>(scratch);
-        uint64_t* val_b = val_a + acc;
-        uint16_t* key_a = reinterpret_cast<uint16_t*>(val_b + acc);
-        uint16_t* key_b = key_a + acc;
+        uint64_t* val_b = val_a + cap;
+        uint16_t* key_a = reinterpret_cast<uint16_t*>(val_b + cap);
+        uint16_t* key_b = key_a + cap;
         SweepTimer timer(ws);
-        if (vlg_status s = launch_locate_sweep(idx->view, d_lh, d_off64, nd, acc, reinterpret_cast<uint32_t*>(Pa), val_a, val_b, key_a, key_b,
+        if (vlg_status s = launch_locate_sweep<pos_t>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b,
                                                d_tmp, sort_tmp, d_counter, d_stats, ws->sweep_tail, st, &timer)) return s;
     } else {
         {
@@ -1603,7 +1604,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             pos_t* np = nullptr; uint32_t* nu = nullptr;
             VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, np, np, (unsigned)phys, (unsigned)dlist.size(), nu, nu, 0,
                                                            bit_width64(idx->hdr.n), ws->stream));
-            if (ws->sweep && sizeof(pos_t) == 4 && phys >= ws->sweep_min)
+            if (ws->sweep && phys >= ws->sweep_min)
                 sort_tmp = std::max(sort_tmp, sweep_temp_bytes(phys, idx->hdr.sigma, ws->stream));
         }
         const uint64_t phys_bytes = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20);
