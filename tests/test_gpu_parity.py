@@ -390,6 +390,42 @@ def test_lazy_join_equals_dense_join_and_oracle(V, oracle, name, seed, kmax):
         assert b.tuples(i).tolist() == o.search(qs[i]).tolist(), qs[i]
 
 
+@pytest.mark.parametrize("pivot", [1, 0])
+@pytest.mark.parametrize("name,seed,kmax,gapmax,cap_mb", [("dna_50k", 61, 3, 300, 0), ("dna_skew", 62, 6, 40, 0), ("zipf40", 63, 4, 2000, 0),
+                                                         ("100a", 64, 3, 5, 0), ("dna_50k", 65, 8, 600, 0), ("dna_50k", 66, 3, 300, 40)])
+def test_window_filter_equals_unfiltered_join_and_oracle(V, oracle, name, seed, kmax, gapmax, cap_mb, pivot):
+    """Dropping the list elements whose gap windows are empty (streaming sweeps over block bitmaps, or outwards from the
+    shortest list of the query) changes no match."""
+    from vlg_matching_amd.index import Workspace
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    rng = np.random.default_rng(seed)
+    qs = random_queries(text, rng, 250, kmax=kmax, mmax=3, gapmax=gapmax, gaplo=8)
+    qs += random_queries(text, rng, 60, kmax=2, mmax=1, gapmax=3, gaplo=2)
+    qs += ["\xfe.{0,5}?" + qs[0][:1], qs[1][:1] + ".{0,5}?\xfe", qs[2][:1]]
+    ws_n = Workspace()
+    ws_f = Workspace(max_hbm_bytes=(cap_mb << 20)) if cap_mb else Workspace()
+    ws_n.set_option("filter", 0)
+    ws_f.set_option("filter_min", 0)
+    ws_f.set_option("filter_pivot", pivot)
+    a, b = idx.search(qs, workspace=ws_n), idx.search(qs, workspace=ws_f)
+    assert "join_filter" not in [k for k, v in ws_n.kernel_stats().items() if v["launches"]]
+    assert ws_f.kernel_stats()["join_filter"]["launches"] > 0
+    for k in ("n_matches", "checksum", "n_tuple_values", "logical_occurrences", "located_occurrences"):
+        assert a.summary[k] == b.summary[k], k
+    for x, y in zip(a.fetch(), b.fetch()):
+        assert (x == y).all()
+    for i in list(range(0, len(qs), 5)) + [len(qs) - 3, len(qs) - 2, len(qs) - 1]:
+        assert b.tuples(i).tolist() == o.search(qs[i]).tolist(), qs[i]
+    for dialect in (V.capi.DIALECT_BENCHMARK,):
+        bq = [x.replace("?", "") for x in qs[:120]]
+        ra = idx.search(bq, dialect=dialect, strict=False, workspace=ws_n)
+        rb = idx.search(bq, dialect=dialect, strict=False, workspace=ws_f)
+        for x, y in zip(ra.fetch(), rb.fetch()):
+            assert (x == y).all()
+
+
 def test_join_many_tiles_single_pattern(V, oracle):
     """k = 1 and k = 2 on a list spanning many tiles (non-overlap chains cross tile borders all the time)."""
     text = (b"ab" * 30000) + dna_text(5000, 3).tobytes() + (b"aab" * 9000)

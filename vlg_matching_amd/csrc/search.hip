@@ -245,8 +245,8 @@ extern "C" void vlg_queries_destroy(vlg_queries* q)
 // =============================================================================================
 // Workspace
 // =============================================================================================
-enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_LOCATE_PART, KS_SORT, KS_JOIN_INIT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_COUNT };
-static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "locate_partition", "sort", "join_init", "join_link", "join_scan", "join_chain", "gather"};
+enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_LOCATE_PART, KS_SORT, KS_JOIN_FILTER, KS_JOIN_INIT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_COUNT };
+static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "locate_partition", "sort", "join_filter", "join_init", "join_link", "join_scan", "join_chain", "gather"};
 
 struct vlg_workspace {
     hipStream_t stream = nullptr;
@@ -260,6 +260,9 @@ struct vlg_workspace {
                                 // Measured on C3 (dense lists): spec 1.5 s + stitch 18.5 s per step vs 1.6 s for the dense passes --
                                 // chains that enter a tile out of phase with the speculated one never merge when almost every
                                 // element is feasible, so the stitch pass degenerates to a serial walk.  Kept for sparse batches.
+    bool filter = true;         // window filter: drop the list elements that can be in no match before the join
+    uint64_t filter_min = 1ull << 16;   // queries with fewer join slots are joined as they are
+    bool filter_pivot = true;   // filter from the shortest list of a query outwards when it is much shorter than the rest
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
     uint64_t sweep_tail = 1ull << 20;   // stragglers of a sweep are finished one lane each
     vlg_kernel_stat stats[KS_COUNT];
@@ -377,6 +380,9 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "sweep")) { ws->sweep = value != 0; return VLG_OK; }
     if (!strcmp(name, "lazy_join")) { ws->lazy_join = value != 0; return VLG_OK; }
     if (!strcmp(name, "sweep_min")) { ws->sweep_min = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "filter")) { ws->filter = value != 0; return VLG_OK; }
+    if (!strcmp(name, "filter_min")) { ws->filter_min = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "filter_pivot")) { ws->filter_pivot = value != 0; return VLG_OK; }
     if (!strcmp(name, "sweep_tail")) { ws->sweep_tail = (uint64_t)value; return VLG_OK; }
     return fail(VLG_E_INVALID, std::string("unknown workspace option ") + name);
 }
@@ -535,6 +541,143 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P
     }
     if (need) res = gallop_lower_bound(P, wb < b ? wb : b, b, key);
     return res < b ? res : b;
+}
+
+// ---- wave-private list tiles -----------------------------------------------------------------------------------
+// A wave that needs the lower bounds of many keys in one sorted list stages the list in LDS, kTB elements at a time
+// (coalesced loads that do not depend on any answer), and every lane searches its kKeys keys there: log2(kTB) LDS probes
+// per key, several independent searches per lane in flight, no dependent global round trip per key.
+constexpr uint32_t kKeys = 8;                 // keys per lane and block
+constexpr uint32_t kBlk = 64 * kKeys;         // slots per block
+constexpr uint32_t kTB = 1024;                // list elements per tile
+constexpr uint32_t kKeyGroup = 4;             // searches interleaved per lane
+constexpr uint32_t kMinPiece = 128;           // shorter pieces of a segment take the per-lane path
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_min(T v)
+{
+    for (int o = 32; o > 0; o >>= 1) { const T u = __shfl_xor(v, o); v = u < v ? u : v; }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(v, o); v = u > v ? u : v; }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uniform(uint64_t v)
+{
+    return (uint64_t)uniform((uint32_t)v) | ((uint64_t)uniform((uint32_t)(v >> 32)) << 32);
+}
+
+// Lower bound of one wave-uniform key in P[a,b): 64 probes per round narrow the range 64-fold.
+template <typename pos_t>
+__device__ __forceinline__ uint32_t wave_kary_lower_bound(const pos_t* __restrict__ P, uint32_t a, uint32_t b, uint64_t key)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    while (b - a > 64) {
+        const uint32_t step = (b - a + 63) / 64;
+        const uint64_t idx = (uint64_t)a + (uint64_t)(lane + 1) * step - 1;
+        const bool in = idx < b;
+        const uint64_t v = in ? (uint64_t)P[idx] : 0;
+        const uint32_t c = (uint32_t)__popcll(__ballot(in && v < key));          // probes 0..c-1 are smaller than the key
+        const uint64_t na = (uint64_t)a + (uint64_t)c * step;                    // <= b
+        const uint64_t nb = (uint64_t)a + (uint64_t)(c + 1) * step - 1;          // probe c (if it exists) is not smaller
+        a = (uint32_t)na;
+        b = nb < b ? (uint32_t)nb : b;
+    }
+    const uint32_t idx = a + lane;
+    const bool in = idx < b;
+    const uint64_t v = in ? (uint64_t)P[idx] : 0;
+    return a + (uint32_t)__popcll(__ballot(in && v < key));
+}
+
+// Lower bounds in P[.,pend) of the keys flagged in `need` (bit i = key[i]).  `wb` is a wave-uniform fence: every element
+// before it is smaller than every flagged key of the wave.  j[i] = the lower bound (pend if there is none), v[i] = P[j[i]].
+// The keys of the wave need not be ordered; tiles that cannot hold an answer are skipped with one probe.
+template <typename pos_t>
+__device__ __forceinline__ void tile_lower_bounds(const pos_t* __restrict__ P, uint32_t wb, const uint32_t pend, pos_t* __restrict__ tile,
+                                                  const pos_t (&key)[kKeys], uint32_t need, uint32_t (&j)[kKeys], pos_t (&v)[kKeys])
+{
+    const uint32_t lane = threadIdx.x & 63;
+    constexpr pos_t kInf = (pos_t)~(pos_t)0;
+#pragma unroll
+    for (uint32_t i = 0; i < kKeys; ++i) { j[i] = pend; v[i] = 0; }
+    while (__any(need != 0) && wb < pend) {
+#pragma unroll
+        for (uint32_t r = 0; r < kTB / 64; ++r) {
+            const uint64_t idx = (uint64_t)wb + lane + 64 * r;
+            tile[lane + 64 * r] = idx < pend ? P[idx] : kInf;                    // +inf behind the list
+        }
+        wave_sync();
+        const pos_t tile_last = tile[kTB - 1];
+#pragma unroll
+        for (uint32_t g = 0; g < kKeys; g += kKeyGroup) {
+            bool take[kKeyGroup];
+            bool any = false;
+#pragma unroll
+            for (uint32_t i = 0; i < kKeyGroup; ++i) { take[i] = ((need >> (g + i)) & 1) && key[g + i] <= tile_last; any |= take[i]; }
+            if (!__any(any)) continue;
+            uint32_t pos[kKeyGroup];
+#pragma unroll
+            for (uint32_t i = 0; i < kKeyGroup; ++i) pos[i] = 0;
+#pragma unroll
+            for (uint32_t step = kTB / 2; step; step >>= 1) {
+#pragma unroll
+                for (uint32_t i = 0; i < kKeyGroup; ++i)
+                    if (tile[pos[i] + step - 1] < key[g + i]) pos[i] += step;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kKeyGroup; ++i) {
+                const pos_t val = tile[pos[i]];
+                if (take[i]) {                                                   // tile[kTB-1] >= key, so pos is the lower bound
+                    const uint64_t at = (uint64_t)wb + pos[i];
+                    j[g + i] = at < pend ? (uint32_t)at : pend;
+                    v[g + i] = val;
+                    need &= ~(1u << (g + i));
+                }
+            }
+        }
+        wave_sync();                                                            // the tile is overwritten next
+        if (!__any(need != 0)) break;
+        // next tile; when even its last element is below the smallest open key, jump to that key's lower bound
+        uint64_t kmin = ~0ull;
+#pragma unroll
+        for (uint32_t i = 0; i < kKeys; ++i)
+            if ((need >> i) & 1) kmin = (uint64_t)key[i] < kmin ? (uint64_t)key[i] : kmin;
+        kmin = wave_min(kmin);
+        const uint64_t nwb = (uint64_t)wb + kTB;
+        if (nwb >= pend) { wb = pend; break; }
+        wb = (uint32_t)nwb;
+        const uint64_t probe_at = nwb + kTB - 1 < pend ? nwb + kTB - 1 : (uint64_t)pend - 1;
+        if ((uint64_t)P[probe_at] < kmin) wb = wave_kary_lower_bound(P, (uint32_t)probe_at + 1, pend, kmin);
+    }
+}
+
+// start-to-start window of one element (position x) in the key domain of the lists; false if no position can be in it
+template <typename pos_t>
+__device__ __forceinline__ bool gap_window(uint64_t x, uint64_t lo, uint64_t hi, pos_t& tlo, pos_t& thi);
+template <>
+__device__ __forceinline__ bool gap_window<uint64_t>(uint64_t x, uint64_t lo, uint64_t hi, uint64_t& tlo, uint64_t& thi)
+{
+    tlo = sat_add(x, lo); thi = sat_add(x, hi);
+    return true;
+}
+template <>
+__device__ __forceinline__ bool gap_window<uint32_t>(uint64_t x, uint64_t lo, uint64_t hi, uint32_t& tlo, uint32_t& thi)
+{
+    const uint64_t a = sat_add(x, lo), b = sat_add(x, hi);
+    tlo = (uint32_t)a;
+    thi = b > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)b;
+    return a <= 0xFFFFFFFFull;                                                   // positions fit 32 bits
 }
 
 // Slots are dealt to waves in contiguous runs so a wave can carry the segment it is in and the last answer
@@ -711,60 +854,100 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
 
 // jump[e] for level-0 elements: first feasible element of list 0 at or after end(e)+end_len (kNone = none);
 // slots of other levels get kNone so the tile pass can treat every slot alike.  Also the start of each chain.
+// Same walk as the link pass; the list searched is the element's own (the answers lie behind the element itself).
 template <typename pos_t>
 __global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
                                                         const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint64_t r0,
                                                         uint64_t r1, FeasRef fb, const pos_t* __restrict__ endp,
                                                         uint32_t* __restrict__ jump, uint32_t* __restrict__ qstart)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    __shared__ pos_t s_tile[4][kTB];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t wave = uniform(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint64_t run_begin = r0 + wave * kRun;
     if (run_begin >= r1) return;
     const uint64_t run_end = run_begin + kRun < r1 ? run_begin + kRun : r1;
-    uint32_t s_w = seg_find(seg_begin, nseg, run_begin);
-    uint32_t hint_seg = kNone, hint = 0;
-    for (uint64_t base = run_begin; base < run_end; base += 64) {
-        const uint64_t e = base + lane;
-        const bool inr = e < run_end;
-        uint32_t s = s_w, jp = 0, fence = 0, mbegin = 0, mend = 0, mpbegin = 0, mpend = 0;
-        uint64_t lim = 0;
-        bool searched = false;
-        if (inr) {
-            while (seg_begin[s + 1] <= e) ++s;
-            const SegMeta m = sm[s];
-            if (m.level == 0 && e < m.end) {
-                if (is_feasible(fb, e)) {                             // feasible start
-                    lim = sat_add((uint64_t)endp[e], qm[m.query].end_len);
-                    fence = phys_of(m, (uint32_t)e) + 1;
-                    searched = true;
+    pos_t* tile = s_tile[wv];
+    uint32_t s = uniform(seg_find(seg_begin, nseg, run_begin));
+    uint64_t cur = run_begin;
+    while (cur < run_end) {
+        while (seg_begin[s + 1] <= cur) ++s;
+        const SegMeta m = sm[s];
+        const uint64_t seg_end = seg_begin[s + 1];                     // beyond m.end only behind the last segment of a class
+        if (m.level != 0) {
+            // ---- not a first sub-pattern: no chain passes through these slots --------------------------------
+            const uint64_t piece_end = run_end < seg_end ? run_end : seg_end;
+            for (uint64_t a = cur + lane; a < piece_end; a += 64) jump[a] = kNone;
+            cur = piece_end;
+        } else if (m.end - m.begin >= kMinPiece && cur < m.end) {
+            // ---- long list: blocks of kBlk slots against tiles of the same list ------------------------------
+            const uint64_t piece_end = run_end < m.end ? run_end : (uint64_t)m.end;
+            const uint64_t end_len = qm[m.query].end_len;
+            if (cur == m.begin && lane == 0) { const uint32_t me = next_feasible(fb, cur); qstart[m.query] = me < m.end ? me : kNone; }
+            uint32_t fence = 0;
+            for (uint64_t blk0 = cur; blk0 < piece_end; blk0 += kBlk) {
+                const uint64_t blk1 = blk0 + kBlk < piece_end ? blk0 + kBlk : piece_end;
+                pos_t key[kKeys], v[kKeys];
+                uint32_t j[kKeys];
+                uint32_t need = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < kKeys; ++i) {
+                    const uint64_t a = blk0 + lane + 64 * i;
+                    key[i] = 0;
+                    if (a < blk1 && is_feasible(fb, a)) {                                  // feasible start
+                        pos_t unused;
+                        if (gap_window<pos_t>((uint64_t)endp[a], end_len, end_len, key[i], unused)) need |= 1u << i;
+                    }
                 }
-                if ((uint32_t)e == m.begin) { const uint32_t me = next_feasible(fb, e); qstart[m.query] = me < m.end ? me : kNone; }
+                const uint32_t own = phys_of(m, (uint32_t)blk0) + 1;                       // every answer lies behind its own element
+                fence = fence > own ? fence : own;
+                const uint32_t asked = need;
+                tile_lower_bounds<pos_t>(P, fence, m.pend, tile, key, need, j, v);
+                uint32_t jm = fence;
+#pragma unroll
+                for (uint32_t i = 0; i < kKeys; ++i) {
+                    const uint64_t a = blk0 + lane + 64 * i;
+                    if (a < blk1) {
+                        uint32_t out = kNone;
+                        if ((asked >> i) & 1) {
+                            jm = j[i] > jm ? j[i] : jm;
+                            if (j[i] < m.pend) {
+                                const uint32_t ej = next_feasible(fb, (uint64_t)m.begin + (j[i] - m.pbegin));
+                                if (ej < m.end) out = ej;
+                            }
+                        }
+                        jump[a] = out;
+                    }
+                }
+                // ends ascend along a list: the largest answer of this block is a fence for the next one
+                jm = wave_max_u32(jm);
+                fence = jm;
             }
-            mbegin = m.begin; mend = m.end; mpbegin = m.pbegin; mpend = m.pend;
-        }
-        const unsigned long long act = __ballot(searched);
-        if (act) {
-            const int first = __ffsll((long long)act) - 1, last = 63 - __clzll((long long)act);
-            const uint32_t s_first = __shfl(s, first), s_last = __shfl(s, last);
-            if (s_first == s_last && s_first == hint_seg && hint >= __shfl(fence, first)) {
-                jp = wave_lower_bound(P, hint, __shfl(mpend, first), lim, searched);
-            } else if (searched) {
-                if (s == hint_seg && hint > fence) fence = hint;
-                jp = gallop_lower_bound(P, fence, mpend, lim);
+            cur = piece_end;
+        } else {
+            // ---- short lists (and the slots between two classes): 64 slots, every lane on its own --------------
+            const uint64_t e = cur + lane;
+            const uint64_t grp_end = cur + 64 < run_end ? cur + 64 : run_end;
+            if (e < grp_end) {
+                uint32_t sl = s;
+                while (seg_begin[sl + 1] <= e) ++sl;
+                const SegMeta ml = sm[sl];
+                uint32_t out = kNone;
+                if (ml.level == 0 && e < ml.end) {
+                    if (is_feasible(fb, e)) {
+                        const uint64_t lim = sat_add((uint64_t)endp[e], qm[ml.query].end_len);
+                        const uint32_t jp = gallop_lower_bound(P, phys_of(ml, (uint32_t)e) + 1, ml.pend, lim);
+                        if (jp < ml.pend) {
+                            const uint32_t ej = next_feasible(fb, (uint64_t)ml.begin + (jp - ml.pbegin));
+                            if (ej < ml.end) out = ej;
+                        }
+                    }
+                    if ((uint32_t)e == ml.begin) { const uint32_t me = next_feasible(fb, e); qstart[ml.query] = me < ml.end ? me : kNone; }
+                }
+                jump[e] = out;
             }
-            hint_seg = s_last;
-            hint = __shfl(jp, last);
+            cur = grp_end;
         }
-        if (inr) {
-            uint32_t out = kNone;
-            if (searched && jp < mpend) {
-                uint32_t ej = next_feasible(fb, (uint64_t)mbegin + (jp - mpbegin));
-                if (ej < mend) out = ej;
-            }
-            jump[e] = out;
-        }
-        s_w = __shfl(s, 0);
     }
 }
 
@@ -775,49 +958,54 @@ __global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict_
 //           leaving one record per tile visited and the query's match count;
 //   emit  : one lane per record lists the matches inside its tile.
 constexpr uint32_t kTile = 1024;
-constexpr uint32_t kTerm = 0xFFFFu;
 
+// per-slot state of the doubling, one word: [0,10) next element inside the tile, bit 10 = chain left the tile,
+// [11,21) chain elements covered so far minus one, [21,31) last chain element inside the tile
 __global__ void __launch_bounds__(256) chain_tiles_kernel(const uint32_t* __restrict__ jump, uint64_t t0 /* multiple of kTile */,
                                                           uint64_t r1, uint2* __restrict__ xh)
 {
+    static_assert(kTile == 1024, "the packed word holds 10-bit tile offsets");
     __shared__ uint32_t s_ext[kTile];
-    __shared__ uint16_t s_nxt[kTile];
-    __shared__ uint16_t s_hop[kTile];
+    __shared__ uint32_t s_st[2][kTile];
+    constexpr uint32_t kDone = 1u << 10;
     const uint64_t base = t0 + (uint64_t)blockIdx.x * kTile;
     const uint64_t tile_end = base + kTile;
+    uint32_t st[4];
+    bool open = false;
 #pragma unroll
     for (uint32_t r = 0; r < 4; ++r) {
-        uint32_t li = threadIdx.x + 256 * r;
-        uint64_t e = base + li;
-        uint32_t j = e < r1 ? jump[e] : kNone;
-        bool inside = j != kNone && (uint64_t)j < tile_end;
-        s_ext[li] = j;                                   // exit if it leaves the tile (or kNone)
-        s_nxt[li] = inside ? (uint16_t)(j - base) : (uint16_t)kTerm;
-        s_hop[li] = 1;
+        const uint32_t li = threadIdx.x + 256 * r;
+        const uint64_t e = base + li;
+        const uint32_t j = e < r1 ? jump[e] : kNone;
+        const bool inside = j != kNone && (uint64_t)j < tile_end;
+        s_ext[li] = j;                                   // where the chain goes when this is its last element inside the tile
+        st[r] = (inside ? (uint32_t)(j - base) : kDone) | (li << 21);
+        s_st[0][li] = st[r];
+        open |= inside;
+    }
+    uint32_t cur = 0;
+    // jump[e] > e, so a chain inside a tile has fewer than 2^10 elements: at most 10 doublings
+    for (uint32_t round = 0; round < 10 && __syncthreads_or(open); ++round) {
+        open = false;
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t li = threadIdx.x + 256 * r;
+            if (!(st[r] & kDone)) {
+                const uint32_t nx = s_st[cur][st[r] & 1023u];
+                const uint32_t hops = ((st[r] >> 11) & 1023u) + ((nx >> 11) & 1023u) + 1;
+                st[r] = (nx & 0x7FFu) | (hops << 11) | (nx & (1023u << 21));
+                open |= !(st[r] & kDone);
+            }
+            s_st[cur ^ 1][li] = st[r];
+        }
+        cur ^= 1;
     }
     __syncthreads();
-    for (uint32_t round = 0; round < 10; ++round) {        // jump[e] > e, so chains inside a tile are shorter than 2^10
-        uint32_t nn[4], hh[4], ee[4];
-#pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) {
-            uint32_t li = threadIdx.x + 256 * r;
-            uint32_t n = s_nxt[li];
-            nn[r] = n; hh[r] = s_hop[li]; ee[r] = s_ext[li];
-            if (n != kTerm) { hh[r] += s_hop[n]; ee[r] = s_ext[n]; nn[r] = s_nxt[n]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) {
-            uint32_t li = threadIdx.x + 256 * r;
-            s_nxt[li] = (uint16_t)nn[r]; s_hop[li] = (uint16_t)hh[r]; s_ext[li] = ee[r];
-        }
-        __syncthreads();
-    }
 #pragma unroll
     for (uint32_t r = 0; r < 4; ++r) {
-        uint32_t li = threadIdx.x + 256 * r;
-        uint64_t e = base + li;
-        if (e < r1) xh[e] = make_uint2(s_ext[li], (uint32_t)s_hop[li]);
+        const uint32_t li = threadIdx.x + 256 * r;
+        const uint64_t e = base + li;
+        if (e < r1) xh[e] = make_uint2(s_ext[st[r] >> 21], ((st[r] >> 11) & 1023u) + 1);
     }
 }
 
@@ -1000,14 +1188,528 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     return VLG_OK;
 }
 
+// =============================================================================================
+// Window filter (semi-join reduction of the lists of one query)
+// =============================================================================================
+// Most elements of a long occurrence list can be in no match at all: an element of sub-pattern i matters only if some
+// element of sub-pattern i+1 lies inside its gap window, and so on to the last sub-pattern -- and likewise towards the
+// first one.  Dropping the others changes no match (a match is a chain of elements that all have such neighbours) but
+// shrinks the lists the join evaluates element by element.  The test is made on blocks of 2^g text positions: a
+// backward sweep (last sub-pattern to first) marks, in a block bitmap per query, the blocks in which an element of the
+// previous sub-pattern could start a chain; the elements of that list inside marked blocks stay active and mark blocks
+// for the list before them.  A forward sweep does the same from the surviving elements of the first list.  Every pass
+// streams sorted lists (coalesced) and touches a bitmap that stays in L2; the survivors are compacted into private
+// lists of the query, which the join then uses in place of the shared ones.
+struct RSeg {                 // one per sub-pattern of a filtered query
+    uint32_t pbegin, pend;    // physical list
+    uint64_t lo, hi;          // gap bounds to the previous sub-pattern (level > 0)
+    uint64_t nlo, nhi;        // gap bounds to the next sub-pattern (dist > 0)
+    uint64_t abit;            // first activity bit of the segment (64-aligned); the last sub-pattern has none (~0)
+    uint32_t fq;              // filtered-query ordinal: selects the query's pair of block bitmaps
+    uint32_t level, dist;
+    uint32_t pad;
+};
+
+struct RPass {
+    int32_t test_buf;         // bitmap an element's block is looked up in (-1: none)
+    int32_t scatter_buf;      // bitmap the windows of the active elements are marked in
+    int32_t dir;              // -1: windows towards the previous sub-pattern, +1: towards the next, 0: no marking
+    int32_t use_bits;         // start from the activity bits of an earlier pass
+    int32_t write_bits;
+};
+
+// Block ranges to mark, merged on the way: the ranges a wave produces ascend (sorted list, one pair of bounds), so
+// overlapping ones fuse into runs and a run is written once, a word per lane, when the next range starts beyond it.
+struct MarkRun {
+    uint64_t* bm;
+    uint32_t S = 0, E = 0;
+    bool open = false;
+    __device__ __forceinline__ void flush()
+    {
+        if (!open) return;
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t w0 = S >> 6, w1 = E >> 6;
+        for (uint32_t w = w0 + lane; w <= w1; w += 64) {
+            const uint32_t b0 = w == w0 ? (S & 63) : 0, b1 = w == w1 ? (E & 63) : 63;
+            const uint64_t m = (~0ull << b0) & (~0ull >> (63 - b1));
+            or_word(bm + w, m);
+        }
+        open = false;
+    }
+    // the word is read at the L2 (where the atomics of the other waves land) so that bits already there cost no atomic
+    static __device__ __forceinline__ void or_word(uint64_t* p, uint64_t m)
+    {
+        const uint64_t have = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((have & m) != m) atomicOr((unsigned long long*)p, (unsigned long long)m);
+    }
+    // ranges [sb,eb] of the lanes with `on`, ascending with the lane
+    __device__ __forceinline__ void add(uint32_t sb, uint32_t eb, bool on)
+    {
+        const uint32_t lane = threadIdx.x & 63;
+        const unsigned long long amask = __ballot(on);
+        if (!amask) return;
+        const unsigned long long below = amask & ((1ull << lane) - 1ull);
+        const int prev = below ? 63 - __clzll((long long)below) : 0;
+        const uint32_t e_prev = __shfl(eb, prev);
+        const bool head = on && (!below || sb > e_prev + 1);                       // first lane of a run inside the wave
+        unsigned long long H = __ballot(head);
+        if (__popcll(H) > 2) {
+            // many short runs (sparse survivors): every head lane writes its own run, all of them at once
+            flush();
+            const unsigned long long above = lane == 63 ? 0ull : (H >> (lane + 1)) << (lane + 1);
+            const unsigned long long in_run = above ? amask & ((1ull << (__ffsll((long long)above) - 1)) - 1ull) : amask;
+            const uint32_t e = __shfl(eb, in_run ? 63 - __clzll((long long)in_run) : 0);
+            if (head) {
+                const uint32_t w0 = sb >> 6, w1 = e >> 6;
+                for (uint32_t w = w0; w <= w1; ++w) {
+                    const uint32_t b0 = w == w0 ? (sb & 63) : 0, b1 = w == w1 ? (e & 63) : 63;
+                    or_word(bm + w, (~0ull << b0) & (~0ull >> (63 - b1)));
+                }
+            }
+            return;
+        }
+        while (H) {
+            const int h = __ffsll((long long)H) - 1;
+            H &= H - 1;
+            const unsigned long long in_run = H ? amask & ((1ull << (__ffsll((long long)H) - 1)) - 1ull) : amask;
+            const uint32_t s = uniform(__shfl(sb, h)), e = uniform(__shfl(eb, 63 - __clzll((long long)in_run)));
+            if (open && s <= E + 1) { E = e > E ? e : E; }
+            else { flush(); S = s; E = e; open = true; }
+        }
+    }
+};
+
+// task of a run: last t with run0[t] <= run
+__device__ __forceinline__ uint32_t task_find(const uint64_t* __restrict__ run0, uint32_t ntasks, uint64_t run)
+{
+    uint32_t lo = 0, hi = ntasks;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (run0[mid] <= run) lo = mid; else hi = mid; }
+    return lo;
+}
+// the same for a whole wave asking about one run: three rounds of 64 probes instead of a chain of dependent loads
+__device__ __forceinline__ uint32_t wave_task_find(const uint64_t* __restrict__ run0, uint32_t ntasks, uint64_t run)
+{
+    return uniform(wave_kary_lower_bound<uint64_t>(run0, 0, ntasks + 1, run + 1)) - 1;
+}
+
+constexpr uint32_t kFilterGroups = 8;         // 64-element groups of a run in flight per wave
+
+template <typename pos_t>
+__global__ void __launch_bounds__(256) filter_pass_kernel(const pos_t* __restrict__ P, const RSeg* __restrict__ segs,
+                                                          const uint32_t* __restrict__ task_seg, const uint64_t* __restrict__ task_run0,
+                                                          uint32_t ntasks, uint64_t* __restrict__ bitmaps, uint64_t nbw, uint32_t g,
+                                                          uint64_t nblocks, uint64_t* __restrict__ abits, RPass ps)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t run = uniform(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (run >= task_run0[ntasks]) return;
+    const uint32_t t = wave_task_find(task_run0, ntasks, run);
+    const RSeg sg = segs[task_seg[t]];
+    const uint64_t len = sg.pend - sg.pbegin;
+    const uint64_t off0 = (run - task_run0[t]) * kRun;
+    const uint64_t off1 = off0 + kRun < len ? off0 + kRun : len;
+    const uint64_t* bm_test = ps.test_buf >= 0 ? bitmaps + ((uint64_t)sg.fq * 2 + (uint32_t)ps.test_buf) * nbw : nullptr;
+    const bool has_bits = sg.abit != ~0ull;
+    const bool mark = ps.dir < 0 ? sg.level > 0 : (ps.dir > 0 ? sg.dist >= 2 : false);
+    MarkRun mr;
+    mr.bm = bitmaps + ((uint64_t)sg.fq * 2 + (uint32_t)ps.scatter_buf) * nbw;
+    for (uint64_t base = off0; base < off1; base += 64 * kFilterGroups) {
+        uint64_t x[kFilterGroups];
+        bool act[kFilterGroups];
+#pragma unroll
+        for (uint32_t i = 0; i < kFilterGroups; ++i) {
+            const uint64_t gb = base + 64 * i, idx = gb + lane;
+            uint64_t cur = gb < off1 ? ~0ull : 0;
+            if (ps.use_bits && cur) cur = abits[(sg.abit + gb) >> 6];          // groups without a survivor read nothing of the list
+            act[i] = idx < off1 && ((cur >> lane) & 1);
+            x[i] = 0;
+            if (act[i]) x[i] = P[sg.pbegin + idx];
+        }
+        if (bm_test) {
+#pragma unroll
+            for (uint32_t i = 0; i < kFilterGroups; ++i)
+                if (act[i]) { const uint64_t blk = x[i] >> g; act[i] = (bm_test[blk >> 6] >> (blk & 63)) & 1; }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kFilterGroups; ++i) {
+            const uint64_t gb = base + 64 * i;
+            const unsigned long long mask = __ballot(act[i]);
+            if (ps.write_bits && has_bits && lane == 0 && gb < off1) abits[(sg.abit + gb) >> 6] = mask;
+            if (mark && mask) {
+                uint32_t sb = 0, eb = 0;
+                bool on = act[i];
+                if (ps.dir < 0) {                                               // positions p with lo <= x - p <= hi
+                    if (x[i] < sg.lo) on = false;
+                    else { eb = (uint32_t)((x[i] - sg.lo) >> g); sb = (uint32_t)((x[i] > sg.hi ? x[i] - sg.hi : 0) >> g); }
+                } else {                                                        // positions p with nlo <= p - x <= nhi
+                    const uint64_t a = sat_add(x[i], sg.nlo) >> g, b = sat_add(x[i], sg.nhi) >> g;
+                    if (a >= nblocks) on = false;
+                    else { sb = (uint32_t)a; eb = (uint32_t)(b >= nblocks ? nblocks - 1 : b); }
+                }
+                mr.add(sb, eb, on);
+            }
+        }
+    }
+    mr.flush();
+}
+
+// Pivot mode: when one list of the query is much shorter than the others, the survivors are found from its elements
+// outwards instead of streaming the long lists.  A lane takes one element of the pivot list and follows it level by
+// level: the elements of the neighbouring list inside its gap window form an index range (two binary searches), which is
+// marked in that list's activity bits; the hull of the range's positions is the "element" followed to the next level
+// (a superset of what the exact windows would mark, which is all the filter needs).
+struct PTask { uint32_t seg0, k, p, pad; };          // first segment of the query, sub-patterns, pivot level
+constexpr uint32_t kPivotRun = 256;                   // pivot elements per wave
+
+template <typename pos_t>
+__global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restrict__ P, const RSeg* __restrict__ segs,
+                                                           const PTask* __restrict__ tasks, const uint64_t* __restrict__ task_run0,
+                                                           uint32_t ntasks, uint64_t* __restrict__ abits)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t run = uniform(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (run >= task_run0[ntasks]) return;
+    const uint32_t t = wave_task_find(task_run0, ntasks, run);
+    const PTask tk = tasks[t];
+    const RSeg pv = segs[tk.seg0 + tk.p];
+    const uint64_t len = pv.pend - pv.pbegin;
+    const uint64_t off0 = (run - task_run0[t]) * kPivotRun;
+    const uint64_t off1 = off0 + kPivotRun < len ? off0 + kPivotRun : len;
+    for (uint64_t base = off0; base < off1; base += 64) {
+        const uint64_t i = base + lane;
+        const bool on0 = i < off1;
+        const uint64_t x = on0 ? (uint64_t)P[pv.pbegin + i] : 0;
+        if (pv.abit != ~0ull) {                                               // every element of the pivot list stays
+            const unsigned long long m = __ballot(on0);
+            if (lane == 0) abits[(pv.abit + base) >> 6] = m;
+        }
+        // towards the first sub-pattern
+        uint64_t lo_pos = x, hi_pos = x;
+        bool on = on0;
+        for (int l = (int)tk.p - 1; l >= 0; --l) {
+            const RSeg sg = segs[tk.seg0 + l], up = segs[tk.seg0 + l + 1];      // gap bounds between l and l+1 belong to l+1
+            uint32_t i0 = 0, i1 = 0;
+            if (on) {
+                if (hi_pos < up.lo) on = false;
+                else {
+                    const uint64_t a = lo_pos > up.hi ? lo_pos - up.hi : 0, b = hi_pos - up.lo;
+                    i0 = lower_bound_dev(P, sg.pbegin, sg.pend, a) - sg.pbegin;
+                    i1 = lower_bound_dev(P, sg.pbegin + i0, sg.pend, b + 1) - sg.pbegin;
+                    on = i0 < i1;
+                }
+            }
+            MarkRun mr;
+            mr.bm = abits + (sg.abit >> 6);
+            mr.add(i0, i1 - 1, on);
+            mr.flush();
+            if (on) { lo_pos = P[sg.pbegin + i0]; hi_pos = P[sg.pbegin + i1 - 1]; }
+        }
+        // towards the last sub-pattern (which keeps no join state itself)
+        lo_pos = hi_pos = x;
+        on = on0;
+        for (uint32_t l = tk.p + 1; l + 1 < tk.k; ++l) {
+            const RSeg sg = segs[tk.seg0 + l];
+            uint32_t i0 = 0, i1 = 0;
+            if (on) {
+                const uint64_t a = sat_add(lo_pos, sg.lo), b = sat_add(hi_pos, sg.hi);
+                i0 = lower_bound_dev(P, sg.pbegin, sg.pend, a) - sg.pbegin;
+                i1 = (b == ~0ull ? sg.pend : lower_bound_dev(P, sg.pbegin + i0, sg.pend, b + 1)) - sg.pbegin;
+                on = i0 < i1;
+            }
+            MarkRun mr;
+            mr.bm = abits + (sg.abit >> 6);
+            mr.add(i0, i1 - 1, on);
+            mr.flush();
+            if (on) { lo_pos = P[sg.pbegin + i0]; hi_pos = P[sg.pbegin + i1 - 1]; }
+        }
+    }
+}
+
+// survivors per run (for the compaction offsets): the activity bits of a filtered list start on a run boundary, so run r of
+// the group owns the words [32 r, 32 r + 32).  Half a wave per run.
+__global__ void __launch_bounds__(256) filter_count_runs_kernel(const uint64_t* __restrict__ abits, uint64_t total_runs,
+                                                                uint32_t* __restrict__ runcnt)
+{
+    static_assert(kRun == 2048, "one run = 32 activity words");
+    const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    uint32_t c = 0;
+    if (r < total_runs) c = (uint32_t)__popcll(abits[r * 32 + (threadIdx.x & 31)]);
+    for (int o = 16; o > 0; o >>= 1) c += __shfl_xor(c, o);                  // both halves of the wave reduce on their own
+    if (r < total_runs && (threadIdx.x & 31) == 0) runcnt[r] = c;
+}
+
+// survivors per list (for the host's plan): a wave per list
+__global__ void __launch_bounds__(256) filter_count_lists_kernel(const uint64_t* __restrict__ crun0, uint32_t ncseg,
+                                                                 const uint32_t* __restrict__ runcnt, unsigned long long* __restrict__ segcnt)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t c = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (c >= ncseg) return;
+    unsigned long long sum = 0;
+    for (uint64_t r = crun0[c] + lane; r < crun0[c + 1]; r += 64) sum += runcnt[r];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) segcnt[c] = sum;
+}
+
+// survivor counts of the runs of a chunk's segments, gathered in task order for the scan
+__global__ void filter_gather_counts_kernel(const uint32_t* __restrict__ task_cidx, const uint64_t* __restrict__ task_run0, uint32_t ntasks,
+                                            const uint64_t* __restrict__ crun0, const uint32_t* __restrict__ runcnt, uint32_t* __restrict__ out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= task_run0[ntasks]) return;
+    const uint32_t t = task_find(task_run0, ntasks, r);
+    out[r] = runcnt[crun0[task_cidx[t]] + (r - task_run0[t])];
+}
+
+// survivors of the chunk's segments -> Pc, in task order; run_cnt = the gathered counts, run_off = their exclusive scan.
+// A wave looks at kCompactRuns runs and works on the ones that have survivors.
+constexpr uint32_t kCompactRuns = 16;
+template <typename pos_t>
+__global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __restrict__ P, const RSeg* __restrict__ segs,
+                                                             const uint32_t* __restrict__ task_seg, const uint64_t* __restrict__ task_run0,
+                                                             uint32_t ntasks, const uint64_t* __restrict__ abits,
+                                                             const uint32_t* __restrict__ run_cnt, const uint32_t* __restrict__ run_off,
+                                                             pos_t* __restrict__ Pc)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t r0 = uniform(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kCompactRuns;
+    const uint64_t total = task_run0[ntasks];
+    if (r0 >= total) return;
+    unsigned long long todo = __ballot(lane < kCompactRuns && r0 + lane < total && run_cnt[r0 + lane] != 0);
+    while (todo) {
+        const uint64_t run = r0 + (uint32_t)(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+        const uint32_t t = wave_task_find(task_run0, ntasks, run);
+        const RSeg sg = segs[task_seg[t]];
+        const uint64_t len = sg.pend - sg.pbegin;
+        const uint64_t off0 = (run - task_run0[t]) * kRun;
+        const uint64_t off1 = off0 + kRun < len ? off0 + kRun : len;
+        uint32_t out = run_off[run];
+        for (uint64_t base = off0; base < off1; base += 64) {
+            const uint64_t bits = abits[(sg.abit + base) >> 6];
+            if (!bits) continue;
+            if ((bits >> lane) & 1) Pc[out + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull))] = P[sg.pbegin + base + lane];
+            out += (uint32_t)__popcll(bits);
+        }
+    }
+}
+
+struct FilterGroup {                 // outcome of the window filter for the queries [g0,g1)
+    uint64_t g0 = 0, g1 = 0;
+    uint64_t sub0 = 0;               // first sub-pattern of the group
+    std::vector<uint8_t> want;       // per query of the group: run the filter on it (set by the planner)
+    std::vector<uint64_t> eff;       // per sub-pattern of the group: list length the join sees (0 for a dead query)
+    std::vector<uint32_t> cidx;      // per sub-pattern: place in the compaction order, kNone = list used as it is
+    std::vector<uint64_t> crun0;     // [ncseg+1] first run of every compacted segment
+    std::vector<uint32_t> cseg;      // [ncseg] segment (index into d_segs) of every compacted segment
+    uint32_t ncseg = 0;
+    RSeg* d_segs = nullptr;
+    uint32_t* d_cseg = nullptr;
+    uint64_t* d_crun0 = nullptr;
+    uint64_t* d_abits = nullptr;
+    uint32_t* d_runcnt = nullptr;
+    uint64_t pc_cap = 0;             // compacted elements one join chunk may hold
+    bool any = false;
+};
+
+inline uint32_t filter_block_shift(uint64_t n) { const unsigned b = bit_width64(n); return b > 31 ? b - 23 : 8; }   // <= 2^23 blocks
+
+// How a query is filtered: 0 = not at all, 1 = streaming sweeps over block bitmaps, 2 = from its shortest list outwards.
+// pivot receives the level of the shortest list.
+inline int filter_mode(const vlg_queries* q, const Plan& pl, const vlg_workspace* ws, uint64_t qi, uint32_t* pivot = nullptr)
+{
+    const uint64_t s0 = q->qsub[qi], k = q->qsub[qi + 1] - s0;
+    if (!ws->filter || k < 2 || !pl.occ[s0]) return 0;
+    uint64_t slots = 0, best = ~0ull;
+    uint32_t p = 0;
+    for (uint64_t i = 0; i < k; ++i) {
+        if (i + 1 < k) slots += pl.occ[s0 + i];
+        if (pl.occ[s0 + i] < best) { best = pl.occ[s0 + i]; p = (uint32_t)i; }
+    }
+    if (slots < ws->filter_min || !slots) return 0;
+    if (pivot) *pivot = p;
+    // two binary searches per pivot element and level against one pass over every element of the long lists
+    return ws->filter_pivot && best * 32 <= slots ? 2 : 1;
+}
+
+// Bytes of filter state a query needs (0 = the query is not filtered).
+inline uint64_t filter_bytes(const vlg_queries* q, const Plan& pl, const vlg_workspace* ws, uint64_t qi, uint64_t nbw)
+{
+    const int mode = filter_mode(q, pl, ws, qi);
+    if (!mode) return 0;
+    const uint64_t s0 = q->qsub[qi], k = q->qsub[qi + 1] - s0;
+    uint64_t bytes = mode == 1 ? 2 * nbw * 8 : 0;
+    for (uint64_t i = 0; i + 1 < k; ++i) bytes += ((pl.occ[s0 + i] + kRun - 1) / kRun) * (kRun / 8 + 4);
+    return bytes + k * (sizeof(RSeg) + 32) + 64;
+}
+
+template <typename pos_t>
+vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, const Plan& pl, const std::vector<uint32_t>& poff,
+                        const pos_t* P, Arena& A /* advanced past the state the join chunks still need */, FilterGroup& fg)
+{
+    hipStream_t st = ws->stream;
+    const uint32_t g = filter_block_shift(idx->hdr.n);
+    const uint64_t nblocks = (idx->hdr.n >> g) + 1, nbw = (nblocks + 63) / 64;
+    const uint64_t nsub = q->qsub[fg.g1] - q->qsub[fg.g0];
+    fg.sub0 = q->qsub[fg.g0];
+    fg.eff.resize(nsub);
+    fg.cidx.assign(nsub, kNone);
+    for (uint64_t s = 0; s < nsub; ++s) fg.eff[s] = pl.occ[fg.sub0 + s];
+    // ---- segments of the filtered queries ------------------------------------------------------------
+    std::vector<RSeg> segs;
+    std::vector<uint32_t> cseg;                       // segments that keep activity bits, in (query, level) order
+    std::vector<uint64_t> crun0(1, 0);
+    std::vector<uint32_t> seg_sub;                    // sub-pattern (group relative) of every segment
+    uint32_t nfq = 0, kmaxf = 0;
+    uint64_t abit = 0;
+    std::vector<PTask> ptasks;                        // queries filtered from a pivot list
+    std::vector<uint64_t> prun0(1, 0);
+    for (uint64_t qi = fg.g0; qi < fg.g1; ++qi) {
+        if (!fg.want[qi - fg.g0]) continue;
+        const uint64_t s0 = q->qsub[qi];
+        const uint32_t k = (uint32_t)(q->qsub[qi + 1] - s0);
+        uint32_t pivot = 0;
+        const bool by_pivot = filter_mode(q, pl, ws, qi, &pivot) == 2;
+        if (by_pivot) {
+            ptasks.push_back(PTask{(uint32_t)segs.size(), k, pivot, 0});
+            prun0.push_back(prun0.back() + (pl.occ[s0 + pivot] + kPivotRun - 1) / kPivotRun);
+        } else {
+            kmaxf = std::max(kmaxf, k);
+        }
+        for (uint32_t i = 0; i < k; ++i) {
+            RSeg r;
+            memset(&r, 0, sizeof r);
+            r.pbegin = poff[pl.did[s0 + i]];
+            r.pend = r.pbegin + (uint32_t)pl.occ[s0 + i];
+            r.lo = q->lo[s0 + i]; r.hi = q->hi[s0 + i];
+            if (i + 1 < k) { r.nlo = q->lo[s0 + i + 1]; r.nhi = q->hi[s0 + i + 1]; }
+            r.fq = by_pivot ? kNone : nfq; r.level = i; r.dist = k - 1 - i;
+            r.abit = ~0ull;
+            if (i + 1 < k) {
+                r.abit = abit;                                   // on a run boundary
+                abit += (pl.occ[s0 + i] + kRun - 1) / kRun * kRun;
+                fg.cidx[s0 + i - fg.sub0] = (uint32_t)cseg.size();
+                cseg.push_back((uint32_t)segs.size());
+                crun0.push_back(crun0.back() + (pl.occ[s0 + i] + kRun - 1) / kRun);
+            }
+            seg_sub.push_back((uint32_t)(s0 + i - fg.sub0));
+            segs.push_back(r);
+        }
+        if (!by_pivot) ++nfq;
+    }
+    fg.any = !segs.empty();
+    if (!fg.any) return VLG_OK;
+    fg.ncseg = (uint32_t)cseg.size();
+    fg.crun0 = crun0;
+    fg.cseg = cseg;
+    const uint64_t total_runs = crun0.back();
+    // ---- device state: what the chunks need first, the bitmaps and task lists (dead after the passes) last ----------
+    fg.d_segs = A.take<RSeg>(segs.size());
+    fg.d_cseg = A.take<uint32_t>(cseg.size());
+    fg.d_crun0 = A.take<uint64_t>(crun0.size());
+    fg.d_abits = A.take<uint64_t>(abit / 64 + 1);
+    fg.d_runcnt = A.take<uint32_t>(total_runs + 1);
+    const uint64_t keep = A.used;
+    unsigned long long* d_segcnt = A.take<unsigned long long>(cseg.size());
+    uint64_t* d_bm = A.take<uint64_t>((uint64_t)nfq * 2 * nbw + 1);
+    uint32_t* d_task_seg = A.take<uint32_t>(segs.size());
+    uint64_t* d_task_run0 = A.take<uint64_t>(segs.size() + 1);
+    PTask* d_ptasks = A.take<PTask>(ptasks.size() + 1);
+    uint64_t* d_prun0 = A.take<uint64_t>(prun0.size());
+    if (!d_prun0 || !d_bm) return fail(VLG_E_INTERNAL, "arena carve failed (filter)");
+    VLG_HIP_TRY(hipMemsetAsync(fg.d_abits, 0, (abit / 64 + 1) * 8, st));
+    VLG_HIP_TRY(hipMemcpyAsync(fg.d_segs, segs.data(), segs.size() * sizeof(RSeg), hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(fg.d_cseg, cseg.data(), cseg.size() * 4, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(fg.d_crun0, crun0.data(), crun0.size() * 8, hipMemcpyHostToDevice, st));
+    if (nfq) VLG_HIP_TRY(hipMemsetAsync(d_bm, 0, (uint64_t)nfq * 2 * nbw * 8, st));
+    if (!ptasks.empty()) {
+        VLG_HIP_TRY(hipMemcpyAsync(d_ptasks, ptasks.data(), ptasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemcpyAsync(d_prun0, prun0.data(), prun0.size() * 8, hipMemcpyHostToDevice, st));
+        Timed t(ws, KS_JOIN_FILTER, 0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t>), dim3((uint32_t)((prun0.back() + 3) / 4)), dim3(256), 0, st, P, fg.d_segs,
+                           d_ptasks, d_prun0, (uint32_t)ptasks.size(), fg.d_abits);
+        VLG_HIP_TRY(hipGetLastError());
+    }
+    auto clear_buf = [&](uint32_t buf) -> vlg_status {
+        if (nfq) VLG_HIP_TRY(hipMemset2DAsync(d_bm + (uint64_t)buf * nbw, 2 * nbw * 8, 0, nbw * 8, nfq, st));
+        return VLG_OK;
+    };
+    std::vector<uint32_t> task_seg;
+    std::vector<uint64_t> task_run0;
+    auto run_pass = [&](const RPass& ps, auto&& pick) -> vlg_status {
+        task_seg.clear(); task_run0.assign(1, 0);
+        uint64_t elems = 0;
+        for (uint32_t i = 0; i < segs.size(); ++i)
+            if (pick(segs[i])) {
+                task_seg.push_back(i);
+                const uint64_t len = segs[i].pend - segs[i].pbegin;
+                task_run0.push_back(task_run0.back() + (len + kRun - 1) / kRun);
+                elems += len;
+            }
+        if (task_seg.empty()) return VLG_OK;
+        VLG_HIP_TRY(hipMemcpyAsync(d_task_seg, task_seg.data(), task_seg.size() * 4, hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemcpyAsync(d_task_run0, task_run0.data(), task_run0.size() * 8, hipMemcpyHostToDevice, st));
+        {
+            Timed t(ws, KS_JOIN_FILTER, elems * sizeof(pos_t));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pass_kernel<pos_t>), dim3((uint32_t)((task_run0.back() + 3) / 4)), dim3(256), 0, st, P,
+                               fg.d_segs, d_task_seg, d_task_run0, (uint32_t)task_seg.size(), d_bm, nbw, g, nblocks, fg.d_abits, ps);
+        }
+        VLG_HIP_TRY(hipGetLastError());
+        VLG_HIP_TRY(hipStreamSynchronize(st));      // the task vectors are rebuilt for the next pass
+        return VLG_OK;
+    };
+    // ---- backward sweep: pass j handles the sub-patterns that have j sub-patterns after them -------------------------
+    for (uint32_t j = 0; j < kmaxf; ++j) {
+        if (j >= 2) if (vlg_status s = clear_buf((j + 1) & 1)) return s;          // it held the marks pass j-1 looked up
+        const RPass ps{j ? (int32_t)(j & 1) : -1, (int32_t)((j + 1) & 1), -1, 0, 1};
+        if (vlg_status s = run_pass(ps, [&](const RSeg& r) { return r.fq != kNone && r.dist == j; })) return s;
+    }
+    // ---- forward sweep: pass l handles the sub-patterns at level l (the last one of a query has no join state) --------
+    if (kmaxf >= 3) {
+        if (nfq) VLG_HIP_TRY(hipMemsetAsync(d_bm, 0, (uint64_t)nfq * 2 * nbw * 8, st));
+        for (uint32_t l = 0; l + 1 < kmaxf; ++l) {
+            if (l >= 2 && l + 3 <= kmaxf) if (vlg_status s = clear_buf((l + 1) & 1)) return s;   // it held the marks pass l-1 looked up
+            const RPass ps{l ? (int32_t)(l & 1) : -1, (int32_t)((l + 1) & 1), +1, 1, 1};
+            if (vlg_status s = run_pass(ps, [&](const RSeg& r) { return r.fq != kNone && r.level == l && r.dist >= 1 && (l >= 1 || r.dist >= 2); })) return s;
+        }
+    }
+    // ---- survivors ------------------------------------------------------------------------------------
+    {
+        Timed t(ws, KS_JOIN_FILTER, abit / 8);
+        hipLaunchKernelGGL(filter_count_runs_kernel, dim3((uint32_t)((total_runs + 7) / 8)), dim3(256), 0, st, fg.d_abits, total_runs, fg.d_runcnt);
+        hipLaunchKernelGGL(filter_count_lists_kernel, dim3((uint32_t)((cseg.size() + 3) / 4)), dim3(256), 0, st, fg.d_crun0, fg.ncseg, fg.d_runcnt,
+                           d_segcnt);
+    }
+    VLG_HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> segcnt(cseg.size());
+    VLG_HIP_TRY(hipMemcpyAsync(segcnt.data(), d_segcnt, cseg.size() * 8, hipMemcpyDeviceToHost, st));
+    VLG_HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t c = 0; c < cseg.size(); ++c) fg.eff[seg_sub[cseg[c]]] = segcnt[c];
+    // a query that lost a whole list has no match; one whose survivors do not fit a chunk is joined on its full lists
+    for (uint64_t qi = fg.g0; qi < fg.g1; ++qi) {
+        const uint64_t s0 = q->qsub[qi] - fg.sub0, k = q->qsub[qi + 1] - q->qsub[qi];
+        if (!k || fg.cidx[s0] == kNone) continue;
+        bool dead = false;
+        uint64_t sum = 0;
+        for (uint64_t i = 0; i + 1 < k; ++i) { dead |= fg.eff[s0 + i] == 0; sum += fg.eff[s0 + i]; }
+        if (dead) for (uint64_t i = 0; i < k; ++i) fg.eff[s0 + i] = 0;
+        else if (sum > fg.pc_cap) for (uint64_t i = 0; i < k; ++i) { fg.eff[s0 + i] = pl.occ[fg.sub0 + s0 + i]; fg.cidx[s0 + i] = kNone; }
+    }
+    A.used = keep;                                   // bitmaps, counters and task lists are dead
+    return VLG_OK;
+}
+
 // ---- join of the queries [q0,q1) against the physical lists -------------------------------------------
 template <typename pos_t>
 vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result* res, uint64_t q0, uint64_t q1,
                           const Plan& pl, const std::vector<uint32_t>& poff, const pos_t* P, Arena A /* by value: scratch past P */,
-                          unsigned long long* d_stats)
+                          unsigned long long* d_stats, const FilterGroup* fg, pos_t* Pc /* survivors of filtered lists go here */)
 {
     (void)idx;
     hipStream_t st = ws->stream;
+    // list lengths as the join sees them: the survivors of the window filter where it ran
+    auto eo = [&](uint64_t s) -> uint64_t { return fg ? fg->eff[s - fg->sub0] : pl.occ[s]; };
+    auto filtered = [&](uint64_t s) -> bool { return fg && fg->cidx[s - fg->sub0] != kNone; };
     const uint64_t s0 = q->qsub[q0], s1 = q->qsub[q1];
     const uint32_t nseg = (uint32_t)(s1 - s0), nq = (uint32_t)(q1 - q0);
     ResultPiece piece;
@@ -1019,13 +1721,13 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
         QueryMeta& Q = qm[qi - q0];
         Q.k = k; Q.end_len = q->end_len[qi]; Q.out_first = Q.out_tuple = 0; Q.seg0 = kNone;
-        bool live = k > 0 && pl.occ[q->qsub[qi]] > 0;
+        bool live = k > 0 && eo(q->qsub[qi]) > 0;
         if (live) kmax = std::max(kmax, k);
     }
     std::vector<uint32_t> cls_count(kmax + 1, 0), cls_first(kmax + 2, 0);   // segments per dist class
     for (uint64_t qi = q0; qi < q1; ++qi) {
         uint32_t k = qm[qi - q0].k;
-        if (!(k > 0 && pl.occ[q->qsub[qi]] > 0)) continue;
+        if (!(k > 0 && eo(q->qsub[qi]) > 0)) continue;
         for (uint32_t i = 0; i < k; ++i) cls_count[k - 1 - i]++;
     }
     // classes are stored from the highest dist down to 0
@@ -1036,13 +1738,15 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     std::vector<uint32_t> seg_of_sub(nseg, kNone);
     for (uint64_t qi = q0; qi < q1; ++qi) {
         uint32_t k = qm[qi - q0].k;
-        if (!(k > 0 && pl.occ[q->qsub[qi]] > 0)) continue;
+        if (!(k > 0 && eo(q->qsub[qi]) > 0)) continue;
         for (uint32_t i = 0; i < k; ++i) {
             uint32_t d = k - 1 - i;
             seg_of_sub[q->qsub[qi] + i - s0] = cls_first[d] + fill[d]++;
         }
         qm[qi - q0].seg0 = seg_of_sub[q->qsub[qi] - s0];
     }
+    uint64_t pc_used = 0;
+    std::vector<uint32_t> pc_tasks;                              // filtered sub-patterns of the chunk (group relative), in Pc order
     for (uint64_t qi = q0; qi < q1; ++qi) {
         uint32_t k = qm[qi - q0].k;
         if (qm[qi - q0].seg0 == kNone) continue;
@@ -1051,8 +1755,14 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
             SegMeta& m = sm[seg_of_sub[s - s0]];
             m.level = i; m.dist = k - 1 - i;
             m.lo = q->lo[s]; m.hi = q->hi[s];
-            m.pbegin = poff[pl.did[s]];
-            m.pend = m.pbegin + (uint32_t)pl.occ[s];
+            if (filtered(s)) {                                   // private list of the query: the survivors, compacted behind P
+                m.pbegin = (uint32_t)((Pc - P) + pc_used);
+                pc_tasks.push_back((uint32_t)(s - fg->sub0));
+                pc_used += eo(s);
+            } else {
+                m.pbegin = poff[pl.did[s]];
+            }
+            m.pend = m.pbegin + (uint32_t)eo(s);
             m.next = (i + 1 < k) ? seg_of_sub[s + 1 - s0] : kNone;
             m.query = (uint32_t)(qi - q0);
         }
@@ -1085,6 +1795,40 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
             if (m0.end > m0.begin) { lvl0_begin = std::min<uint64_t>(lvl0_begin, m0.begin); lvl0_end = std::max<uint64_t>(lvl0_end, m0.end); }
         }
     if (lvl0_end <= lvl0_begin) { res->pieces.push_back(piece); return VLG_OK; }
+    // ---- private lists: compact the survivors of the chunk's filtered lists behind P ------------------------
+    if (!pc_tasks.empty()) {
+        std::vector<uint32_t> t_seg(pc_tasks.size()), t_cidx(pc_tasks.size());
+        std::vector<uint64_t> t_run0(pc_tasks.size() + 1, 0);
+        for (size_t i = 0; i < pc_tasks.size(); ++i) {
+            const uint32_t c = fg->cidx[pc_tasks[i]];
+            t_cidx[i] = c;
+            t_seg[i] = fg->cseg[c];
+            t_run0[i + 1] = t_run0[i] + (fg->crun0[c + 1] - fg->crun0[c]);
+        }
+        const uint64_t runs = t_run0.back();
+        uint32_t* d_tseg = A.take<uint32_t>(t_seg.size());
+        uint32_t* d_tcidx = A.take<uint32_t>(t_cidx.size());
+        uint64_t* d_trun0 = A.take<uint64_t>(t_run0.size());
+        uint32_t* d_cnt = A.take<uint32_t>(runs + 1);
+        uint32_t* d_off = A.take<uint32_t>(runs + 1);
+        size_t scan_tmp = 0;
+        VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tmp, d_cnt, d_off, 0u, runs, rocprim::plus<uint32_t>(), st));
+        void* d_scan = A.take<uint8_t>(scan_tmp + 256);
+        if (!d_scan || !d_off) return fail(VLG_E_INTERNAL, "arena carve failed (compaction)");
+        VLG_HIP_TRY(hipMemcpyAsync(d_tseg, t_seg.data(), t_seg.size() * 4, hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemcpyAsync(d_tcidx, t_cidx.data(), t_cidx.size() * 4, hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemcpyAsync(d_trun0, t_run0.data(), t_run0.size() * 8, hipMemcpyHostToDevice, st));
+        {
+            Timed t(ws, KS_JOIN_FILTER, pc_used * sizeof(pos_t));
+            hipLaunchKernelGGL(filter_gather_counts_kernel, dim3((uint32_t)((runs + 255) / 256)), dim3(256), 0, st, d_tcidx, d_trun0,
+                               (uint32_t)t_seg.size(), fg->d_crun0, fg->d_runcnt, d_cnt);
+            VLG_HIP_TRY(rocprim::exclusive_scan(d_scan, scan_tmp, d_cnt, d_off, 0u, runs, rocprim::plus<uint32_t>(), st));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_compact_kernel<pos_t>), dim3((uint32_t)(((runs + kCompactRuns - 1) / kCompactRuns + 3) / 4)),
+                               dim3(256), 0, st, P, fg->d_segs, d_tseg, d_trun0, (uint32_t)t_seg.size(), fg->d_abits, d_cnt, d_off, Pc);
+        }
+        VLG_HIP_TRY(hipGetLastError());
+        VLG_HIP_TRY(hipStreamSynchronize(st));        // host task vectors go out of scope
+    }
     // ---- carve the arena ---------------------------------------------------------------------------
     uint32_t* link = A.take<uint32_t>(T);
     pos_t* endp = A.take<pos_t>(T);
@@ -1572,30 +2316,30 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             ++Q1;
         }
         ++epoch;
-        // ---- arena: physical lists first, join scratch behind them -----------------------------------
+        // ---- arena: physical lists first, filter state and join scratch behind them ---------------------
         const bool lazy = ws->lazy_join && q->kmax <= kLazyK;
-        // cost of a query in bytes of join scratch
-        const uint64_t per_slot = 1;
         const bool uniform_k = q->kmin == q->kmax;
-        auto slots_of = [&](uint64_t qi) -> uint64_t {
+        // cost of a query in bytes of join scratch / in join slots, for list lengths given by occ_of(sub-pattern)
+        auto bytes_of = [&](uint64_t qi, auto&& occ_of) -> uint64_t {
             uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
-            if (lazy) return (k ? (pl.occ[q->qsub[qi]] + kLazyTile - 1) / kLazyTile * kLazyTile : 0) * kLazyBytesPerSlot;   // whole tiles of list 0
+            if (lazy) return (k ? (occ_of(q->qsub[qi]) + kLazyTile - 1) / kLazyTile * kLazyTile : 0) * kLazyBytesPerSlot;   // whole tiles of list 0
             uint64_t t = 0;
-            for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += pl.occ[q->qsub[qi] + i];
+            for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += occ_of(q->qsub[qi] + i);
             // list-0 arrays cover the slot range of all lists 0, which is exactly those slots when every query has the same k
-            uint64_t t0s = k ? (uniform_k ? pl.occ[q->qsub[qi]] : t) : 0;
+            uint64_t t0s = k ? (uniform_k ? occ_of(q->qsub[qi]) : t) : 0;
             return t * kJoinBytesPerSlot + t0s * kJoinBytesPerSlot0;
         };
-        auto nslots_of = [&](uint64_t qi) -> uint64_t {                      // slot indices are 32-bit inside a chunk
+        auto slots_of = [&](uint64_t qi, auto&& occ_of) -> uint64_t {        // slot indices are 32-bit inside a chunk
             uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
-            if (lazy) return k ? (pl.occ[q->qsub[qi]] + kLazyTile - 1) / kLazyTile * kLazyTile : 0;
+            if (lazy) return k ? (occ_of(q->qsub[qi]) + kLazyTile - 1) / kLazyTile * kLazyTile : 0;
             uint64_t t = 64ull * k;                                           // class alignment slack
-            for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += pl.occ[q->qsub[qi] + i];
+            for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += occ_of(q->qsub[qi] + i);
             return t;
         };
+        auto full = [&](uint64_t s) -> uint64_t { return pl.occ[s]; };
         uint64_t logical_total = 0, logical_max_query = 0;
         for (uint64_t qi = Q0; qi < Q1; ++qi) {
-            uint64_t t = slots_of(qi);
+            uint64_t t = bytes_of(qi, full);
             logical_total += t;
             logical_max_query = std::max(logical_max_query, t);
         }
@@ -1608,35 +2352,85 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
                 sort_tmp = std::max(sort_tmp, sweep_temp_bytes(phys, idx->hdr.sigma, ws->stream));
         }
         const uint64_t phys_bytes = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20);
-        uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
-        uint64_t cap_slots = join_budget / per_slot;                          // bytes
+        const uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
+        // window filter: state of the filtered queries of a group (at most a third of the budget), dropped query by query if it
+        // would not leave room for the largest unfiltered join
+        const uint64_t nbw = (((idx->hdr.n >> filter_block_shift(idx->hdr.n)) + 1) + 63) / 64;
+        const uint64_t group_cap = join_budget / 3;
+        std::vector<uint64_t> fbytes(Q1 - Q0, 0);
+        uint64_t filter_total = 0;
+        if (!lazy && ws->filter && logical_max_query + group_cap <= join_budget)
+            for (uint64_t qi = Q0; qi < Q1; ++qi) {
+                uint64_t b = filter_bytes(q, pl, ws, qi, nbw);
+                if (b > group_cap) b = 0;
+                fbytes[qi - Q0] = b;
+                filter_total += b;
+            }
+        uint64_t filter_runs = 0;                                             // runs the compaction of one chunk may have to index
+        for (uint64_t qi = Q0; qi < Q1; ++qi)
+            if (fbytes[qi - Q0]) for (uint64_t s = q->qsub[qi]; s + 1 < q->qsub[qi + 1]; ++s) filter_runs += pl.occ[s] / kRun + 1;
+        const uint64_t filter_need = std::min(filter_total, group_cap) + filter_runs * 8;
+        const uint64_t cap_bytes = join_budget - filter_need;
         const uint64_t max_chunk_slots = 0xF0000000ull;
-        if (logical_max_query > cap_slots)
+        if (logical_max_query > cap_bytes)
             return fail(VLG_E_WORKSPACE, "a query needs " + std::to_string(logical_max_query) + " bytes of join scratch; workspace cap allows " +
-                                             std::to_string(cap_slots));
-        uint64_t want_slots = std::min<uint64_t>(logical_total, cap_slots);
-        uint64_t meta = (q->qsub[Q1] - q->qsub[Q0] + 4) * (sizeof(SegMeta) + 16) + (Q1 - Q0 + 4) * (sizeof(QueryMeta) + sizeof(LQuery) + 32) +
-                        (want_slots / (kLazyTile * 8) + (Q1 - Q0) + 8) * 48 + (1ull << 20);
-        if (vlg_status s = ws_reserve(ws, phys_bytes + want_slots * per_slot + meta + fixed)) return s;
+                                             std::to_string(cap_bytes));
+        const uint64_t want_bytes = std::min<uint64_t>(logical_total, cap_bytes);
+        uint64_t meta = (q->qsub[Q1] - q->qsub[Q0] + 4) * (sizeof(SegMeta) + 48) + (Q1 - Q0 + 4) * (sizeof(QueryMeta) + sizeof(LQuery) + 32) +
+                        (want_bytes / (kLazyTile * 8) + (Q1 - Q0) + 8) * 48 + (1ull << 20);
+        if (vlg_status s = ws_reserve(ws, phys_bytes + filter_need + want_bytes + meta + fixed)) return s;
         Arena A{ws->arena, ws->arena_bytes};
         pos_t* P = nullptr;
         uint64_t Tphys = 0;
         if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats)) return s;
-        // ---- join chunks ----------------------------------------------------------------------------
-        uint64_t q0 = Q0;
-        while (q0 < Q1) {
-            uint64_t T = 0, S = 0, q1 = q0;
-            while (q1 < Q1) {
-                uint64_t t = slots_of(q1), sl = nslots_of(q1);
-                if (sl > max_chunk_slots) return fail(VLG_E_WORKSPACE, "a query has more than 2^32 join slots");
-                if (((T + t > want_slots || S + sl > max_chunk_slots) && q1 > q0) || (q1 - q0) >= (1u << 22)) break;
-                T += t; S += sl;
-                ++q1;
+        // survivors of filtered lists are compacted into the part of the locate scratch behind the sorted lists
+        const uint64_t pc_first = align_up(Tphys, 64);
+        pos_t* Pc = P ? P + pc_first : nullptr;
+        uint64_t pc_cap = 0;
+        if (Tphys * kPhysScratchPerElem<pos_t>() > (pc_first + 64) * sizeof(pos_t) && pc_first < 0xFFFFFF00ull)
+            pc_cap = std::min<uint64_t>(Tphys * kPhysScratchPerElem<pos_t>() / sizeof(pos_t) - pc_first - 64, 0xFFFFFF00ull - pc_first);
+        // ---- groups of queries that share one run of the filter; join chunks inside a group -------------------
+        uint64_t g0 = Q0;
+        while (g0 < Q1) {
+            Arena GA = A;
+            FilterGroup fg;
+            fg.g0 = g0; fg.pc_cap = pc_cap;
+            uint64_t fb = 0, g1 = g0;
+            while (g1 < Q1) {
+                const uint64_t b = pc_cap ? fbytes[g1 - Q0] : 0;
+                if (fb + b > group_cap && g1 > g0) break;
+                fb += b;
+                fg.want.push_back(b > 0);
+                ++g1;
             }
-            vlg_status s = lazy ? run_lazy_chunk<pos_t>(q, ws, res, q0, q1, pl, poff, P, A, d_stats)
-                                : run_join_chunk<pos_t>(idx, q, ws, res, q0, q1, pl, poff, P, A, d_stats);
-            if (s) return s;
-            q0 = q1;
+            fg.g1 = g1;
+            const FilterGroup* fgp = nullptr;
+            if (fb) {
+                if (vlg_status s = filter_group<pos_t>(idx, q, ws, pl, poff, P, GA, fg)) return s;
+                if (fg.any) fgp = &fg;
+            }
+            auto eff = [&](uint64_t s) -> uint64_t { return fgp ? fgp->eff[s - fgp->sub0] : pl.occ[s]; };
+            auto pc_of = [&](uint64_t qi) -> uint64_t {                      // survivors the query puts into Pc
+                uint64_t t = 0;
+                if (fgp) for (uint64_t s = q->qsub[qi]; s < q->qsub[qi + 1]; ++s) if (fgp->cidx[s - fgp->sub0] != kNone) t += fgp->eff[s - fgp->sub0];
+                return t;
+            };
+            uint64_t q0 = g0;
+            while (q0 < g1) {
+                uint64_t T = 0, S = 0, C = 0, q1 = q0;
+                while (q1 < g1) {
+                    uint64_t t = bytes_of(q1, eff), sl = slots_of(q1, eff), pc = pc_of(q1);
+                    if (sl > max_chunk_slots) return fail(VLG_E_WORKSPACE, "a query has more than 2^32 join slots");
+                    if (((T + t > want_bytes || S + sl > max_chunk_slots || C + pc > pc_cap) && q1 > q0) || (q1 - q0) >= (1u << 22)) break;
+                    T += t; S += sl; C += pc;
+                    ++q1;
+                }
+                vlg_status s = lazy ? run_lazy_chunk<pos_t>(q, ws, res, q0, q1, pl, poff, P, GA, d_stats)
+                                    : run_join_chunk<pos_t>(idx, q, ws, res, q0, q1, pl, poff, P, GA, d_stats, fgp, Pc);
+                if (s) return s;
+                q0 = q1;
+            }
+            g0 = g1;
         }
         Q0 = Q1;
     }
