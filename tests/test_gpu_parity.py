@@ -390,6 +390,34 @@ def test_lazy_join_equals_dense_join_and_oracle(V, oracle, name, seed, kmax):
         assert b.tuples(i).tolist() == o.search(qs[i]).tolist(), qs[i]
 
 
+@pytest.mark.parametrize("name,seed,tail", [("dna_50k", 71, 16), ("zipf40", 72, 1), ("100a", 73, 4), ("dna_skew", 74, 1000), ("abracadabra", 75, 1)])
+def test_locate_trail_sharing_equals_plain_locate_and_oracle(V, oracle, name, seed, tail):
+    """Sorted sweep with shared LF trails (an element stops where another one has stood and takes its position plus the
+    distance) against the random-access kernel and the oracle; nested SA intervals put the same index into two lists."""
+    from vlg_matching_amd.index import Workspace
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    rng = np.random.default_rng(seed)
+    qs = random_queries(text, rng, 300, kmax=4, mmax=4)
+    t = text.decode("latin-1")
+    qs += [t[:1], t[:2], t[:3], t[1:2], t[:1] + ".{0,9}?" + t[:2], t[-1:], t[-2:]]           # prefixes of each other: nested intervals
+    ws_a, ws_b, ws_c = Workspace(), Workspace(), Workspace()
+    ws_a.set_option("sweep", 0)
+    for ws in (ws_b, ws_c):
+        ws.set_option("sweep_min", 1)
+        ws.set_option("sweep_tail", tail)
+    ws_c.set_option("trail", 0)
+    a, b, c = idx.search(qs, workspace=ws_a), idx.search(qs, workspace=ws_b), idx.search(qs, workspace=ws_c)
+    assert b.summary["lf_steps"] <= c.summary["lf_steps"] == a.summary["lf_steps"]
+    for k in ("n_matches", "checksum", "n_tuple_values", "located_occurrences", "logical_occurrences"):
+        assert a.summary[k] == b.summary[k] == c.summary[k], k
+    for x, y, z in zip(a.fetch(), b.fetch(), c.fetch()):
+        assert (x == y).all() and (x == z).all()
+    for i in list(range(0, len(qs), 6)) + list(range(len(qs) - 7, len(qs))):
+        assert b.tuples(i).tolist() == o.search(qs[i]).tolist(), qs[i]
+
+
 @pytest.mark.parametrize("pivot", [1, 0])
 @pytest.mark.parametrize("name,seed,kmax,gapmax,cap_mb", [("dna_50k", 61, 3, 300, 0), ("dna_skew", 62, 6, 40, 0), ("zipf40", 63, 4, 2000, 0),
                                                          ("100a", 64, 3, 5, 0), ("dna_50k", 65, 8, 600, 0), ("dna_50k", 66, 3, 300, 40)])

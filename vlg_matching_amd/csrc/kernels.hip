@@ -555,11 +555,16 @@ __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t
     }
 }
 
-template <class BV, typename pos_t>
+// kTrail: LF trails are shared.  trail[i] remembers the first element that stood on SA index i and at which step; an
+// element that arrives there later has the same future, so it stops and records (that element, steps apart) in rec -- or,
+// when that element has a record already, the record one hop further.  rec[slot]: a position (high bits 0), or
+// delta << kShift | slot of the element it follows; ~0 while the element is still walking.  slot0 = first slot of the sweep.
+template <class BV, typename pos_t, bool kTrail>
 __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count,
                                                          uint32_t step, pos_t* __restrict__ out,
                                                          unsigned long long* __restrict__ stats /* lf, levels */,
-                                                         unsigned long long* __restrict__ n_done)
+                                                         unsigned long long* __restrict__ n_done, uint64_t* __restrict__ trail,
+                                                         uint64_t* __restrict__ rec, uint64_t slot0)
 {
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
@@ -579,10 +584,24 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
             uint64_t q = pow2 ? (i >> dshift) : (i / dens);
             uint64_t r = (uint64_t)samples[q] + step;
             if (r >= iv.n) r -= iv.n;                        // csa_wt.hpp:343-347
-            out[v64 >> kShift] = (pos_t)r;
+            if (kTrail) rec[slot0 + (v64 >> kShift)] = r;
+            else out[v64 >> kShift] = (pos_t)r;
+            key[e] = (uint16_t)iv.sigma;
+            ++n_fin;
+        } else if (kTrail && trail[i] != 0 && (trail[i] & 0xFFFFu) != step) {        // (an equal step is a twin: same index in two lists)
+            // someone stood here `delta` steps ago: same text trail, `delta` positions further left when it started
+            const uint64_t m = trail[i];
+            const uint64_t owner = (m >> 16) - 1, delta = step - (m & 0xFFFFu);
+            const uint64_t ro = rec[owner];
+            uint64_t r;
+            if (ro == ~0ull) r = (delta << kShift) | owner;                       // still walking: follow it
+            else if ((ro >> kShift) == 0) r = ro + delta;                          // its position is known
+            else r = ro + (delta << kShift);                                       // it follows someone itself: follow that one
+            rec[slot0 + (v64 >> kShift)] = r;
             key[e] = (uint16_t)iv.sigma;
             ++n_fin;
         } else {
+            if (kTrail) trail[i] = ((slot0 + (v64 >> kShift) + 1) << 16) | step;
             uint32_t v = 0, c;
             uint64_t pos = i;
             for (;;) {                                       // inverse_select: wt_pc.hpp:385-402
@@ -613,7 +632,8 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
 // stragglers: finish the few elements still alive after the sweep, one lane each
 template <class BV, typename pos_t>
 __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uint64_t* __restrict__ val, uint64_t count, uint32_t step,
-                                                         pos_t* __restrict__ out, unsigned long long* __restrict__ stats)
+                                                         pos_t* __restrict__ out, unsigned long long* __restrict__ stats,
+                                                         uint64_t* __restrict__ rec, uint64_t slot0)
 {
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
@@ -644,11 +664,36 @@ __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uin
         }
         uint64_t r = (uint64_t)samples[i / dens] + off;
         if (r >= iv.n) r -= iv.n;
-        out[v64 >> kShift] = (pos_t)r;
+        if (rec) rec[slot0 + (v64 >> kShift)] = r;
+        else out[v64 >> kShift] = (pos_t)r;
     }
     unsigned long long a = n_lf, b = n_lv;
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
     if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&stats[0], a); if (b) atomicAdd(&stats[1], b); }
+}
+
+// One round of pointer jumping over the records of a trail-sharing sweep: an element that follows another takes over
+// that element's position (done) or its pointer (one hop less next round).  Records are single 64-bit words, so a reader
+// sees a valid state of the element it follows whichever round that one is in.
+template <typename pos_t>
+__global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict__ rec, uint64_t count, pos_t* __restrict__ out,
+                                                            unsigned long long* __restrict__ n_open)
+{
+    constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
+    constexpr uint64_t kLow = (1ull << kShift) - 1;
+    uint32_t open = 0;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = rec[e];
+        if (r >> kShift) {
+            const uint64_t ro = rec[r & kLow], delta = r >> kShift;
+            if ((ro >> kShift) == 0) r = ro + delta;
+            else { r = ro + (delta << kShift); ++open; }
+            rec[e] = r;
+        }
+        if ((r >> kShift) == 0) out[e] = (pos_t)r;
+    }
+    for (int o = 32; o > 0; o >>= 1) open += __shfl_down(open, o);
+    if ((threadIdx.x & 63) == 0 && open) atomicAdd(n_open, (unsigned long long)open);
 }
 
 template <typename pos_t>
@@ -735,29 +780,37 @@ template <typename pos_t>
 vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
                                pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
-                               hipStream_t stream, LaunchTimer* timer)
+                               hipStream_t stream, LaunchTimer* timer, uint64_t* trail /* n words, or null */, uint64_t* rec /* total words */)
 {
     constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
     if (iv.n > (1ull << kShift)) return fail(VLG_E_UNSUPPORTED, "sorted sweep: text too long for the packed position");
     const unsigned bits = bit_width64(iv.sigma);            // keys 0..sigma (sigma = finished, sorts last)
     const uint64_t batch_max = sweep_batch_max<pos_t>();
+    if (trail) VLG_HIP_TRY(hipMemsetAsync(rec, 0xFF, total * 8, stream));
     for (uint64_t t0 = 0; t0 < total; t0 += batch_max) {
         const uint64_t t1 = std::min(total, t0 + batch_max);
+        if (trail) VLG_HIP_TRY(hipMemsetAsync(trail, 0, iv.n * 8, stream));      // steps are counted per sweep: trails are not shared across sweeps
         hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for(t1 - t0, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
                            t0, t1, val_a);
         VLG_HIP_TRY(hipGetLastError());
         uint64_t alive = t1 - t0;
         uint32_t step = 0;
         pos_t* out = d_out + t0;
-        while (alive > tail_threshold) {
+        while (alive > tail_threshold && step < 0xFFFFu) {       // the trail table keeps 16 bits of the step
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
             if (timer) timer->begin(0);
-            if (iv.bv_kind == kBvRrr63)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, key_a,
-                                   alive, step, out, d_stats, d_counter);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a,
-                                   key_a, alive, step, out, d_stats, d_counter);
+            const dim3 grid(grid_for(alive, 4096));
+            if (iv.bv_kind == kBvRrr63) {
+                if (trail) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t, true>), grid, dim3(256), 0, stream, iv, val_a, key_a,
+                                              alive, step, out, d_stats, d_counter, trail, rec, t0);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t, false>), grid, dim3(256), 0, stream, iv, val_a, key_a,
+                                        alive, step, out, d_stats, d_counter, trail, rec, t0);
+            } else {
+                if (trail) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t, true>), grid, dim3(256), 0, stream, iv, val_a, key_a,
+                                              alive, step, out, d_stats, d_counter, trail, rec, t0);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t, false>), grid, dim3(256), 0, stream, iv, val_a, key_a,
+                                        alive, step, out, d_stats, d_counter, trail, rec, t0);
+            }
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
             size_t tb = temp_bytes;
@@ -778,22 +831,38 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             if (timer) timer->begin(0);
             if (iv.bv_kind == kBvRrr63)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<RrrBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, alive,
-                                   step, out, d_stats);
+                                   step, out, d_stats, trail ? rec : nullptr, t0);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<PlainBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a,
-                                   alive, step, out, d_stats);
+                                   alive, step, out, d_stats, trail ? rec : nullptr, t0);
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
+        }
+    }
+    if (trail) {
+        // every element has a record now; jump pointers until all of them are positions
+        for (uint32_t round = 0;; ++round) {
+            VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
+            if (timer) timer->begin(0);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_kernel<pos_t>), dim3(grid_for(total, 16384)), dim3(256), 0, stream, rec, total, d_out,
+                               d_counter);
+            if (timer) timer->end(0);
+            VLG_HIP_TRY(hipGetLastError());
+            unsigned long long open = 0;
+            VLG_HIP_TRY(hipMemcpyAsync(&open, d_counter, 8, hipMemcpyDeviceToHost, stream));
+            VLG_HIP_TRY(hipStreamSynchronize(stream));
+            if (!open) break;
+            if (round > 64) return fail(VLG_E_INTERNAL, "trail records did not resolve");
         }
     }
     return VLG_OK;
 }
 template vlg_status launch_locate_sweep<uint32_t>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint32_t*, uint64_t*,
                                                   uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, uint64_t,
-                                                  hipStream_t, LaunchTimer*);
+                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*);
 template vlg_status launch_locate_sweep<uint64_t>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint64_t*, uint64_t*,
                                                   uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, uint64_t,
-                                                  hipStream_t, LaunchTimer*);
+                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*);
 
 }  // namespace vlg
 

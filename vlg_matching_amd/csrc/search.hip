@@ -260,6 +260,8 @@ struct vlg_workspace {
                                 // Measured on C3 (dense lists): spec 1.5 s + stitch 18.5 s per step vs 1.6 s for the dense passes --
                                 // chains that enter a tile out of phase with the speculated one never merge when almost every
                                 // element is feasible, so the stitch pass degenerates to a serial walk.  Kept for sparse batches.
+    bool trail = true;          // sorted-sweep locate: elements that step onto an SA index another element has visited share its LF trail
+                                // (needs dedup; with dedup off every occurrence walks its own LF steps like the reference)
     bool filter = true;         // window filter: drop the list elements that can be in no match before the join
     uint64_t filter_min = 1ull << 16;   // queries with fewer join slots are joined as they are
     bool filter_pivot = true;   // filter from the shortest list of a query outwards when it is much shorter than the rest
@@ -380,6 +382,7 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "sweep")) { ws->sweep = value != 0; return VLG_OK; }
     if (!strcmp(name, "lazy_join")) { ws->lazy_join = value != 0; return VLG_OK; }
     if (!strcmp(name, "sweep_min")) { ws->sweep_min = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "trail")) { ws->trail = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter")) { ws->filter = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter_min")) { ws->filter_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_pivot")) { ws->filter_pivot = value != 0; return VLG_OK; }
@@ -1160,13 +1163,20 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     VLG_HIP_TRY(hipMemcpyAsync(d_lh, lh.data(), nd * 8, hipMemcpyHostToDevice, st));
     if (use_sweep) {
         const uint64_t cap = std::min<uint64_t>(acc, sweep_batch_max<pos_t>());
+        uint64_t* trail = nullptr;
+        uint64_t* rec = nullptr;
+        if (ws->trail && ws->dedup) {
+            trail = A.take<uint64_t>(idx->hdr.n);
+            rec = A.take<uint64_t>(acc);
+            if (!trail || !rec) return fail(VLG_E_INTERNAL, "arena carve failed (trail table)");
+        }
         uint64_t* val_a = reinterpret_cast<uint64_t*>(scratch);
         uint64_t* val_b = val_a + cap;
         uint16_t* key_a = reinterpret_cast<uint16_t*>(val_b + cap);
         uint16_t* key_b = key_a + cap;
         SweepTimer timer(ws);
         if (vlg_status s = launch_locate_sweep<pos_t>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b,
-                                               d_tmp, sort_tmp, d_counter, d_stats, ws->sweep_tail, st, &timer)) return s;
+                                               d_tmp, sort_tmp, d_counter, d_stats, ws->sweep_tail, st, &timer, trail, rec)) return s;
     } else {
         {
             Timed t(ws, KS_EXPAND, 0);
@@ -2351,7 +2361,9 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             if (ws->sweep && phys >= ws->sweep_min)
                 sort_tmp = std::max(sort_tmp, sweep_temp_bytes(phys, idx->hdr.sigma, ws->stream));
         }
-        const uint64_t phys_bytes = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20);
+        const bool will_sweep = ws->sweep && phys >= ws->sweep_min;
+        const uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup ? (idx->hdr.n + phys) * 8 + 512 : 0;
+        const uint64_t phys_bytes = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20) + trail_bytes;
         const uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
         // window filter: state of the filtered queries of a group (at most a third of the budget), dropped query by query if it
         // would not leave room for the largest unfiltered join
