@@ -408,6 +408,7 @@ def test_locate_trail_sharing_equals_plain_locate_and_oracle(V, oracle, name, se
         ws.set_option("sweep_min", 1)
         ws.set_option("sweep_tail", tail)
     ws_c.set_option("trail", 0)
+    ws_b.set_option("global_sort_min", 1)                 # one radix sort of (list, position) keys instead of a sort per list
     a, b, c = idx.search(qs, workspace=ws_a), idx.search(qs, workspace=ws_b), idx.search(qs, workspace=ws_c)
     assert b.summary["lf_steps"] <= c.summary["lf_steps"] == a.summary["lf_steps"]
     for k in ("n_matches", "checksum", "n_tuple_values", "located_occurrences", "logical_occurrences"):
@@ -437,6 +438,7 @@ def test_window_filter_equals_unfiltered_join_and_oracle(V, oracle, name, seed, 
     ws_n.set_option("filter", 0)
     ws_f.set_option("filter_min", 0)
     ws_f.set_option("filter_pivot", pivot)
+    ws_f.set_option("global_sort_min", 1 if pivot else 1 << 40)      # all lists sorted at once / one sort per list
     a, b = idx.search(qs, workspace=ws_n), idx.search(qs, workspace=ws_f)
     assert "join_filter" not in [k for k, v in ws_n.kernel_stats().items() if v["launches"]]
     assert ws_f.kernel_stats()["join_filter"]["launches"] > 0

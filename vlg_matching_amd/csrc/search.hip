@@ -12,6 +12,9 @@
 //   element at or after j";  a per-query wavefront then hops along list 0 (window of 64 jump targets per
 //   load) emitting the non-overlapping matches in order;  a gather pass writes the tuples.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string.h>
 #include <string>
@@ -265,6 +268,7 @@ struct vlg_workspace {
     bool filter = true;         // window filter: drop the list elements that can be in no match before the join
     uint64_t filter_min = 1ull << 16;   // queries with fewer join slots are joined as they are
     bool filter_pivot = true;   // filter from the shortest list of a query outwards when it is much shorter than the rest
+    uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
     uint64_t sweep_tail = 1ull << 20;   // stragglers of a sweep are finished one lane each
     vlg_kernel_stat stats[KS_COUNT];
@@ -273,6 +277,23 @@ struct vlg_workspace {
 };
 
 namespace {
+
+// VLG_TRACE=1: wall time of the host phases of a batch on stderr (the stream is drained at every mark, so the figures
+// include the kernels launched in the phase)
+struct PhaseTrace {
+    bool on;
+    hipStream_t st;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTrace(hipStream_t s) : on(getenv("VLG_TRACE") != nullptr), st(s), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what)
+    {
+        if (!on) return;
+        (void)hipStreamSynchronize(st);
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vlg trace] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 hipEvent_t ws_event(vlg_workspace* ws)
 {
@@ -382,6 +403,7 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "sweep")) { ws->sweep = value != 0; return VLG_OK; }
     if (!strcmp(name, "lazy_join")) { ws->lazy_join = value != 0; return VLG_OK; }
     if (!strcmp(name, "sweep_min")) { ws->sweep_min = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "global_sort_min")) { ws->global_sort_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "trail")) { ws->trail = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter")) { ws->filter = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter_min")) { ws->filter_min = (uint64_t)value; return VLG_OK; }
@@ -1126,11 +1148,41 @@ template <typename pos_t> constexpr uint64_t kPhysScratchPerElem() { return 20; 
 constexpr uint64_t kJoinBytesPerSlot = 4 + 8 + 1;      // link, endp(<=8), feasibility bits + summaries (any slot)
 constexpr uint64_t kJoinBytesPerSlot0 = 4 + 4 + 8 + 1; // jump, mlist, (exit,hops), chain records (slots of list 0)
 
+// ---- sort of all lists at once: one radix sort of (list, position) keys instead of one sort per list -------------
+template <typename pos_t>
+__global__ void sort_compose_kernel(const pos_t* __restrict__ P, const uint64_t* __restrict__ off /* [nd+1] */, uint64_t nd, uint64_t total,
+                                    uint32_t pos_bits, uint64_t* __restrict__ keys)
+{
+    __shared__ uint64_t s_first;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256; base < total; base += (uint64_t)gridDim.x * 256) {
+        if (threadIdx.x == 0) {
+            uint64_t lo = 0, hi = nd;                      // last list with off[l] <= base
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (off[mid] <= base) lo = mid; else hi = mid; }
+            s_first = lo;
+        }
+        __syncthreads();
+        const uint64_t t = base + threadIdx.x;
+        if (t < total) {
+            uint64_t l = s_first;
+            while (off[l + 1] <= t) ++l;                   // empty lists are skipped too
+            keys[t] = (l << pos_bits) | (uint64_t)P[t];
+        }
+        __syncthreads();
+    }
+}
+
+template <typename pos_t>
+__global__ void sort_narrow_kernel(const uint64_t* __restrict__ keys, uint64_t total, uint32_t pos_bits, pos_t* __restrict__ P)
+{
+    const uint64_t mask = (1ull << pos_bits) - 1;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) P[t] = (pos_t)(keys[t] & mask);
+}
+
 // ---- physical pass: locate + sort every distinct interval used by queries [Q0,Q1) -------------------
 template <typename pos_t>
 vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* res, const std::vector<uint32_t>& dlist /* distinct ids */,
                           const Plan& pl, Arena& A, pos_t*& P_out, std::vector<uint32_t>& poff /* per distinct id -> offset (size dl) */,
-                          uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats)
+                          uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats, pos_t*& Pc_out, uint64_t& pc_cap)
 {
     hipStream_t st = ws->stream;
     const uint32_t nd = (uint32_t)dlist.size();
@@ -1145,6 +1197,8 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     off64[nd] = acc; off32[nd] = (uint32_t)acc;
     Tphys = acc;
     P_out = nullptr;
+    Pc_out = nullptr;
+    pc_cap = 0;
     if (!acc) return VLG_OK;
     const unsigned bits = bit_width64(idx->hdr.n);
     const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (sizeof(pos_t) == 4 ? 32 : 33));
@@ -1187,13 +1241,38 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
             if (vlg_status s = launch_locate<pos_t>(idx->view, Pa, acc, d_stats, st)) return s;
         }
     }
-    {   // sort every occurrence list ascending (std::sort, index_sasearch.hpp:80)
+    // sort every occurrence list ascending (std::sort, index_sasearch.hpp:80)
+    const unsigned list_bits = bit_width64(nd);
+    const bool global_sort = acc >= ws->global_sort_min && bits + list_bits <= 64;
+    uint64_t dead_bytes;                                  // free bytes behind the sorted lists (the survivors of the window filter go there)
+    if (global_sort) {
+        // one radix sort of (list, position) keys: the passes stream the whole batch whatever the list sizes are
+        uint64_t* ka = reinterpret_cast<uint64_t*>(scratch);
+        uint64_t* kb = ka + acc;
+        Timed t(ws, KS_SORT, 2ull * acc * sizeof(pos_t));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_compose_kernel<pos_t>), dim3(grid_for(acc, 32768)), dim3(256), 0, st, Pa, d_off64, (uint64_t)nd, acc, bits, ka);
+        rocprim::double_buffer<uint64_t> keys(ka, kb);
+        size_t tb = sort_tmp;
+        VLG_HIP_TRY(rocprim::radix_sort_keys(d_tmp, tb, keys, acc, 0, bits + list_bits, st));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_narrow_kernel<pos_t>), dim3(grid_for(acc, 32768)), dim3(256), 0, st, keys.current(), acc, bits, Pa);
+        VLG_HIP_TRY(hipGetLastError());
+        P_out = Pa;
+        dead_bytes = (uint64_t)(scratch - reinterpret_cast<uint8_t*>(Pa)) + acc * kPhysScratchPerElem<pos_t>() - acc * sizeof(pos_t);
+    } else {
         Timed t(ws, KS_SORT, 2ull * acc * sizeof(pos_t));
         size_t tb = sort_tmp;
         VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(d_tmp, tb, Pa, Pb, (unsigned)acc, nd, d_off32, d_off32 + 1, 0, bits, st));
+        P_out = Pb;
+        dead_bytes = acc * kPhysScratchPerElem<pos_t>() - acc * sizeof(pos_t);
     }
     VLG_HIP_TRY(hipStreamSynchronize(st));        // host staging vectors go out of scope
-    P_out = Pb;
+    {
+        const uint64_t pc_first = align_up(acc, 64);
+        if (dead_bytes > (pc_first - acc + 64) * sizeof(pos_t) && pc_first < 0xFFFFFF00ull) {
+            Pc_out = P_out + pc_first;
+            pc_cap = std::min<uint64_t>(dead_bytes / sizeof(pos_t) - (pc_first - acc) - 64, 0xFFFFFF00ull - pc_first);
+        }
+    }
     res->sum.located_occurrences += acc;
     return VLG_OK;
 }
@@ -2360,6 +2439,12 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
                                                            bit_width64(idx->hdr.n), ws->stream));
             if (ws->sweep && phys >= ws->sweep_min)
                 sort_tmp = std::max(sort_tmp, sweep_temp_bytes(phys, idx->hdr.sigma, ws->stream));
+            if (phys >= ws->global_sort_min) {
+                size_t tb = 0;
+                rocprim::double_buffer<uint64_t> nk(nullptr, nullptr);
+                VLG_HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, nk, phys, 0, 64, ws->stream));
+                sort_tmp = std::max(sort_tmp, tb);
+            }
         }
         const bool will_sweep = ws->sweep && phys >= ws->sweep_min;
         const uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup ? (idx->hdr.n + phys) * 8 + 512 : 0;
@@ -2394,13 +2479,11 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         Arena A{ws->arena, ws->arena_bytes};
         pos_t* P = nullptr;
         uint64_t Tphys = 0;
-        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats)) return s;
-        // survivors of filtered lists are compacted into the part of the locate scratch behind the sorted lists
-        const uint64_t pc_first = align_up(Tphys, 64);
-        pos_t* Pc = P ? P + pc_first : nullptr;
+        PhaseTrace tr(ws->stream);
+        pos_t* Pc = nullptr;
         uint64_t pc_cap = 0;
-        if (Tphys * kPhysScratchPerElem<pos_t>() > (pc_first + 64) * sizeof(pos_t) && pc_first < 0xFFFFFF00ull)
-            pc_cap = std::min<uint64_t>(Tphys * kPhysScratchPerElem<pos_t>() / sizeof(pos_t) - pc_first - 64, 0xFFFFFF00ull - pc_first);
+        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap)) return s;
+        tr.mark("locate + sort");
         // ---- groups of queries that share one run of the filter; join chunks inside a group -------------------
         uint64_t g0 = Q0;
         while (g0 < Q1) {
@@ -2420,6 +2503,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             if (fb) {
                 if (vlg_status s = filter_group<pos_t>(idx, q, ws, pl, poff, P, GA, fg)) return s;
                 if (fg.any) fgp = &fg;
+                tr.mark("filter group");
             }
             auto eff = [&](uint64_t s) -> uint64_t { return fgp ? fgp->eff[s - fgp->sub0] : pl.occ[s]; };
             auto pc_of = [&](uint64_t qi) -> uint64_t {                      // survivors the query puts into Pc
@@ -2440,6 +2524,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
                 vlg_status s = lazy ? run_lazy_chunk<pos_t>(q, ws, res, q0, q1, pl, poff, P, GA, d_stats)
                                     : run_join_chunk<pos_t>(idx, q, ws, res, q0, q1, pl, poff, P, GA, d_stats, fgp, Pc);
                 if (s) return s;
+                tr.mark("join chunk");
                 q0 = q1;
             }
             g0 = g1;
@@ -2465,6 +2550,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
     uint64_t* d_l = nullptr;
     uint64_t* d_r = nullptr;
     unsigned long long* d_stats = nullptr;
+    PhaseTrace tr(st);
     auto run = [&]() -> vlg_status {
         const uint64_t nsub = q->nsub;
         VLG_HIP_TRY(hipMalloc((void**)&d_l, (nsub + 1) * 8));
@@ -2509,6 +2595,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
                 for (uint64_t s : order) { pl.did[s] = (uint32_t)pl.dl.size(); pl.dl.push_back(l[s]); pl.docc.push_back(pl.occ[s]); }
             }
         }
+        tr.mark("backward search + plan");
         const uint64_t pos_bytes = idx->hdr.sample_bytes;
         vlg_status s = (pos_bytes == 4) ? run_batch<uint32_t>(idx, q, ws, res, pl, d_stats) : run_batch<uint64_t>(idx, q, ws, res, pl, d_stats);
         if (s) return s;
