@@ -100,10 +100,18 @@ def test_c3_headline_config_modes_and_oracle_sample(oracle):
     assert sa["n_queries"] == cfg["nq"] and sa["logical_occurrences"] > 100 * sa["located_occurrences"] > 0
     ws.set_option("sweep", 0)                                    # random-access locate kernel instead of the sorted sweep
     b = idx.search(q, workspace=ws)
-    for k in ("n_matches", "checksum", "n_tuple_values", "located_occurrences", "lf_steps", "wt_levels_locate"):
-        assert sa[k] == b.summary[k], k
+    ws.set_option("sweep", 1)
+    ws.set_option("trail", 0)                                    # sorted sweep, every occurrence walks its own LF steps,
+    ws.set_option("filter", 0)                                   # join over the full lists
+    c = idx.search(q, workspace=ws)
+    for k in ("n_matches", "checksum", "n_tuple_values", "located_occurrences"):
+        assert sa[k] == b.summary[k] == c.summary[k], k
+    for k in ("lf_steps", "wt_levels_locate"):
+        assert c.summary[k] == b.summary[k] and sa[k] * 4 < b.summary[k], k     # shared trails: a fraction of the LF steps
     counts = a.counts
-    assert (counts == b.counts).all()
+    assert (counts == b.counts).all() and (counts == c.counts).all()
+    kst = ws.kernel_stats()
+    assert kst["join_filter"]["launches"] > 0
     # bounded oracle sample: light queries only (a heavy one costs minutes on one core)
     o = oracle.Index.from_parts(idx.export_parts())
     rng = np.random.default_rng(5)

@@ -1219,7 +1219,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         const uint64_t cap = std::min<uint64_t>(acc, sweep_batch_max<pos_t>());
         uint64_t* trail = nullptr;
         uint64_t* rec = nullptr;
-        if (ws->trail && ws->dedup) {
+        if (ws->trail && ws->dedup && acc <= sweep_batch_max<pos_t>()) {          // (trails are shared inside one sweep)
             trail = A.take<uint64_t>(idx->hdr.n);
             rec = A.take<uint64_t>(acc);
             if (!trail || !rec) return fail(VLG_E_INTERNAL, "arena carve failed (trail table)");
@@ -1350,9 +1350,9 @@ struct MarkRun {
             const uint32_t e = __shfl(eb, in_run ? 63 - __clzll((long long)in_run) : 0);
             if (head) {
                 const uint32_t w0 = sb >> 6, w1 = e >> 6;
-                for (uint32_t w = w0; w <= w1; ++w) {
+                for (uint32_t w = w0; w <= w1; ++w) {                             // no look first: nothing here waits for memory
                     const uint32_t b0 = w == w0 ? (sb & 63) : 0, b1 = w == w1 ? (e & 63) : 63;
-                    or_word(bm + w, (~0ull << b0) & (~0ull >> (63 - b1)));
+                    atomicOr((unsigned long long*)(bm + w), (unsigned long long)((~0ull << b0) & (~0ull >> (63 - b1))));
                 }
             }
             return;
@@ -1442,6 +1442,29 @@ __global__ void __launch_bounds__(256) filter_pass_kernel(const pos_t* __restric
     mr.flush();
 }
 
+// Index ranges [i0,i1) (relative to pbegin) of the list elements inside the position windows [a,b] of the lanes with `on`;
+// `on` is cleared for empty ranges.  The windows ascend with the lane, so the wave first brackets all answers between
+// the lower bounds of its smallest a and its largest b (64 probes per round), then every lane searches inside the
+// bracket and gallops from i0 to i1 (a window holds few elements).
+template <typename pos_t>
+__device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, uint32_t pbegin, uint32_t pend, uint64_t a, uint64_t b, bool& on,
+                                             uint32_t& i0, uint32_t& i1)
+{
+    const unsigned long long m = __ballot(on);
+    i0 = i1 = 0;
+    if (!m) return;
+    const int first = __ffsll((long long)m) - 1, last = 63 - __clzll((long long)m);
+    const uint64_t amin = uniform(__shfl(a, first)), bmax = uniform(__shfl(b, last));
+    const uint32_t lo = wave_kary_lower_bound(P, pbegin, pend, amin);
+    const uint32_t hi = bmax == ~0ull ? pend : wave_kary_lower_bound(P, lo, pend, bmax + 1);
+    if (on) {
+        const uint32_t j0 = lower_bound_dev(P, lo, hi, a);
+        const uint32_t j1 = gallop_lower_bound(P, j0, hi, b + 1);
+        i0 = j0 - pbegin; i1 = j1 - pbegin;
+        on = j0 < j1;
+    }
+}
+
 // Pivot mode: when one list of the query is much shorter than the others, the survivors are found from its elements
 // outwards instead of streaming the long lists.  A lane takes one element of the pivot list and follows it level by
 // level: the elements of the neighbouring list inside its gap window form an index range (two binary searches), which is
@@ -1478,15 +1501,12 @@ __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restri
         for (int l = (int)tk.p - 1; l >= 0; --l) {
             const RSeg sg = segs[tk.seg0 + l], up = segs[tk.seg0 + l + 1];      // gap bounds between l and l+1 belong to l+1
             uint32_t i0 = 0, i1 = 0;
+            uint64_t a = 0, b = 0;
             if (on) {
                 if (hi_pos < up.lo) on = false;
-                else {
-                    const uint64_t a = lo_pos > up.hi ? lo_pos - up.hi : 0, b = hi_pos - up.lo;
-                    i0 = lower_bound_dev(P, sg.pbegin, sg.pend, a) - sg.pbegin;
-                    i1 = lower_bound_dev(P, sg.pbegin + i0, sg.pend, b + 1) - sg.pbegin;
-                    on = i0 < i1;
-                }
+                else { a = lo_pos > up.hi ? lo_pos - up.hi : 0; b = hi_pos - up.lo; }
             }
+            pivot_ranges(P, sg.pbegin, sg.pend, a, b, on, i0, i1);
             MarkRun mr;
             mr.bm = abits + (sg.abit >> 6);
             mr.add(i0, i1 - 1, on);
@@ -1499,12 +1519,10 @@ __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restri
         for (uint32_t l = tk.p + 1; l + 1 < tk.k; ++l) {
             const RSeg sg = segs[tk.seg0 + l];
             uint32_t i0 = 0, i1 = 0;
-            if (on) {
-                const uint64_t a = sat_add(lo_pos, sg.lo), b = sat_add(hi_pos, sg.hi);
-                i0 = lower_bound_dev(P, sg.pbegin, sg.pend, a) - sg.pbegin;
-                i1 = (b == ~0ull ? sg.pend : lower_bound_dev(P, sg.pbegin + i0, sg.pend, b + 1)) - sg.pbegin;
-                on = i0 < i1;
-            }
+            const uint64_t a = sat_add(lo_pos, sg.lo);
+            uint64_t b = sat_add(hi_pos, sg.hi);
+            if (b == ~0ull) b = ~0ull - 1;                                       // (b + 1 below)
+            pivot_ranges(P, sg.pbegin, sg.pend, a, b, on, i0, i1);
             MarkRun mr;
             mr.bm = abits + (sg.abit >> 6);
             mr.add(i0, i1 - 1, on);
@@ -1609,16 +1627,17 @@ inline int filter_mode(const vlg_queries* q, const Plan& pl, const vlg_workspace
 {
     const uint64_t s0 = q->qsub[qi], k = q->qsub[qi + 1] - s0;
     if (!ws->filter || k < 2 || !pl.occ[s0]) return 0;
-    uint64_t slots = 0, best = ~0ull;
+    uint64_t slots = 0, all = 0, best = ~0ull;
     uint32_t p = 0;
     for (uint64_t i = 0; i < k; ++i) {
         if (i + 1 < k) slots += pl.occ[s0 + i];
+        all += pl.occ[s0 + i];
         if (pl.occ[s0 + i] < best) { best = pl.occ[s0 + i]; p = (uint32_t)i; }
     }
     if (slots < ws->filter_min || !slots) return 0;
     if (pivot) *pivot = p;
-    // two binary searches per pivot element and level against one pass over every element of the long lists
-    return ws->filter_pivot && best * 32 <= slots ? 2 : 1;
+    // two binary searches per pivot element and level against a pass (or two) over every element of every list
+    return ws->filter_pivot && best * 32 <= all ? 2 : 1;
 }
 
 // Bytes of filter state a query needs (0 = the query is not filtered).
