@@ -234,7 +234,9 @@ def main():
         names = {"locate": "sweep_step_kernel" if kstats["locate_partition"]["launches"] else "locate_kernel",
                  "join_link": "join_link_kernel", "join_init": "join_init_kernel", "join_scan": "rocprim scan (reverse min)", "join_chain": "join_jump+chain_tiles/walk/emit",
                  "gather": "join_gather_kernel", "sort": "rocprim segmented_radix_sort", "locate_partition": "rocprim radix_sort_pairs",
-                 "backward_search": "backward_search_kernel", "expand": "expand_kernel", "join_filter": "filter_pass_kernel"}
+                 "backward_search": "backward_search_kernel", "expand": "expand_kernel", "filter_pass": "filter_pass_kernel",
+                 "filter_pivot": "filter_pivot_kernel", "filter_compact": "filter_count_runs + scan + filter_compact_kernel",
+                 "locate_resolve": "trail_resolve_kernel"}
         dominant = max(kstats, key=lambda k: kstats[k]["total_ms"])
         out = {
             "metric": "vlg_queries_per_sec",

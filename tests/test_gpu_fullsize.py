@@ -111,7 +111,7 @@ def test_c3_headline_config_modes_and_oracle_sample(oracle):
     counts = a.counts
     assert (counts == b.counts).all() and (counts == c.counts).all()
     kst = ws.kernel_stats()
-    assert kst["join_filter"]["launches"] > 0
+    assert kst["filter_compact"]["launches"] > 0
     # bounded oracle sample: light queries only (a heavy one costs minutes on one core)
     o = oracle.Index.from_parts(idx.export_parts())
     rng = np.random.default_rng(5)

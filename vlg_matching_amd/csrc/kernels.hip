@@ -673,47 +673,35 @@ __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uin
 }
 
 // One round of pointer jumping over the records of a trail-sharing sweep: an element that follows another takes over
-// that element's position (done) or its pointer (one hop less next round).  Records are single 64-bit words, so a reader
-// sees a valid state of the element it follows whichever round that one is in.  The first round looks at every element
-// (work == null); the elements still open are appended to `next` and only those are visited again.
+// that element's position (done) or its pointer (two hops per round).  Records are single 64-bit words, so a reader
+// sees a valid state of the element it follows whichever round that one is in.
 template <typename pos_t>
-__global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict__ rec, const uint64_t* __restrict__ work, uint64_t count,
-                                                            pos_t* __restrict__ out, uint64_t* __restrict__ next,
-                                                            unsigned long long* __restrict__ n_open)
+__global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict__ rec, uint64_t count, pos_t* __restrict__ out,
+                                                            unsigned long long* __restrict__ n_open, uint32_t round)
 {
     constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
     constexpr uint64_t kLow = (1ull << kShift) - 1;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
-        const uint64_t j = base + lane;
-        bool open = false;
-        uint64_t e = 0;
-        if (j < count) {
-            e = work ? work[j] : j;
-            uint64_t r = rec[e];
-            if (r >> kShift) {
-                uint64_t ro = rec[r & kLow];
-                const uint64_t delta = r >> kShift;
-                r = (ro >> kShift) == 0 ? ro + delta : ro + (delta << kShift);
-                if (r >> kShift) {                                                // a second hop in the same round
-                    ro = rec[r & kLow];
-                    const uint64_t d2 = r >> kShift;
-                    r = (ro >> kShift) == 0 ? ro + d2 : ro + (d2 << kShift);
-                }
-                rec[e] = r;
+    uint32_t open = 0;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = rec[e];
+        if (r >> kShift) {
+            uint64_t ro = rec[r & kLow];
+            const uint64_t delta = r >> kShift;
+            r = (ro >> kShift) == 0 ? ro + delta : ro + (delta << kShift);
+            if (r >> kShift) {                                                    // second hop
+                ro = rec[r & kLow];
+                const uint64_t d2 = r >> kShift;
+                r = (ro >> kShift) == 0 ? ro + d2 : ro + (d2 << kShift);
             }
+            rec[e] = r;
             if ((r >> kShift) == 0) out[e] = (pos_t)r;
-            else open = true;
-        }
-        const unsigned long long m = __ballot(open);
-        if (m) {
-            unsigned long long at = 0;
-            if (lane == 0) at = atomicAdd(n_open, (unsigned long long)__popcll(m));
-            at = __shfl(at, 0);
-            if (open) next[at + __popcll(m & ((1ull << lane) - 1ull))] = e;
+            else ++open;
+        } else if (round == 0) {
+            out[e] = (pos_t)r;                                                    // elements that never followed anyone
         }
     }
+    for (int o = 32; o > 0; o >>= 1) open += __shfl_down(open, o);
+    if ((threadIdx.x & 63) == 0 && open) atomicAdd(n_open, (unsigned long long)open);
 }
 
 template <typename pos_t>
@@ -860,24 +848,18 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
         }
     }
     if (trail) {
-        // every element has a record now; jump pointers until all of them are positions (val_a / val_b hold the work lists)
-        const uint64_t* work = nullptr;
-        uint64_t* next = val_a;
-        uint64_t count = total;
-        if (total > batch_max) return fail(VLG_E_UNSUPPORTED, "trail sharing: more occurrences than one sweep holds");
-        for (uint32_t round = 0; count; ++round) {
+        // every element has a record now; jump pointers until all of them are positions
+        for (uint32_t round = 0;; ++round) {
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
-            if (timer) timer->begin(0);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_kernel<pos_t>), dim3(grid_for(count, 16384)), dim3(256), 0, stream, rec, work, count,
-                               d_out, next, d_counter);
-            if (timer) timer->end(0);
+            if (timer) timer->begin(2);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_kernel<pos_t>), dim3(grid_for(total, 16384)), dim3(256), 0, stream, rec, total, d_out,
+                               d_counter, round);
+            if (timer) timer->end(2);
             VLG_HIP_TRY(hipGetLastError());
             unsigned long long open = 0;
             VLG_HIP_TRY(hipMemcpyAsync(&open, d_counter, 8, hipMemcpyDeviceToHost, stream));
             VLG_HIP_TRY(hipStreamSynchronize(stream));
-            count = open;
-            work = next;
-            next = next == val_a ? val_b : val_a;
+            if (!open) break;
             if (round > 64) return fail(VLG_E_INTERNAL, "trail records did not resolve");
         }
     }

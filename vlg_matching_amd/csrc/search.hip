@@ -248,8 +248,10 @@ extern "C" void vlg_queries_destroy(vlg_queries* q)
 // =============================================================================================
 // Workspace
 // =============================================================================================
-enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_LOCATE_PART, KS_SORT, KS_JOIN_FILTER, KS_JOIN_INIT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_COUNT };
-static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "locate_partition", "sort", "join_filter", "join_init", "join_link", "join_scan", "join_chain", "gather"};
+enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_LOCATE_PART, KS_LOCATE_RESOLVE, KS_SORT, KS_FILTER_PIVOT, KS_FILTER_PASS, KS_FILTER_COMPACT,
+       KS_JOIN_INIT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_COUNT };
+static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "locate_partition", "locate_resolve", "sort", "filter_pivot",
+                                             "filter_pass", "filter_compact", "join_init", "join_link", "join_scan", "join_chain", "gather"};
 
 struct vlg_workspace {
     hipStream_t stream = nullptr;
@@ -319,14 +321,14 @@ struct SweepTimer : LaunchTimer {      // one event pair per launch of the sweep
     explicit SweepTimer(vlg_workspace* w) : ws(w) {}
     void begin(int which) override
     {
-        int k = which == 0 ? KS_LOCATE : KS_LOCATE_PART;
+        int k = which == 0 ? KS_LOCATE : (which == 1 ? KS_LOCATE_PART : KS_LOCATE_RESOLVE);
         ws->stats[k].launches++;
         a = b = nullptr;
         if (ws->profile) { a = ws_event(ws); b = ws_event(ws); if (a) (void)hipEventRecord(a, ws->stream); }
     }
     void end(int which) override
     {
-        int k = which == 0 ? KS_LOCATE : KS_LOCATE_PART;
+        int k = which == 0 ? KS_LOCATE : (which == 1 ? KS_LOCATE_PART : KS_LOCATE_RESOLVE);
         if (a && b) { (void)hipEventRecord(b, ws->stream); ws->pending[k].emplace_back(a, b); }
     }
 };
@@ -1733,7 +1735,7 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
     if (!ptasks.empty()) {
         VLG_HIP_TRY(hipMemcpyAsync(d_ptasks, ptasks.data(), ptasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st));
         VLG_HIP_TRY(hipMemcpyAsync(d_prun0, prun0.data(), prun0.size() * 8, hipMemcpyHostToDevice, st));
-        Timed t(ws, KS_JOIN_FILTER, 0);
+        Timed t(ws, KS_FILTER_PIVOT, 0);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t>), dim3((uint32_t)((prun0.back() + 3) / 4)), dim3(256), 0, st, P, fg.d_segs,
                            d_ptasks, d_prun0, (uint32_t)ptasks.size(), fg.d_abits);
         VLG_HIP_TRY(hipGetLastError());
@@ -1758,7 +1760,7 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
         VLG_HIP_TRY(hipMemcpyAsync(d_task_seg, task_seg.data(), task_seg.size() * 4, hipMemcpyHostToDevice, st));
         VLG_HIP_TRY(hipMemcpyAsync(d_task_run0, task_run0.data(), task_run0.size() * 8, hipMemcpyHostToDevice, st));
         {
-            Timed t(ws, KS_JOIN_FILTER, elems * sizeof(pos_t));
+            Timed t(ws, KS_FILTER_PASS, elems * sizeof(pos_t));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pass_kernel<pos_t>), dim3((uint32_t)((task_run0.back() + 3) / 4)), dim3(256), 0, st, P,
                                fg.d_segs, d_task_seg, d_task_run0, (uint32_t)task_seg.size(), d_bm, nbw, g, nblocks, fg.d_abits, ps);
         }
@@ -1783,7 +1785,7 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
     }
     // ---- survivors ------------------------------------------------------------------------------------
     {
-        Timed t(ws, KS_JOIN_FILTER, abit / 8);
+        Timed t(ws, KS_FILTER_COMPACT, abit / 8);
         hipLaunchKernelGGL(filter_count_runs_kernel, dim3((uint32_t)((total_runs + 7) / 8)), dim3(256), 0, st, fg.d_abits, total_runs, fg.d_runcnt);
         hipLaunchKernelGGL(filter_count_lists_kernel, dim3((uint32_t)((cseg.size() + 3) / 4)), dim3(256), 0, st, fg.d_crun0, fg.ncseg, fg.d_runcnt,
                            d_segcnt);
@@ -1927,7 +1929,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         VLG_HIP_TRY(hipMemcpyAsync(d_tcidx, t_cidx.data(), t_cidx.size() * 4, hipMemcpyHostToDevice, st));
         VLG_HIP_TRY(hipMemcpyAsync(d_trun0, t_run0.data(), t_run0.size() * 8, hipMemcpyHostToDevice, st));
         {
-            Timed t(ws, KS_JOIN_FILTER, pc_used * sizeof(pos_t));
+            Timed t(ws, KS_FILTER_COMPACT, 2 * pc_used * sizeof(pos_t));
             hipLaunchKernelGGL(filter_gather_counts_kernel, dim3((uint32_t)((runs + 255) / 256)), dim3(256), 0, st, d_tcidx, d_trun0,
                                (uint32_t)t_seg.size(), fg->d_crun0, fg->d_runcnt, d_cnt);
             VLG_HIP_TRY(rocprim::exclusive_scan(d_scan, scan_tmp, d_cnt, d_off, 0u, runs, rocprim::plus<uint32_t>(), st));
