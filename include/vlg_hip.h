@@ -280,6 +280,15 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
  * "sweep" (default 1): locate by the synchronous sorted LF sweep (coalesced super-block reads) when the batch has
  * at least "sweep_min" occurrences (default 2^22); the last "sweep_tail" (default 2^20) stragglers and smaller
  * batches use the one-lane-per-occurrence random-access kernel.
+ * "trail" (default 1, needs "dedup"): inside a sorted sweep an occurrence that steps onto an SA index another occurrence
+ * has visited stops there and takes that occurrence's position plus the distance (csa[i] = csa[LF(i)] + 1 shared between
+ * lanes), so a batch walks every LF trail once; 0 = every occurrence walks to its own sample like csa_wt::operator[].
+ * "global_sort_min" (default 2^20): from this many occurrences on all lists are sorted by one radix sort of
+ * (list, position) keys instead of one segmented sort.
+ * "filter" (default 1): before the join drop the list elements whose gap windows hold no element of the neighbouring
+ * lists (they are in no match); "filter_min" (default 2^16) = join slots below which a query is joined as it is;
+ * "filter_pivot" (default 1): filter outwards from the shortest list of a query when it is >= 32x shorter than all of
+ * them together, otherwise (or with 0) by streaming sweeps over block bitmaps.
  * "lazy_join" (default 0, experimental): follow the match chains lazily with tile speculation (queries of up to 8
  * sub-patterns) instead of the dense passes that evaluate every list element; pays only for sparse lists.
  * Results are identical whatever the options. */

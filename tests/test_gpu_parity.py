@@ -527,13 +527,15 @@ def test_rrr_index_variant_equals_plain_and_oracle(torch_cuda, V, oracle, name, 
     # whole searches, both locate kernels
     qs = random_queries(text, rng, 200, kmax=4, mmax=4) if len(text) > 30 else ["a.{0,10}?a.{0,10}?a", "ac.{2,5}?a.{4,8}?b", "abra"]
     a = plain.search(qs)
-    for opts in ({}, {"sweep_min": 1, "sweep_tail": 50}):
+    for opts in ({}, {"sweep_min": 1, "sweep_tail": 50, "trail": 0}, {"sweep_min": 1, "sweep_tail": 50}):
         ws = Workspace()
         for k_, v_ in opts.items():
             ws.set_option(k_, v_)
         b = rrr.search(qs, workspace=ws)
-        for k in ("n_matches", "checksum", "located_occurrences", "lf_steps", "wt_levels_locate", "wt_levels_bsearch"):
+        shared = "sweep_min" in opts and "trail" not in opts        # shared LF trails: fewer steps, same positions
+        for k in ("n_matches", "checksum", "located_occurrences", "wt_levels_bsearch") + (() if shared else ("lf_steps", "wt_levels_locate")):
             assert a.summary[k] == b.summary[k], (k, opts)
+        assert not shared or b.summary["lf_steps"] <= a.summary["lf_steps"]
         for x, y in zip(a.fetch(), b.fetch()):
             assert (x == y).all()
     for i in range(0, len(qs), 9):

@@ -86,6 +86,7 @@ constexpr uint32_t kRrrBlockBits = 63, kRrrBlocksPerSuper = 32, kRrrSuperBits = 
 
 void set_error(const std::string& msg);
 vlg_status fail(vlg_status st, const std::string& msg);
+void release_cached_device_memory();      // result buffers parked for reuse (search.hip) go back to the driver
 
 #define VLG_HIP_TRY(expr)                                                                        \
     do {                                                                                         \

@@ -255,6 +255,8 @@ extern "C" vlg_status vlg_set_device(int ordinal)
 
 extern "C" vlg_status vlg_index_from_parts(const vlg_index_parts* p, vlg_index** out)
 {
+    release_cached_device_memory();          // an index wants its memory now; parked result buffers can be allocated again
+
     if (!p || !out) return fail(VLG_E_INVALID, "null argument");
     *out = nullptr;
     if (vlg_status st = check_device()) return st;
@@ -545,6 +547,8 @@ __global__ void __launch_bounds__(256) rrr_encode_kernel(const Block* __restrict
 
 extern "C" vlg_status vlg_index_compress(const vlg_index* src, int kind, vlg_index** out)
 {
+    release_cached_device_memory();          // an index wants its memory now; parked result buffers can be allocated again
+
     if (!src || !out) return fail(VLG_E_INVALID, "null argument");
     *out = nullptr;
     if (kind != VLG_BV_RRR63) return fail(VLG_E_INVALID, "unknown bit-vector kind");
@@ -943,6 +947,8 @@ vlg_status build_on_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens
 
 extern "C" vlg_status vlg_index_build_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens, void* stream, vlg_index** out)
 {
+    release_cached_device_memory();          // an index wants its memory now; parked result buffers can be allocated again
+
     if (!out || (n_text && !d_text)) return fail(VLG_E_INVALID, "null argument");
     *out = nullptr;
     if (vlg_status st = check_device()) return st;

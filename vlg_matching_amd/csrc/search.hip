@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -356,11 +357,18 @@ void ws_reset_stats(vlg_workspace* ws)
     }
 }
 
+void drain_result_cache();
+
 vlg_status ws_reserve(vlg_workspace* ws, uint64_t bytes)
 {
     if (bytes <= ws->arena_bytes) return VLG_OK;
     if (ws->arena) { (void)hipFree(ws->arena); ws->arena = nullptr; ws->arena_bytes = 0; }
-    VLG_HIP_TRY(hipMalloc((void**)&ws->arena, bytes));
+    if (hipMalloc((void**)&ws->arena, bytes) != hipSuccess) {        // parked result buffers may be in the way
+        (void)hipGetLastError();
+        ws->arena = nullptr;
+        drain_result_cache();
+        VLG_HIP_TRY(hipMalloc((void**)&ws->arena, bytes));
+    }
     ws->arena_bytes = bytes;
     return VLG_OK;
 }
@@ -431,6 +439,7 @@ struct ResultPiece {
     uint64_t matches = 0, tuple_vals = 0;
     uint64_t* d_first = nullptr;   // [matches]
     uint64_t* d_tuples = nullptr;  // [tuple_vals]
+    uint64_t first_bytes = 0, tuple_bytes = 0;   // sizes of the allocations (a parked buffer may be larger than needed)
 };
 
 struct vlg_result {
@@ -440,12 +449,71 @@ struct vlg_result {
     std::vector<ResultPiece> pieces;
 };
 
+// Result buffers are large and batches come one after the other: freed buffers are parked (up to kResultCacheBytes) and
+// handed to the next result of a similar size instead of going through hipFree / hipMalloc every batch.
+namespace {
+constexpr uint64_t kResultCacheBytes = 48ull << 30;
+struct ResultCache {
+    std::mutex mu;
+    std::vector<std::pair<void*, uint64_t>> free_list;
+    uint64_t bytes = 0;
+    void* take(uint64_t need, uint64_t* size)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = free_list.size();
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].second >= need && free_list[i].second <= need + need / 4 + (1u << 20) &&
+                (best == free_list.size() || free_list[i].second < free_list[best].second)) best = i;
+        if (best == free_list.size()) return nullptr;
+        void* p = free_list[best].first;
+        *size = free_list[best].second;
+        bytes -= free_list[best].second;
+        free_list.erase(free_list.begin() + best);
+        return p;
+    }
+    void give(void* p, uint64_t size)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (bytes + size <= kResultCacheBytes && free_list.size() < 64) { free_list.emplace_back(p, size); bytes += size; return; }
+        }
+        (void)hipFree(p);
+    }
+    void drain()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& e : free_list) (void)hipFree(e.first);
+        free_list.clear();
+        bytes = 0;
+    }
+};
+ResultCache& result_cache() { static ResultCache* c = new ResultCache(); return *c; }     // never destroyed: no HIP calls at exit
+void drain_result_cache() { result_cache().drain(); }
+
+hipError_t result_alloc(uint64_t** out, uint64_t bytes, uint64_t* got)
+{
+    if (void* p = result_cache().take(bytes, got)) { *out = (uint64_t*)p; return hipSuccess; }
+    hipError_t e = hipMalloc((void**)out, bytes);
+    if (e != hipSuccess) {                                   // memory may be parked in the cache: release it and retry once
+        (void)hipGetLastError();
+        result_cache().drain();
+        e = hipMalloc((void**)out, bytes);
+    }
+    *got = bytes;
+    return e;
+}
+}  // namespace
+
+namespace vlg {
+void release_cached_device_memory() { result_cache().drain(); }
+}
+
 extern "C" void vlg_result_destroy(vlg_result* r)
 {
     if (!r) return;
     for (auto& p : r->pieces) {
-        if (p.d_first) (void)hipFree(p.d_first);
-        if (p.d_tuples) (void)hipFree(p.d_tuples);
+        if (p.d_first) result_cache().give(p.d_first, p.first_bytes);
+        if (p.d_tuples) result_cache().give(p.d_tuples, p.tuple_bytes);
     }
     delete r;
 }
@@ -1311,27 +1379,52 @@ struct RPass {
 
 // Block ranges to mark, merged on the way: the ranges a wave produces ascend (sorted list, one pair of bounds), so
 // overlapping ones fuse into runs and a run is written once, a word per lane, when the next range starts beyond it.
+// With a window (kMarkWin words of LDS per wave) the words are combined on chip first and reach the bitmap once when the
+// ranges have moved past them: marks of sparse survivors cost an LDS atomic instead of a 64-byte request each.
+constexpr uint32_t kMarkWin = 32;
 struct MarkRun {
     uint64_t* bm;
+    uint64_t* win = nullptr;              // LDS, zeroed, private to the wave (null: every word goes to memory directly)
+    uint32_t wbase = 0;
     uint32_t S = 0, E = 0;
     bool open = false;
+    // write the window out and move it to start at word w
+    __device__ __forceinline__ void slide(uint32_t w)
+    {
+        const uint32_t lane = threadIdx.x & 63;
+        wave_sync();
+        if (lane < kMarkWin) {
+            const uint64_t m = win[lane];
+            if (m) { atomicOr((unsigned long long*)(bm + wbase + lane), (unsigned long long)m); win[lane] = 0; }
+        }
+        wave_sync();
+        wbase = w;
+    }
+    // make room for bits up to word w1 of ranges that start at word w0 or later; false if they do not fit the window
+    __device__ __forceinline__ bool fits(uint32_t w0, uint32_t w1)
+    {
+        if (!win) return false;
+        if (w1 >= wbase + kMarkWin || w0 < wbase) slide(w0);
+        return w1 < wbase + kMarkWin;
+    }
     __device__ __forceinline__ void flush()
     {
         if (!open) return;
         const uint32_t lane = threadIdx.x & 63;
         const uint32_t w0 = S >> 6, w1 = E >> 6;
+        const bool local = fits(w0, w1);
         for (uint32_t w = w0 + lane; w <= w1; w += 64) {
             const uint32_t b0 = w == w0 ? (S & 63) : 0, b1 = w == w1 ? (E & 63) : 63;
             const uint64_t m = (~0ull << b0) & (~0ull >> (63 - b1));
-            or_word(bm + w, m);
+            if (local) win[w - wbase] |= m;                                         // one lane per word
+            else atomicOr((unsigned long long*)(bm + w), (unsigned long long)m);
         }
         open = false;
     }
-    // the word is read at the L2 (where the atomics of the other waves land) so that bits already there cost no atomic
-    static __device__ __forceinline__ void or_word(uint64_t* p, uint64_t m)
+    __device__ __forceinline__ void finish()
     {
-        const uint64_t have = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((have & m) != m) atomicOr((unsigned long long*)p, (unsigned long long)m);
+        flush();
+        if (win) slide(0);
     }
     // ranges [sb,eb] of the lanes with `on`, ascending with the lane
     __device__ __forceinline__ void add(uint32_t sb, uint32_t eb, bool on)
@@ -1350,11 +1443,16 @@ struct MarkRun {
             const unsigned long long above = lane == 63 ? 0ull : (H >> (lane + 1)) << (lane + 1);
             const unsigned long long in_run = above ? amask & ((1ull << (__ffsll((long long)above) - 1)) - 1ull) : amask;
             const uint32_t e = __shfl(eb, in_run ? 63 - __clzll((long long)in_run) : 0);
+            const uint32_t first_w = uniform(__shfl(sb, __ffsll((long long)amask) - 1)) >> 6;
+            const uint32_t last_w = uniform(__shfl(eb, 63 - __clzll((long long)amask))) >> 6;
+            const bool local = fits(first_w, last_w);
             if (head) {
                 const uint32_t w0 = sb >> 6, w1 = e >> 6;
                 for (uint32_t w = w0; w <= w1; ++w) {                             // no look first: nothing here waits for memory
                     const uint32_t b0 = w == w0 ? (sb & 63) : 0, b1 = w == w1 ? (e & 63) : 63;
-                    atomicOr((unsigned long long*)(bm + w), (unsigned long long)((~0ull << b0) & (~0ull >> (63 - b1))));
+                    const unsigned long long m = (~0ull << b0) & (~0ull >> (63 - b1));
+                    if (local) atomicOr((unsigned long long*)(win + (w - wbase)), m);
+                    else atomicOr((unsigned long long*)(bm + w), m);
                 }
             }
             return;
@@ -1402,8 +1500,12 @@ __global__ void __launch_bounds__(256) filter_pass_kernel(const pos_t* __restric
     const uint64_t* bm_test = ps.test_buf >= 0 ? bitmaps + ((uint64_t)sg.fq * 2 + (uint32_t)ps.test_buf) * nbw : nullptr;
     const bool has_bits = sg.abit != ~0ull;
     const bool mark = ps.dir < 0 ? sg.level > 0 : (ps.dir > 0 ? sg.dist >= 2 : false);
+    __shared__ uint64_t s_win[4][kMarkWin];
     MarkRun mr;
     mr.bm = bitmaps + ((uint64_t)sg.fq * 2 + (uint32_t)ps.scatter_buf) * nbw;
+    mr.win = s_win[threadIdx.x >> 6];
+    if (lane < kMarkWin) mr.win[lane] = 0;
+    wave_sync();
     for (uint64_t base = off0; base < off1; base += 64 * kFilterGroups) {
         uint64_t x[kFilterGroups];
         bool act[kFilterGroups];
@@ -1441,7 +1543,7 @@ __global__ void __launch_bounds__(256) filter_pass_kernel(const pos_t* __restric
             }
         }
     }
-    mr.flush();
+    mr.finish();
 }
 
 // Index ranges [i0,i1) (relative to pbegin) of the list elements inside the position windows [a,b] of the lanes with `on`;
@@ -1817,6 +1919,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
 {
     (void)idx;
     hipStream_t st = ws->stream;
+    PhaseTrace jt(st);
     // list lengths as the join sees them: the survivors of the window filter where it ran
     auto eo = [&](uint64_t s) -> uint64_t { return fg ? fg->eff[s - fg->sub0] : pl.occ[s]; };
     auto filtered = [&](uint64_t s) -> bool { return fg && fg->cidx[s - fg->sub0] != kNone; };
@@ -1905,6 +2008,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
             if (m0.end > m0.begin) { lvl0_begin = std::min<uint64_t>(lvl0_begin, m0.begin); lvl0_end = std::max<uint64_t>(lvl0_end, m0.end); }
         }
     if (lvl0_end <= lvl0_begin) { res->pieces.push_back(piece); return VLG_OK; }
+    jt.mark("  chunk: host metadata");
     // ---- private lists: compact the survivors of the chunk's filtered lists behind P ------------------------
     if (!pc_tasks.empty()) {
         std::vector<uint32_t> t_seg(pc_tasks.size()), t_cidx(pc_tasks.size());
@@ -1939,6 +2043,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         VLG_HIP_TRY(hipGetLastError());
         VLG_HIP_TRY(hipStreamSynchronize(st));        // host task vectors go out of scope
     }
+    jt.mark("  chunk: compaction");
     // ---- carve the arena ---------------------------------------------------------------------------
     uint32_t* link = A.take<uint32_t>(T);
     pos_t* endp = A.take<pos_t>(T);
@@ -2039,6 +2144,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     std::vector<unsigned long long> counts(nq);
     VLG_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, nq * 8, hipMemcpyDeviceToHost, st));
     VLG_HIP_TRY(hipStreamSynchronize(st));
+    jt.mark("  chunk: link + chain");
     uint64_t M = 0, TV = 0;
     for (uint32_t i = 0; i < nq; ++i) {
         qm[i].out_first = M; qm[i].out_tuple = TV;
@@ -2047,9 +2153,10 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     }
     piece.matches = M; piece.tuple_vals = TV;
     if (M) {
-        VLG_HIP_TRY(hipMalloc((void**)&piece.d_first, M * 8));
-        VLG_HIP_TRY(hipMalloc((void**)&piece.d_tuples, TV * 8));
+        VLG_HIP_TRY(result_alloc(&piece.d_first, M * 8, &piece.first_bytes));
+        VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * 8, &piece.tuple_bytes));
         res->pieces.push_back(piece);
+        jt.mark("  chunk: result malloc");
         VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
         Timed t(ws, KS_GATHER, 8ull * (M + TV));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(runs_grid(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, d_segb, nlive,
@@ -2059,6 +2166,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         res->pieces.push_back(piece);
     }
     VLG_HIP_TRY(hipStreamSynchronize(st));     // qm / counts host buffers are read by the async copies above
+    jt.mark("  chunk: gather");
     res->sum.n_matches += M;
     res->sum.n_tuple_values += TV;
     res->sum.n_chunks++;
@@ -2370,8 +2478,8 @@ vlg_status run_lazy_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
     moff[nq] = M;
     piece.matches = M; piece.tuple_vals = TV;
     if (M) {
-        VLG_HIP_TRY(hipMalloc((void**)&piece.d_first, M * 8));
-        VLG_HIP_TRY(hipMalloc((void**)&piece.d_tuples, TV * 8));
+        VLG_HIP_TRY(result_alloc(&piece.d_first, M * 8, &piece.first_bytes));
+        VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * 8, &piece.tuple_bytes));
         res->pieces.push_back(piece);
         VLG_HIP_TRY(hipMemcpyAsync(d_lq, lq.data(), (nq + 1) * sizeof(LQuery), hipMemcpyHostToDevice, st));
         VLG_HIP_TRY(hipMemcpyAsync(d_moff, moff.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
@@ -2583,6 +2691,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
             Timed t(ws, KS_BSEARCH, 0);
             if (vlg_status s = launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_l, d_r, d_stats + 3, st)) return s;
         }
+        tr.mark("backward search");
         std::vector<uint64_t> l(nsub), r(nsub);
         if (nsub) {
             VLG_HIP_TRY(hipMemcpyAsync(l.data(), d_l, nsub * 8, hipMemcpyDeviceToHost, st));
@@ -2606,17 +2715,30 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
             order.reserve(nsub);
             for (uint64_t s = 0; s < nsub; ++s) if (pl.occ[s]) { order.push_back(s); res->sum.logical_occurrences += pl.occ[s]; }
             if (ws->dedup) {
-                std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return l[a] != l[b] ? l[a] < l[b] : r[a] < r[b]; });
-                for (size_t i = 0; i < order.size(); ++i) {
-                    uint64_t s = order[i];
-                    if (i == 0 || l[s] != l[order[i - 1]] || r[s] != r[order[i - 1]]) { pl.dl.push_back(l[s]); pl.docc.push_back(pl.occ[s]); }
-                    pl.did[s] = (uint32_t)(pl.dl.size() - 1);
+                // open-addressing table keyed by the interval; ids in order of first appearance
+                uint64_t cap = 16;
+                while (cap < 2 * order.size()) cap <<= 1;
+                std::vector<uint32_t> table(cap, 0xFFFFFFFFu);
+                for (uint64_t s : order) {
+                    uint64_t h = (l[s] * 0x9E3779B97F4A7C15ull) ^ (r[s] * 0xC2B2AE3D27D4EB4Full);
+                    h ^= h >> 29;
+                    uint64_t at = h & (cap - 1);
+                    for (;; at = (at + 1) & (cap - 1)) {
+                        const uint32_t d = table[at];
+                        if (d == 0xFFFFFFFFu) {
+                            table[at] = (uint32_t)pl.dl.size();
+                            pl.did[s] = (uint32_t)pl.dl.size();
+                            pl.dl.push_back(l[s]); pl.docc.push_back(pl.occ[s]);
+                            break;
+                        }
+                        if (pl.dl[d] == l[s] && pl.docc[d] == pl.occ[s]) { pl.did[s] = d; break; }      // same l and same length = same interval
+                    }
                 }
             } else {
                 for (uint64_t s : order) { pl.did[s] = (uint32_t)pl.dl.size(); pl.dl.push_back(l[s]); pl.docc.push_back(pl.occ[s]); }
             }
         }
-        tr.mark("backward search + plan");
+        tr.mark("intervals to host + plan");
         const uint64_t pos_bytes = idx->hdr.sample_bytes;
         vlg_status s = (pos_bytes == 4) ? run_batch<uint32_t>(idx, q, ws, res, pl, d_stats) : run_batch<uint64_t>(idx, q, ws, res, pl, d_stats);
         if (s) return s;
