@@ -1695,12 +1695,21 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __rest
         const uint64_t len = sg.pend - sg.pbegin;
         const uint64_t off0 = (run - task_run0[t]) * kRun;
         const uint64_t off1 = off0 + kRun < len ? off0 + kRun : len;
-        uint32_t out = run_off[run];
-        for (uint64_t base = off0; base < off1; base += 64) {
-            const uint64_t bits = abits[(sg.abit + base) >> 6];
-            if (!bits) continue;
-            if ((bits >> lane) & 1) Pc[out + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull))] = P[sg.pbegin + base + lane];
-            out += (uint32_t)__popcll(bits);
+        // the 32 activity words of the run in one load; every lane then knows where each word's survivors go
+        const uint64_t w0 = (sg.abit + off0) >> 6;
+        const uint32_t nw = (uint32_t)((off1 - off0 + 63) >> 6);
+        const uint64_t mine = lane < nw ? abits[w0 + lane] : 0;
+        uint32_t before = (uint32_t)__popcll(mine);                              // inclusive scan over the words
+        for (int o = 1; o < 32; o <<= 1) { const uint32_t v = __shfl_up(before, o); if ((int)lane >= o) before += v; }
+        before -= (uint32_t)__popcll(mine);
+        const uint32_t out0 = run_off[run];
+        unsigned long long todo_w = __ballot(mine != 0);
+        while (todo_w) {
+            const int wi = __ffsll((long long)todo_w) - 1;
+            todo_w &= todo_w - 1;
+            const uint64_t bits = __shfl(mine, wi);
+            const uint32_t out = out0 + __shfl(before, wi);
+            if ((bits >> lane) & 1) Pc[out + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull))] = P[sg.pbegin + off0 + 64ull * wi + lane];
         }
     }
 }
@@ -2513,6 +2522,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
     std::vector<uint32_t> poff(pl.dl.size(), 0);
     uint64_t Q0 = 0;
     uint32_t epoch = 0;
+    PhaseTrace tr(ws->stream);
     while (Q0 < q->nq) {
         // ---- choose the super-chunk ----------------------------------------------------------------
         std::vector<uint32_t> dlist;
@@ -2608,7 +2618,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         Arena A{ws->arena, ws->arena_bytes};
         pos_t* P = nullptr;
         uint64_t Tphys = 0;
-        PhaseTrace tr(ws->stream);
+        tr.mark("plan super-chunk");
         pos_t* Pc = nullptr;
         uint64_t pc_cap = 0;
         if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap)) return s;
@@ -2680,6 +2690,10 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
     uint64_t* d_r = nullptr;
     unsigned long long* d_stats = nullptr;
     PhaseTrace tr(st);
+    static std::chrono::steady_clock::time_point last_end;
+    if (tr.on && last_end.time_since_epoch().count())
+        fprintf(stderr, "[vlg trace] %-28s %9.3f ms\n", "(between two batches)",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - last_end).count());
     auto run = [&]() -> vlg_status {
         const uint64_t nsub = q->nsub;
         VLG_HIP_TRY(hipMalloc((void**)&d_l, (nsub + 1) * 8));
@@ -2755,9 +2769,12 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         return VLG_OK;
     };
     vlg_status stt = run();
+    tr.mark("statistics");
     if (d_l) (void)hipFree(d_l);
     if (d_r) (void)hipFree(d_r);
     if (d_stats) (void)hipFree(d_stats);
+    tr.mark("free");
+    last_end = std::chrono::steady_clock::now();
     if (stt) { vlg_result_destroy(res); return stt; }
     *out = res;
     return VLG_OK;
