@@ -626,6 +626,16 @@ def test_64bit_position_kernels(torch_cuda, V, oracle, monkeypatch):
             assert res.tuples(i).tolist() == o.search(q, stats=occ).tolist(), (q, lazy, sweep_min)
         assert res.summary["logical_occurrences"] == int(occ[0]) == res.summary["located_occurrences"]
         assert res.summary["lf_steps"] == int(occ[1]) and res.summary["wt_levels_locate"] == int(occ[2])
+    # the batch-level shortcuts on 64-bit positions: shared intervals, shared LF trails, one-pass sort, window filter (both modes)
+    want = [o.search(q).tolist() for q in qs]
+    for pivot in (1, 0):
+        ws = Workspace()
+        for k_, v_ in (("sweep_min", 1), ("sweep_tail", 16), ("global_sort_min", 1), ("filter_min", 0), ("filter_pivot", pivot)):
+            ws.set_option(k_, v_)
+        res = idx.search(qs, workspace=ws)
+        assert ws.kernel_stats()["filter_compact"]["launches"] > 0 and ws.kernel_stats()["locate_resolve"]["launches"] > 0
+        for i in range(len(qs)):
+            assert res.tuples(i).tolist() == want[i], (qs[i], pivot)
     # csa[i] through the 64-bit locate kernel, and the rrr variant on top of it
     L = V.lib()
     ii = rng.integers(0, o.n, 20000).astype(np.uint64)

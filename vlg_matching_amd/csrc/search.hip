@@ -1252,7 +1252,7 @@ __global__ void sort_narrow_kernel(const uint64_t* __restrict__ keys, uint64_t t
 template <typename pos_t>
 vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* res, const std::vector<uint32_t>& dlist /* distinct ids */,
                           const Plan& pl, Arena& A, pos_t*& P_out, std::vector<uint32_t>& poff /* per distinct id -> offset (size dl) */,
-                          uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats, pos_t*& Pc_out, uint64_t& pc_cap)
+                          uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats, pos_t*& Pc_out, uint64_t& pc_cap, bool share_trails)
 {
     hipStream_t st = ws->stream;
     const uint32_t nd = (uint32_t)dlist.size();
@@ -1289,7 +1289,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         const uint64_t cap = std::min<uint64_t>(acc, sweep_batch_max<pos_t>());
         uint64_t* trail = nullptr;
         uint64_t* rec = nullptr;
-        if (ws->trail && ws->dedup && acc <= sweep_batch_max<pos_t>()) {          // (trails are shared inside one sweep)
+        if (share_trails) {                                                       // (trails are shared inside one sweep)
             trail = A.take<uint64_t>(idx->hdr.n);
             rec = A.take<uint64_t>(acc);
             if (!trail || !rec) return fail(VLG_E_INTERNAL, "arena carve failed (trail table)");
@@ -2586,7 +2586,10 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             }
         }
         const bool will_sweep = ws->sweep && phys >= ws->sweep_min;
-        const uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup ? (idx->hdr.n + phys) * 8 + 512 : 0;
+        // the trail table (8 B per text position) and the records (8 B per occurrence) must leave most of the workspace to the rest
+        uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup ? (idx->hdr.n + phys) * 8 + 512 : 0;
+        if (trail_bytes > budget / 4) trail_bytes = 0;
+        const bool share_trails = trail_bytes != 0;
         const uint64_t phys_bytes = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20) + trail_bytes;
         const uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
         // window filter: state of the filtered queries of a group (at most a third of the budget), dropped query by query if it
@@ -2621,7 +2624,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         tr.mark("plan super-chunk");
         pos_t* Pc = nullptr;
         uint64_t pc_cap = 0;
-        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap)) return s;
+        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, share_trails)) return s;
         tr.mark("locate + sort");
         // ---- groups of queries that share one run of the filter; join chunks inside a group -------------------
         uint64_t g0 = Q0;
