@@ -25,10 +25,15 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 
 # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/*_pmc_*.csv; FETCH_SIZE + WRITE_SIZE,
 # KiB -> bytes); filled in by tools/pmc_summary.py.  None = not measured for that kernel.
-PMC_TRAFFIC = {}
+PMC_TRAFFIC, PMC_DETAIL = {}, {}
 try:
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as _f:
-        PMC_TRAFFIC = {k: v["bytes_per_launch"] for k, v in json.load(_f).items()}
+        for _k, _v in json.load(_f).items():
+            PMC_TRAFFIC[_k] = _v["bytes_per_launch"]
+            # FETCH_SIZE is exact for the 64-byte requests of block reads (tools/k1_bench.py) and reads half of a wide
+            # coalesced streaming read on gfx950 (MI355X_MICROARCH.md, HBM): both readings are kept next to the raw sum
+            PMC_DETAIL[_k] = {"read_raw": _v["read_bytes_per_launch_raw"], "read_if_all_wide_streaming": _v["read_bytes_per_launch_x2_if_streaming"],
+                              "write": _v["write_bytes_per_launch"], "source": "profiles/pmc_traffic.json (" + _v.get("tag", "") + ")"}
 except Exception:
     pass
 
@@ -229,11 +234,12 @@ def main():
             alg = st["algorithmic_bytes"] / launches
             ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {"bound": "hbm", "kernel": kernel, "kernel_class": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC.get(kernel), "algorithmic_bytes_per_launch": alg,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC.get(kernel), "traffic_detail": PMC_DETAIL.get(kernel),
+                    "algorithmic_bytes_per_launch": alg,
                     "avg_launch_ms": ms, "launches": st["launches"], "ms_per_step": st["total_ms"] / args.steps}
         names = {"locate": "sweep_step_kernel" if kstats["locate_partition"]["launches"] else "locate_kernel",
                  "join_link": "join_link_kernel", "join_init": "join_init_kernel", "join_scan": "rocprim scan (reverse min)", "join_chain": "join_jump+chain_tiles/walk/emit",
-                 "gather": "join_gather_kernel", "sort": "rocprim segmented_radix_sort", "locate_partition": "rocprim radix_sort_pairs",
+                 "gather": "join_gather_kernel", "sort": "rocprim radix_sort_keys on (list, position) keys", "locate_partition": "rocprim radix_sort_pairs",
                  "backward_search": "backward_search_kernel", "expand": "expand_kernel", "filter_pass": "filter_pass_kernel",
                  "filter_pivot": "filter_pivot_kernel", "filter_compact": "filter_count_runs + scan + filter_compact_kernel",
                  "locate_resolve": "trail_resolve_kernel"}

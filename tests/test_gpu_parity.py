@@ -456,6 +456,30 @@ def test_window_filter_equals_unfiltered_join_and_oracle(V, oracle, name, seed, 
             assert (x == y).all()
 
 
+@pytest.mark.parametrize("pivot", [1, 0])
+def test_window_filter_extreme_gaps(V, oracle, pivot):
+    """Windows wider than the text, windows that start beyond it, exact-distance windows, many sub-patterns."""
+    from vlg_matching_amd.index import Workspace
+    text = TEXTS["dna_50k"]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    t = text.decode()
+    a, b, c = t[100:104], t[30000:30003], t[49000:49005]
+    qs = [a + ".{0,100000000}?" + b, a + ".{0,4000000000000000000}?" + b + ".{0,7}?" + c, a + ".{60000,70000}?" + b,
+          a + ".{29890,29900}?" + b, b + ".{18990,19005}?" + c, "A.{0,0}?C.{0,0}?G", "AC.{5,5}?GT.{5,5}?AC.{5,5}?GT",
+          ".{1,2}?".join(["A", "C", "G", "T"] * 8), "T.{49990,49999}?A", c + ".{0,3}?" + a, a + ".{0,49999}?" + a + ".{0,49999}?" + a]
+    ws_n, ws_f = Workspace(), Workspace()
+    ws_n.set_option("filter", 0)
+    ws_f.set_option("filter_min", 0)
+    ws_f.set_option("filter_pivot", pivot)
+    ra, rb = idx.search(qs, workspace=ws_n), idx.search(qs, workspace=ws_f)
+    assert ws_f.kernel_stats()["filter_compact"]["launches"] > 0
+    for i, q in enumerate(qs):
+        want = o.search(q).tolist()
+        assert ra.tuples(i).tolist() == want, q
+        assert rb.tuples(i).tolist() == want, q
+
+
 def test_join_many_tiles_single_pattern(V, oracle):
     """k = 1 and k = 2 on a list spanning many tiles (non-overlap chains cross tile borders all the time)."""
     text = (b"ab" * 30000) + dna_text(5000, 3).tobytes() + (b"aab" * 9000)
