@@ -123,6 +123,13 @@ vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out
 vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* info);
 void vlg_index_destroy(vlg_index* idx);
 
+/* ISA samples as csa_wt keeps them (include/sdsl/csa_sampling_strategy.hpp:626-642): h_out[j] = the SA index i with SA[i] = j * inv_dens,
+ * count = (n-1)/inv_dens + 1.  Computed from the index alone by walking LF from every SA sample. */
+vlg_status vlg_index_isa_samples(const vlg_index* idx, uint32_t inv_dens, uint64_t* h_out, uint64_t count);
+/* Store the index in the reference's on-disk format of csa_wt<wt_huff<>,32,64> (csa_wt.hpp:374-393) so that stock sdsl
+ * can load_from_file() it: wavelet tree with rank_support_v and both select_support_mcl, SA samples, ISA samples (density
+ * 64), byte_alphabet.  The index must be a plain one with SA sample density 32. */
+vlg_status vlg_index_save_sdsl(const vlg_index* idx, const char* path);
 /* Load an index stored by stock sdsl: the file written by `store_to_file(csa, file)` / `csa.serialize(out)` for
  * csa_wt<wt_huff<>, t_dens, t_inv_dens> with the default sampling strategies and byte_alphabet
  * (include/sdsl/csa_wt.hpp:374-393; member formats: wt_pc.hpp:638-652, int_vector.hpp:584-600, rank_support_v.hpp:134-148,

@@ -140,6 +140,8 @@ def ref():
         R.vref_lf.restype = C.c_uint64
         R.vref_write_csa_image.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
         R.vref_write_csa_image.restype = C.c_int
+        R.vref_check_csa_image.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        R.vref_check_csa_image.restype = C.c_int
         R.vref_bitrank.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         R.vref_rank_v_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         R.vref_rank_v_blocks.restype = C.c_uint64
@@ -389,6 +391,14 @@ class RefIndex:
         s = np.ascontiguousarray(sa, dtype=np.uint64)
         rc = ref().vref_write_csa_image(self.h, str(path).encode(), s.ctypes.data, len(s))
         assert rc == 0
+
+
+def ref_check_csa_image(path, bwt, sa, step=1):
+    """Load a csa_wt<wt_huff<>,32,64> file member by member with the reference's own load() functions and check access, rank,
+    inverse_select, select, both sample vectors and the alphabet against the BWT / SA given.  0 = all good."""
+    b = _np_u8(bwt)
+    s = np.ascontiguousarray(sa, dtype=np.uint64)
+    return int(ref().vref_check_csa_image(str(path).encode(), b.ctypes.data, s.ctypes.data, len(b), int(step)))
 
 
 def ref_bitrank(words, nbits, variant, idx):

@@ -260,4 +260,58 @@ uint64_t vref_rank_v_blocks(const uint64_t* words, uint64_t nbits, uint64_t* out
     return nw;
 }
 
+// Loads a csa_wt<wt_huff<>,32,64> file image member by member with the reference's own load() functions (wt_huff incl. its
+// rank_support_v and both select_support_mcl, int_vector<> samples, byte_alphabet) and checks it against the truth handed
+// in (BWT and SA of the text): access, rank, select through the loaded structures, both sample vectors, the alphabet.
+// Returns 0 if everything agrees, otherwise a code telling which check failed first.
+int vref_check_csa_image(const char* path, const uint8_t* bwt, const uint64_t* sa, uint64_t n, uint64_t step)
+{
+    try {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) return 1;
+        wt_v wt;
+        wt.load(in);
+        int_vector<> sa_sample, isa_sample;
+        sa_sample.load(in);
+        isa_sample.load(in);
+        byte_alphabet alpha;
+        alpha.load(in);
+        if (!in) return 2;
+        in.peek();
+        if (!in.eof()) return 3;                                        // trailing bytes
+        if (wt.size() != n) return 10;
+        if (step == 0) step = 1;
+        // access + rank
+        std::vector<uint64_t> cnt(256, 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (i % step == 0) {
+                if (wt[i] != bwt[i]) return 11;
+                if (wt.rank(i, bwt[i]) != cnt[bwt[i]]) return 12;
+                auto is = wt.inverse_select(i);
+                if (is.second != bwt[i] || is.first != cnt[bwt[i]]) return 13;
+            }
+            ++cnt[bwt[i]];
+            // select through select_support_mcl of the concatenated bit-vector (wt_pc::select)
+            if (i % step == 0 && wt.select(cnt[bwt[i]], bwt[i]) != i) return 14;
+        }
+        // samples
+        if (sa_sample.size() != (n + 31) / 32) return 20;
+        for (uint64_t j = 0; j < sa_sample.size(); ++j) if (sa_sample[j] != sa[32 * j]) return 21;
+        if (isa_sample.size() != (n - 1) / 64 + 1) return 22;
+        for (uint64_t j = 0; j < isa_sample.size(); ++j) if (isa_sample[j] >= n || sa[isa_sample[j]] != 64 * j) return 23;
+        if (sa_sample.width() != bits::hi(n) + 1 || isa_sample.width() != bits::hi(n) + 1) return 24;
+        // alphabet
+        uint64_t sigma = 0;
+        for (int c = 0; c < 256; ++c) if (cnt[c]) {
+            if (alpha.char2comp[c] != sigma || alpha.comp2char[sigma] != c) return 30;
+            if (alpha.C[sigma + 1] - alpha.C[sigma] != cnt[c]) return 31;
+            ++sigma;
+        }
+        if (alpha.sigma != sigma || alpha.C[sigma] != n) return 32;
+        return 0;
+    } catch (...) {
+        return 99;
+    }
+}
+
 } // extern "C"

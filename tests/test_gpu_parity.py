@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from util import dna_text, skewed_text
+from util import bwt_from_sa, dna_text, skewed_text
 
 pytestmark = pytest.mark.gpu
 
@@ -621,6 +621,35 @@ def test_load_index_stored_by_stock_sdsl(V, refmod, tmp_path):
     res = idx.search(qs)
     for i, q in enumerate(qs):
         assert res.tuples(i).tolist() == o.search(q).tolist(), q
+
+
+@pytest.mark.parametrize("name", ["abracadabra", "one_byte", "100a", "all_symbols", "dna_20k", "dna_50k", "zipf40"])
+def test_save_sdsl_is_loadable_by_the_reference(V, oracle, refmod, tmp_path, name):
+    """SURVEY 8f-2, the writer: a device-built index stored with vlg_index_save_sdsl is (a) loaded member by member by the
+    reference's own load() functions and answers access / rank / inverse_select / select / samples / alphabet correctly,
+    (b) byte-identical to the image the reference's serialize() functions write where the reference builds its select
+    structures the same way (bit-vectors below 100 000 bits), (c) read back by vlg_index_load_sdsl into the same index."""
+    text = dna_text(20000, 5).tobytes() if name == "dna_20k" else TEXTS[name]()
+    tz = np.frombuffer(text + b"\0", np.uint8)
+    sa = oracle.suffix_array(tz)
+    bwt = bwt_from_sa(tz, sa)
+    idx = V.VlgIndex.build(text)
+    path = tmp_path / "gpu.sdsl"
+    idx.save_sdsl(path)
+    assert oracle.ref_check_csa_image(path, bwt, sa, step=1 if len(tz) <= 30000 else 7) == 0
+    isa = idx.isa_samples(64)
+    assert (sa[isa.astype(np.int64)] == 64 * np.arange(len(isa), dtype=np.uint64)).all()
+    ref_path = tmp_path / "ref.sdsl"
+    R = oracle.RefIndex(bwt, sa, 0)
+    R.write_csa_image(ref_path, sa)
+    if R.bv_size() < 100000:
+        assert open(path, "rb").read() == open(ref_path, "rb").read()
+    back = V.VlgIndex.load_sdsl(path)
+    assert_parts_equal(back.export_parts(), idx.export_parts())
+    qs = random_queries(text, np.random.default_rng(3), 40, kmax=3, mmax=3) if len(text) > 30 else [text[:1].decode("latin-1")]
+    a, b = idx.search(qs), back.search(qs)
+    for x, y in zip(a.fetch(), b.fetch()):
+        assert (x == y).all()
 
 
 def test_64bit_position_kernels(torch_cuda, V, oracle, monkeypatch):

@@ -704,6 +704,37 @@ __global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict
     if ((threadIdx.x & 63) == 0 && open) atomicAdd(n_open, (unsigned long long)open);
 }
 
+// ISA samples (csa_sampling_strategy.hpp:626-642: isa_sample[SA[i] / d'] = i for every i with SA[i] % d' == 0), computed from the
+// index alone: a lane starts at one SA sample (i, SA[i]) and walks LF -- (LF(i), SA[i] - 1) -- until the next sampled
+// index, so every SA index is visited exactly once and every text position passes by with its SA index.
+template <class BV, typename pos_t>
+__global__ void __launch_bounds__(256) isa_samples_kernel(IndexView iv, uint32_t inv_dens, uint64_t* __restrict__ out)
+{
+    __shared__ WalkLds<BV> s;
+    stage_walk(s, iv);
+    const pos_t* samples = reinterpret_cast<const pos_t*>(iv.samples);
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < iv.n_samples; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t i = j * iv.dens, v = samples[j];
+        do {
+            if (v % inv_dens == 0) out[v / inv_dens] = i;
+            uint32_t node = 0, c;
+            uint64_t pos = i;
+            for (;;) {                                       // inverse_select: wt_pc.hpp:385-402
+                const DNode nd = s.nodes[node];
+                uint32_t bit;
+                uint64_t r1;
+                BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
+                pos = bit ? r1 : pos - r1;
+                const uint32_t ch = nd.child[bit];
+                if (ch & kLeafFlag) { c = ch & ~kLeafFlag; break; }
+                node = ch;
+            }
+            i = s.C[c] + pos;                                // LF
+            v = v ? v - 1 : iv.n - 1;
+        } while (i % iv.dens);
+    }
+}
+
 template <typename pos_t>
 __global__ void widen_kernel(const pos_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t count)
 {
@@ -936,6 +967,27 @@ extern "C" vlg_status vlg_locate_batch(const vlg_index* idx, const uint64_t* d_l
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(tmp);
     if (s2) return s2;
+    VLG_HIP_TRY(e);
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_index_isa_samples(const vlg_index* idx, uint32_t inv_dens, uint64_t* h_out, uint64_t count)
+{
+    if (!idx || !h_out || !inv_dens) return fail(VLG_E_INVALID, "null argument");
+    const uint64_t n = idx->hdr.n;
+    if (count != (n - 1) / inv_dens + 1) return fail(VLG_E_INVALID, "ISA sample count must be (n-1)/inv_dens + 1");
+    uint64_t* d_out = nullptr;
+    VLG_HIP_TRY(hipMalloc((void**)&d_out, count * 8));
+    VLG_HIP_TRY(hipMemset(d_out, 0, count * 8));
+    const dim3 grid(grid_for(idx->view.n_samples, 8192));
+    const bool rrr = idx->view.bv_kind == kBvRrr63, wide = idx->hdr.sample_bytes == 8;
+    if (rrr && wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(isa_samples_kernel<RrrBV, uint64_t>), grid, dim3(256), 0, nullptr, idx->view, inv_dens, d_out);
+    else if (rrr) hipLaunchKernelGGL(HIP_KERNEL_NAME(isa_samples_kernel<RrrBV, uint32_t>), grid, dim3(256), 0, nullptr, idx->view, inv_dens, d_out);
+    else if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(isa_samples_kernel<PlainBV, uint64_t>), grid, dim3(256), 0, nullptr, idx->view, inv_dens, d_out);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(isa_samples_kernel<PlainBV, uint32_t>), grid, dim3(256), 0, nullptr, idx->view, inv_dens, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(h_out, d_out, count * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
     VLG_HIP_TRY(e);
     return VLG_OK;
 }

@@ -159,3 +159,176 @@ extern "C" vlg_status vlg_index_load_sdsl(const char* path, uint32_t sa_sample_d
     vlg_sdsl_file_close(f);
     return st;
 }
+
+// =============================================================================================
+// Writer: the same format, so that stock sdsl can `load_from_file(csa, path)` an index built on the device.
+//   rank_support_v<1,1>     include/sdsl/rank_support_v.hpp:67-106      (interleaved absolute / 7 x 9-bit relative counts)
+//   select_support_mcl<b,1> include/sdsl/select_support_mcl.hpp:203-262 (the structure init_slow builds; load() and
+//                           select() accept it whatever size the vector has -- the reference's init_fast, used from
+//                           100 000 bits on, differs only in where it draws the long/mini line for some super-blocks)
+//   _isa_sampling           include/sdsl/csa_sampling_strategy.hpp:626-642, density 64 (csa_wt's default t_inv_dens)
+// =============================================================================================
+extern "C" vlg_status vlg_index_isa_samples(const vlg_index* idx, uint32_t inv_dens, uint64_t* h_out, uint64_t count);
+
+namespace {
+
+struct Sink {
+    FILE* fp; bool ok = true;
+    void raw(const void* p, size_t bytes) { if (ok && bytes && fwrite(p, 1, bytes, fp) != bytes) ok = false; }
+    template <class T> void put(T v) { raw(&v, sizeof v); }
+    // int_vector<w>: u64 size in bits [, u8 width when w == 0], ceil(bits/64) words (int_vector.hpp:584-600,1507-1557)
+    void int_vector_packed(const std::vector<uint64_t>& values, uint8_t width, bool width_in_stream)
+    {
+        const uint64_t bits = (uint64_t)values.size() * width;
+        std::vector<uint64_t> words((bits + 63) / 64, 0);
+        for (uint64_t i = 0; i < values.size(); ++i) {
+            const uint64_t bit = i * width, w = bit >> 6, o = bit & 63;
+            const uint64_t v = width == 64 ? values[i] : (values[i] & ((1ull << width) - 1));
+            words[w] |= v << o;
+            if (o + width > 64) words[w + 1] |= v >> (64 - o);
+        }
+        put<uint64_t>(bits);
+        if (width_in_stream) put<uint8_t>(width);
+        raw(words.data(), words.size() * 8);
+    }
+    void bit_vector_words(const uint64_t* words, uint64_t bits) { put<uint64_t>(bits); raw(words, ((bits + 63) / 64) * 8); }
+};
+
+inline uint32_t hi_bit(uint64_t x) { return x ? 63 - (uint32_t)__builtin_clzll(x) : 0; }      // bits::hi
+
+inline bool bit_at(const uint64_t* w, uint64_t i) { return (w[i >> 6] >> (i & 63)) & 1; }
+
+// rank_support_v<1,1>(&bv): the int_vector<64> m_basic_block
+void write_rank_support_v(Sink& out, const uint64_t* data, uint64_t bits)
+{
+    std::vector<uint64_t> bb;
+    if (bits == 0) { bb.assign(2, 0); out.int_vector_packed(bb, 64, false); return; }
+    const uint64_t cap_words = (bits + 63) / 64;                      // capacity() >> 6
+    bb.assign((((cap_words * 64) >> 9) + 1) << 1, 0);
+    uint64_t i, j = 0, sum = (uint64_t)__builtin_popcountll(data[0]), second = 0;
+    for (i = 1; i < cap_words; ++i) {
+        if (!(i & 7)) { j += 2; bb[j - 1] = second; bb[j] = bb[j - 2] + sum; second = sum = 0; }
+        else second |= sum << (63 - 9 * (i & 7));
+        sum += (uint64_t)__builtin_popcountll(data[i]);
+    }
+    if (i & 7) { second |= sum << (63 - 9 * (i & 7)); bb[j + 1] = second; }
+    else { j += 2; bb[j - 1] = second; bb[j] = bb[j - 2] + sum; bb[j + 1] = 0; }
+    out.int_vector_packed(bb, 64, false);
+}
+
+// select_support_mcl<b,1>: arg count, super-block starts, mini_or_long flags, then per super-block either the 4096 positions
+// (long) or the offsets of every 64th argument (mini)
+void write_select_mcl(Sink& out, const uint64_t* data, uint64_t bits, bool ones)
+{
+    const uint64_t kSuper = 4096;
+    uint64_t arg_cnt = 0;
+    for (uint64_t w = 0; w < (bits + 63) / 64; ++w) {
+        uint64_t x = ones ? data[w] : ~data[w];
+        if (w == (bits + 63) / 64 - 1 && (bits & 63)) x &= (1ull << (bits & 63)) - 1;
+        arg_cnt += (uint64_t)__builtin_popcountll(x);
+    }
+    out.put<uint64_t>(arg_cnt);
+    if (!arg_cnt) return;
+    const uint64_t capacity = ((bits + 63) / 64) * 64;
+    const uint64_t logn = hi_bit(capacity) + 1, logn4 = logn * logn * logn * logn;
+    const uint64_t sb = (arg_cnt + kSuper - 1) / kSuper;
+    std::vector<uint64_t> superblock(sb, 0);
+    std::vector<uint8_t> is_mini(sb, 0);
+    std::vector<std::vector<uint64_t>> payload(sb);
+    std::vector<uint8_t> payload_width(sb, 0);
+    bool any_long = false;
+    std::vector<uint64_t> pos(kSuper);
+    uint64_t cnt = 0, sbi = 0;
+    for (uint64_t i = 0; i < bits; ++i) {
+        if (bit_at(data, i) != ones) continue;
+        pos[cnt % kSuper] = i;
+        ++cnt;
+        if (cnt % kSuper == 0 || cnt == arg_cnt) {
+            const uint64_t last = (cnt - 1) % kSuper;
+            superblock[sbi] = pos[0];
+            const uint64_t diff = pos[last] - pos[0];
+            if (diff > logn4) {                                       // long: every position, 4096 entries of hi(last position)+1 bits
+                any_long = true;
+                payload_width[sbi] = (uint8_t)(hi_bit(pos[last]) + 1);
+                payload[sbi].assign(kSuper, 0);
+                for (uint64_t j = 0; j <= last; ++j) payload[sbi][j] = pos[j];
+            } else {                                                  // mini: offset of every 64th argument, 64 entries
+                is_mini[sbi] = 1;
+                payload_width[sbi] = (uint8_t)(hi_bit(diff) + 1);
+                payload[sbi].assign(64, 0);
+                for (uint64_t j = 0; j <= last; j += 64) payload[sbi][j / 64] = pos[j] - pos[0];
+            }
+            ++sbi;
+        }
+    }
+    out.int_vector_packed(superblock, (uint8_t)logn, true);
+    {   // mini_or_long: empty unless some super-block is long
+        std::vector<uint64_t> flags(any_long ? (sb + 63) / 64 : 0, 0);
+        if (any_long) for (uint64_t i = 0; i < sb; ++i) if (is_mini[i]) flags[i >> 6] |= 1ull << (i & 63);
+        out.bit_vector_words(flags.data(), any_long ? sb : 0);
+    }
+    for (uint64_t i = 0; i < sb; ++i) out.int_vector_packed(payload[i], payload_width[i], true);
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_index_save_sdsl(const vlg_index* idx, const char* path)
+{
+    using namespace vlg;
+    if (!idx || !path) return fail(VLG_E_INVALID, "null argument");
+    vlg_index_parts sz;
+    if (vlg_status st = vlg_index_export_parts(idx, &sz, nullptr)) return st;
+    if (sz.sa_sample_dens != 32) return fail(VLG_E_UNSUPPORTED, "the reference type csa_wt<wt_huff<>,32,64> has SA sample density 32");
+    uint8_t c2c[256];
+    std::vector<uint64_t> C(257), bv((sz.bv_bits + 63) / 64 + 1, 0), samples(sz.n_samples);
+    std::vector<vlg_wt_node> nodes(sz.n_nodes);
+    vlg_index_parts_out po{c2c, C.data(), bv.data(), nodes.data(), samples.data()};
+    if (vlg_status st = vlg_index_export_parts(idx, &sz, &po)) return st;
+    const uint64_t n = sz.n, inv_dens = 64;
+    std::vector<uint64_t> isa((n - 1) / inv_dens + 1);
+    if (vlg_status st = vlg_index_isa_samples(idx, (uint32_t)inv_dens, isa.data(), isa.size())) return st;
+    const HostTree& tree = idx->tree;
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return fail(VLG_E_INVALID, std::string("cannot create ") + path);
+    Sink out{fp};
+    // ---- wt_pc::serialize (wt_pc.hpp:638-652) -----------------------------------------------------------
+    out.put<uint64_t>(n);
+    out.put<uint64_t>(sz.sigma);
+    out.bit_vector_words(bv.data(), sz.bv_bits);
+    write_rank_support_v(out, bv.data(), sz.bv_bits);
+    write_select_mcl(out, bv.data(), sz.bv_bits, true);
+    write_select_mcl(out, bv.data(), sz.bv_bits, false);
+    out.put<uint64_t>(sz.n_nodes);
+    uint16_t c_to_leaf[256];
+    for (int c = 0; c < 256; ++c) c_to_leaf[c] = 0xFFFF;
+    for (uint32_t v = 0; v < sz.n_nodes; ++v) {
+        out.put<uint64_t>(nodes[v].bv_pos); out.put<uint64_t>(nodes[v].bv_pos_rank);
+        out.put<uint16_t>(nodes[v].parent); out.put<uint16_t>(nodes[v].child[0]); out.put<uint16_t>(nodes[v].child[1]);
+        if (nodes[v].child[0] == 0xFFFF) c_to_leaf[nodes[v].bv_pos_rank & 0xFF] = (uint16_t)v;
+    }
+    out.raw(c_to_leaf, sizeof c_to_leaf);
+    out.raw(tree.paths.data(), 256 * 8);
+    // ---- SA samples, ISA samples: int_vector<0> of width hi(n)+1 (csa_sampling_strategy.hpp:85-98, 626-642) ------------
+    const uint8_t w = (uint8_t)(hi_bit(n) + 1);
+    out.int_vector_packed(samples, w, true);
+    out.int_vector_packed(isa, w, true);
+    // ---- byte_alphabet (lib/csa_alphabet_strategy.cpp:103-112) -------------------------------------------------
+    {
+        std::vector<uint64_t> v(256);
+        for (int c = 0; c < 256; ++c) v[c] = c2c[c];
+        out.int_vector_packed(v, 8, false);
+        // comp2char: comp ranks are assigned in byte order (lib/csa_alphabet_strategy.cpp:43-49), so it is the sorted list of
+        // the occurring bytes; bytes that do not occur map to 0 in char2comp like the sentinel
+        std::vector<uint64_t> occurring;
+        occurring.push_back(0);
+        for (int c = 1; c < 256; ++c) if (c2c[c]) occurring.push_back(c);
+        if (occurring.size() != sz.sigma) { fclose(fp); return fail(VLG_E_INTERNAL, "alphabet does not match sigma"); }
+        out.int_vector_packed(occurring, 8, false);
+        std::vector<uint64_t> Cv(C.begin(), C.begin() + sz.sigma + 1);
+        out.int_vector_packed(Cv, 64, false);
+        out.put<uint16_t>((uint16_t)sz.sigma);
+    }
+    const bool ok = out.ok;
+    if (fclose(fp) != 0 || !ok) return fail(VLG_E_INVALID, std::string("write failed: ") + path);
+    return VLG_OK;
+}

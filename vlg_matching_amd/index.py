@@ -225,6 +225,17 @@ class VlgIndex:
         check(lib().vlg_index_load_sdsl(str(path).encode(), dens, C.byref(h)))
         return cls(h)
 
+    def save_sdsl(self, path):
+        """Store in the reference's on-disk format of csa_wt<wt_huff<>,32,64> (stock sdsl can load_from_file it)."""
+        check(lib().vlg_index_save_sdsl(self._h, str(path).encode()))
+
+    def isa_samples(self, inv_dens=64):
+        """isa_sample of csa_wt: out[j] = SA index of text position j * inv_dens."""
+        n = self.info()["n"]
+        out = np.zeros((n - 1) // inv_dens + 1, dtype=np.uint64)
+        check(lib().vlg_index_isa_samples(self._h, inv_dens, out.ctypes.data, len(out)))
+        return out
+
     @classmethod
     def attach_blob(cls, d_ptr, nbytes, keep=None):
         h = C.c_void_p()
