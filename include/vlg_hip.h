@@ -123,6 +123,9 @@ vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out
 vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* info);
 void vlg_index_destroy(vlg_index* idx);
 
+/* Suffix array of text + sentinel on the device (what sdsl::construct_sa computes, include/sdsl/construct_sa.hpp:145-170): d_sa
+ * receives n_text + 1 entries, d_sa[0] = n_text.  The same prefix-doubling sorter the index builder uses; n_text < 2^32 - 1. */
+vlg_status vlg_suffix_array_device(const uint8_t* d_text, uint64_t n_text, uint32_t* d_sa, void* stream);
 /* ISA samples as csa_wt keeps them (include/sdsl/csa_sampling_strategy.hpp:626-642): h_out[j] = the SA index i with SA[i] = j * inv_dens,
  * count = (n-1)/inv_dens + 1.  Computed from the index alone by walking LF from every SA sample. */
 vlg_status vlg_index_isa_samples(const vlg_index* idx, uint32_t inv_dens, uint64_t* h_out, uint64_t count);

@@ -105,6 +105,10 @@ def lib():
         L.vlgo_join.restype = C.c_uint64
         L.vlgo_search.argtypes = [C.c_void_p, C.POINTER(Query), C.c_void_p, C.c_uint64, C.c_void_p]
         L.vlgo_search.restype = C.c_uint64
+        L.vlgo_sasearch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(Query), C.c_void_p, C.c_uint64, C.c_void_p]
+        L.vlgo_sasearch.restype = C.c_uint64
+        L.vlgo_sa_forward_search.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.vlgo_sa_forward_search.restype = C.c_uint64
         _LIB = L
     return _LIB
 
@@ -314,6 +318,31 @@ class Index:
         m = lib().vlgo_search(self.h, C.byref(q), None, 0, st.ctypes.data)
         out = np.empty((max(m, 1), q.k), dtype=np.uint64)
         lib().vlgo_search(self.h, C.byref(q), out.ctypes.data, m, None)
+        if stats is not None:
+            stats += st
+        return out[:m]
+
+
+class SaSearch:
+    """The benchmark's SASEARCH index (index_sasearch.hpp): text + plain suffix array, forward_search, sort, join."""
+
+    def __init__(self, text_with_sentinel, sa):
+        self.text = _np_u8(text_with_sentinel)
+        self.sa = np.ascontiguousarray(sa, dtype=np.uint32)
+        assert len(self.text) == len(self.sa)
+
+    def count(self, pat):
+        p = _np_u8(pat)
+        l, r = C.c_uint64(), C.c_uint64()
+        return int(lib().vlgo_sa_forward_search(self.text.ctypes.data, len(self.text), self.sa.ctypes.data, p.ctypes.data, len(p),
+                                                C.byref(l), C.byref(r)))
+
+    def search(self, regexp, dialect=0, stats=None):
+        q = parse(regexp, dialect)
+        st = np.zeros(4, dtype=np.uint64)
+        m = lib().vlgo_sasearch(self.text.ctypes.data, len(self.text), self.sa.ctypes.data, C.byref(q), None, 0, st.ctypes.data)
+        out = np.empty((max(m, 1), q.k), dtype=np.uint64)
+        lib().vlgo_sasearch(self.text.ctypes.data, len(self.text), self.sa.ctypes.data, C.byref(q), out.ctypes.data, m, None)
         if stats is not None:
             stats += st
         return out[:m]

@@ -670,6 +670,65 @@ uint64_t vlgo_search(const vlgo_index* x, const vlgo_query* q, uint64_t* out, ui
 }
 
 /* ------------------------------------------------------------------------------------------
+ * SASEARCH: the benchmark's plain-suffix-array index (benchmark/gapped-matching/include/index_sasearch.hpp:58-118), kept
+ * beside the FM path as the fastest CPU algorithm of the reference (CPU baseline (3)).
+ *   forward_search over text + SA   include/sdsl/suffix_array_algorithm.hpp:48-112  (two binary searches, the pattern
+ *                                    compared with the text suffix, a suffix that ends inside the pattern is smaller)
+ *   copy SA[sp..ep], std::sort, merge join   index_sasearch.hpp:76-116
+ * text: n bytes incl. the sentinel; sa: n entries (32-bit, n <= 2^32).
+ * ---------------------------------------------------------------------------------------- */
+static int sa_compare(const uint8_t* text, uint64_t n, const uint32_t* sa, uint64_t i, const uint8_t* pat, uint64_t m)
+{
+    uint64_t t = sa[i];
+    for (uint64_t j = 0; j < m; ++j, ++t) {
+        if (t == n) return 1;
+        if (text[t] < pat[j]) return 1;
+        if (text[t] > pat[j]) return -1;
+    }
+    return 0;
+}
+
+uint64_t vlgo_sa_forward_search(const uint8_t* text, uint64_t n, const uint32_t* sa, const uint8_t* pat, uint64_t m,
+                                uint64_t* l_res_out, uint64_t* r_res_out)
+{
+    uint64_t l_res = 0, r_res = (uint64_t)0 - 1, l_upper = n, r_upper = n;     /* l = 0, r = n - 1 */
+    if (m >= n) { *l_res_out = 0; *r_res_out = (uint64_t)0 - 1; return 0; }
+    while (l_res < l_upper) {
+        uint64_t sample = l_res + (l_upper - l_res) / 2;
+        if (sa_compare(text, n, sa, sample, pat, m) == 1) l_res = sample + 1; else l_upper = sample;
+    }
+    while (r_res + 1 < r_upper) {
+        uint64_t sample = r_res + (r_upper - r_res) / 2;
+        if (sa_compare(text, n, sa, sample, pat, m) == -1) r_upper = sample; else r_res = sample;
+    }
+    *l_res_out = l_res; *r_res_out = r_res;
+    return r_res - l_res + 1;
+}
+
+uint64_t vlgo_sasearch(const uint8_t* text, uint64_t n, const uint32_t* sa, const vlgo_query* q, uint64_t* out, uint64_t cap,
+                       uint64_t* stats)
+{
+    uint64_t* lists[VLGO_MAX_SUB];
+    uint64_t lens[VLGO_MAX_SUB];
+    uint32_t k = q->k;
+    uint64_t res = 0, st_occ = 0;
+    for (uint32_t i = 0; i < VLGO_MAX_SUB; ++i) { lists[i] = NULL; lens[i] = 0; }
+    for (uint32_t i = 0; i < k; ++i) {                       /* every range is materialised and sorted (index_sasearch.hpp:76-82) */
+        uint64_t sp, ep;
+        uint64_t occ = vlgo_sa_forward_search(text, n, sa, q->sub[i], q->sub_len[i], &sp, &ep);
+        lens[i] = occ;
+        lists[i] = (uint64_t*)malloc(8 * (occ ? occ : 1));
+        for (uint64_t j = 0; j < occ; ++j) lists[i][j] = sa[sp + j];
+        qsort(lists[i], occ, 8, cmp_u64);
+        st_occ += occ;
+    }
+    if (k) res = vlgo_join(k, (const uint64_t* const*)lists, lens, q->lo, q->hi, q->end_len, out, cap);
+    for (uint32_t i = 0; i < k; ++i) free(lists[i]);
+    if (stats) stats[0] += st_occ;
+    return res;
+}
+
+/* ------------------------------------------------------------------------------------------
  * rrr_vector<63> + rank_support_rrr<1,63>  (SURVEY a-11; BASELINE config 5)
  *   ctor    include/sdsl/rrr_vector.hpp:145-237   (block 63 bits, rank/pointer sample every 32 blocks,
  *                                                  per-superblock inversion of the stored classes)

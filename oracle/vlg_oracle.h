@@ -118,6 +118,13 @@ uint64_t vlgo_join(uint32_t k, const uint64_t* const* lists, const uint64_t* len
  * stats (optional, 4 x u64): located occurrences, LF steps, WT levels walked, backward-search ranks */
 uint64_t vlgo_search(const vlgo_index*, const vlgo_query* q, uint64_t* tuples_out, uint64_t cap, uint64_t* stats);
 
+/* SASEARCH (benchmark/gapped-matching/include/index_sasearch.hpp:58-118): plain suffix array + text; forward_search of
+ * suffix_array_algorithm.hpp:48-112, every range copied and sorted, then the same join.  text has n bytes incl. the sentinel. */
+uint64_t vlgo_sa_forward_search(const uint8_t* text, uint64_t n, const uint32_t* sa, const uint8_t* pat, uint64_t m,
+                                uint64_t* l_res, uint64_t* r_res);
+uint64_t vlgo_sasearch(const uint8_t* text, uint64_t n, const uint32_t* sa, const vlgo_query* q, uint64_t* tuples_out, uint64_t cap,
+                       uint64_t* stats);
+
 #ifdef __cplusplus
 }
 #endif

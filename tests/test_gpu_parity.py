@@ -623,6 +623,19 @@ def test_load_index_stored_by_stock_sdsl(V, refmod, tmp_path):
         assert res.tuples(i).tolist() == o.search(q).tolist(), q
 
 
+@pytest.mark.parametrize("name", ["abracadabra", "one_byte", "100a", "all_symbols", "dna_50k", "zipf40"])
+def test_suffix_array_device(torch_cuda, V, oracle, name):
+    """The device suffix sorter on its own (what construct_sa computes): SA of text + sentinel."""
+    torch = torch_cuda
+    text = TEXTS[name]()
+    tz = np.frombuffer(text + b"\0", np.uint8)
+    d_text = torch.from_numpy(np.frombuffer(text, np.uint8).copy()).cuda()
+    d_sa = torch.zeros(len(tz), dtype=torch.int32, device="cuda")
+    V.capi.check(V.lib().vlg_suffix_array_device(d_text.data_ptr(), len(text), d_sa.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert (d_sa.cpu().numpy().view(np.uint32).astype(np.uint64) == oracle.suffix_array(tz)).all()
+
+
 @pytest.mark.parametrize("name", ["abracadabra", "one_byte", "100a", "all_symbols", "dna_20k", "dna_50k", "zipf40"])
 def test_save_sdsl_is_loadable_by_the_reference(V, oracle, refmod, tmp_path, name):
     """SURVEY 8f-2, the writer: a device-built index stored with vlg_index_save_sdsl is (a) loaded member by member by the

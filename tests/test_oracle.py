@@ -198,3 +198,29 @@ def test_from_parts_roundtrip(oracle):
     for q in ["!.{0,9}?\"", "#\"", "!!.{1,30}?!.{0,5}?\""]:
         assert a.search(q).tolist() == b.search(q).tolist()
     assert (a.rank_blocks() == b.rank_blocks()).all()
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_sasearch_restatement_equals_fm_path(oracle, dialect):
+    """The plain-suffix-array index of the benchmark (index_sasearch.hpp) and the FM path answer alike: same SA ranges
+    (forward_search vs backward_search), same matches."""
+    import numpy as np
+    from util import dna_text, skewed_text
+    rng = np.random.default_rng(31)
+    for text in (dna_text(6000, 9).tobytes(), skewed_text(5000, 10).tobytes(), b"a" * 60, b"abracadabrasimsalabim"):
+        tz = np.frombuffer(text + b"\0", np.uint8)
+        sa = oracle.suffix_array(tz)
+        o = oracle.Index.from_text(text)
+        s = oracle.SaSearch(tz, sa)
+        for _ in range(60):
+            k = int(rng.integers(1, 4))
+            subs = []
+            for _ in range(k):
+                a = int(rng.integers(0, len(text) - 1))
+                subs.append(text[a:a + int(rng.integers(1, 4))].decode("latin-1"))
+            assert s.count(subs[0].encode("latin-1")) == o.backward_search(subs[0].encode("latin-1"))[0]
+            lo = int(rng.integers(0, 6))
+            g = ".{%d,%d}%s" % (lo, lo + int(rng.integers(0, 30)), "?" if dialect == 0 else "")
+            q = g.join(subs)
+            assert s.search(q, dialect).tolist() == o.search(q, dialect).tolist(), q
+        assert s.count(b"\xfe") == 0 and s.count(text + b"x") == 0

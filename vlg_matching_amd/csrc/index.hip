@@ -783,7 +783,15 @@ vlg_status sort_pairs(DevBuf& temp, size_t& temp_cap, K* kin, K* kout, V* vin, V
 
 inline uint32_t grid_for(uint64_t n) { return (uint32_t)std::min<uint64_t>((n + 255) / 256, 16384); }
 
-vlg_status build_on_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens, hipStream_t stream, vlg_index** out)
+__global__ void sa_export_kernel(const uint32_t* __restrict__ sa, uint64_t n_text, uint32_t* __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_text; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = i ? sa[i - 1] : (uint32_t)n_text;          // the sentinel suffix sorts first
+}
+
+// d_sa_out (optional): the suffix array of text + sentinel, n_text + 1 entries (needs n_text < 2^32); sa_only: stop there.
+vlg_status build_on_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens, hipStream_t stream, vlg_index** out,
+                           uint32_t* d_sa_out = nullptr, bool sa_only = false)
 {
     const uint64_t n = n_text + 1;
     // The sentinel suffix is the smallest one by definition (SA[0] = n-1), so only the n_text proper suffixes are sorted:
@@ -842,6 +850,12 @@ vlg_status build_on_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens
                 std::swap(sa_cur, sa_other);                   // keys_sorted now holds the sorted keys again
             }
         }
+        if (d_sa_out) {
+            hipLaunchKernelGGL(sa_export_kernel, dim3(g), dim3(256), 0, stream, sa_cur, n_text, d_sa_out);
+            VLG_HIP_TRY(hipGetLastError());
+            VLG_HIP_TRY(hipStreamSynchronize(stream));
+        }
+        if (sa_only) return VLG_OK;
         // free the big sort buffers we no longer need
         (void)hipFree(keys_a.p); keys_a.p = nullptr;
         (void)hipFree(keys_b.p); keys_b.p = nullptr;
@@ -938,12 +952,22 @@ vlg_status build_on_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens
         return VLG_OK;
     };
     vlg_status st = run();
-    if (st) { vlg_index_destroy(idx); return st; }
+    if (st || sa_only) { vlg_index_destroy(idx); return st; }
     *out = idx;
     return VLG_OK;
 }
 
 }  // namespace
+
+extern "C" vlg_status vlg_suffix_array_device(const uint8_t* d_text, uint64_t n_text, uint32_t* d_sa, void* stream)
+{
+    if (!d_sa || (n_text && !d_text)) return fail(VLG_E_INVALID, "null argument");
+    if (n_text >= 0xFFFFFFFFull) return fail(VLG_E_UNSUPPORTED, "32-bit suffix array: text too long");
+    if (vlg_status st = check_device()) return st;
+    release_cached_device_memory();
+    vlg_index* none = nullptr;
+    return build_on_device(d_text, n_text, 32, (hipStream_t)stream, &none, d_sa, true);
+}
 
 extern "C" vlg_status vlg_index_build_device(const uint8_t* d_text, uint64_t n_text, uint32_t dens, void* stream, vlg_index** out)
 {
