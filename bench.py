@@ -240,6 +240,8 @@ def main():
     del text
     q = Queries(queries)                      # parsed + uploaded: resident in HBM before the timed region
     ws = Workspace(int(args.workspace_gb * (1 << 30)))
+    for kv in filter(None, os.environ.get("VLG_BENCH_OPTIONS", "").split(",")):      # development: name=value workspace options
+        ws.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
     def step():
         return idx.search(q, workspace=ws)

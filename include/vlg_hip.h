@@ -297,8 +297,8 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
  * (list, position) keys instead of one segmented sort.
  * "filter" (default 1): before the join drop the list elements whose gap windows hold no element of the neighbouring
  * lists (they are in no match); "filter_min" (default 2^16) = join slots below which a query is joined as it is;
- * "filter_pivot" (default 1): filter outwards from the shortest list of a query when it is >= 32x shorter than all of
- * them together, otherwise (or with 0) by streaming sweeps over block bitmaps.
+ * "filter_pivot" (default 1): filter outwards from the shortest list of a query when it is >= 12x shorter than all of
+ * them together ("filter_pivot_ratio", default 12), otherwise (or with 0) by streaming sweeps over block bitmaps.
  * "lazy_join" (default 0, experimental): follow the match chains lazily with tile speculation (queries of up to 8
  * sub-patterns) instead of the dense passes that evaluate every list element; pays only for sparse lists.
  * Results are identical whatever the options. */

@@ -271,6 +271,7 @@ struct vlg_workspace {
     bool filter = true;         // window filter: drop the list elements that can be in no match before the join
     uint64_t filter_min = 1ull << 16;   // queries with fewer join slots are joined as they are
     bool filter_pivot = true;   // filter from the shortest list of a query outwards when it is much shorter than the rest
+    uint64_t filter_pivot_ratio = 12;   // ... i.e. when all lists together are at least this many times longer (measured on C3: 12)
     uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
     uint64_t sweep_tail = 1ull << 20;   // stragglers of a sweep are finished one lane each
@@ -418,6 +419,7 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "filter")) { ws->filter = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter_min")) { ws->filter_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_pivot")) { ws->filter_pivot = value != 0; return VLG_OK; }
+    if (!strcmp(name, "filter_pivot_ratio")) { ws->filter_pivot_ratio = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "sweep_tail")) { ws->sweep_tail = (uint64_t)value; return VLG_OK; }
     return fail(VLG_E_INVALID, std::string("unknown workspace option ") + name);
 }
@@ -454,35 +456,39 @@ struct vlg_result {
 namespace {
 constexpr uint64_t kResultCacheBytes = 48ull << 30;
 struct ResultCache {
+    struct Entry { void* p; uint64_t size; int device; };
     std::mutex mu;
-    std::vector<std::pair<void*, uint64_t>> free_list;
+    std::vector<Entry> free_list;
     uint64_t bytes = 0;
+    static int device() { int d = 0; (void)hipGetDevice(&d); return d; }
     void* take(uint64_t need, uint64_t* size)
     {
+        const int dev = device();
         std::lock_guard<std::mutex> g(mu);
         size_t best = free_list.size();
         for (size_t i = 0; i < free_list.size(); ++i)
-            if (free_list[i].second >= need && free_list[i].second <= need + need / 4 + (1u << 20) &&
-                (best == free_list.size() || free_list[i].second < free_list[best].second)) best = i;
+            if (free_list[i].device == dev && free_list[i].size >= need && free_list[i].size <= need + need / 4 + (1u << 20) &&
+                (best == free_list.size() || free_list[i].size < free_list[best].size)) best = i;
         if (best == free_list.size()) return nullptr;
-        void* p = free_list[best].first;
-        *size = free_list[best].second;
-        bytes -= free_list[best].second;
+        void* p = free_list[best].p;
+        *size = free_list[best].size;
+        bytes -= free_list[best].size;
         free_list.erase(free_list.begin() + best);
         return p;
     }
     void give(void* p, uint64_t size)
     {
         {
+            const int dev = device();             // results are created and destroyed with their device current
             std::lock_guard<std::mutex> g(mu);
-            if (bytes + size <= kResultCacheBytes && free_list.size() < 64) { free_list.emplace_back(p, size); bytes += size; return; }
+            if (bytes + size <= kResultCacheBytes && free_list.size() < 64) { free_list.push_back(Entry{p, size, dev}); bytes += size; return; }
         }
         (void)hipFree(p);
     }
     void drain()
     {
         std::lock_guard<std::mutex> g(mu);
-        for (auto& e : free_list) (void)hipFree(e.first);
+        for (auto& e : free_list) (void)hipFree(e.p);
         free_list.clear();
         bytes = 0;
     }
@@ -1750,7 +1756,7 @@ inline int filter_mode(const vlg_queries* q, const Plan& pl, const vlg_workspace
     if (slots < ws->filter_min || !slots) return 0;
     if (pivot) *pivot = p;
     // two binary searches per pivot element and level against a pass (or two) over every element of every list
-    return ws->filter_pivot && best * 32 <= all ? 2 : 1;
+    return ws->filter_pivot && best * ws->filter_pivot_ratio <= all ? 2 : 1;
 }
 
 // Bytes of filter state a query needs (0 = the query is not filtered).
