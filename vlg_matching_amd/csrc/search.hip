@@ -1552,42 +1552,119 @@ __global__ void __launch_bounds__(256) filter_pass_kernel(const pos_t* __restric
     mr.finish();
 }
 
-// Index ranges [i0,i1) (relative to pbegin) of the list elements inside the position windows [a,b] of the lanes with `on`;
-// `on` is cleared for empty ranges.  The windows ascend with the lane, so the wave first brackets all answers between
-// the lower bounds of its smallest a and its largest b (64 probes per round), then every lane searches inside the
-// bracket and gallops from i0 to i1 (a window holds few elements).
+// Index ranges [i0,i1) (relative to pbegin) of the list elements inside the position windows [a,b] of the lanes with `on`,
+// for kPivotGroups groups of 64 windows at once; `on` is cleared for empty ranges.  Everything runs in lockstep over the
+// groups so that every round has one load per group in flight instead of one in all: the windows of a group ascend
+// with the lane, so first 2 x kPivotGroups wave-wide 64-ary searches bracket each group's answers between the lower bounds
+// of its smallest a and its largest b + 1, then every lane bisects its own a and b + 1 inside its group's bracket.
+constexpr uint32_t kPivotGroups = 4;
 template <typename pos_t>
-__device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, uint32_t pbegin, uint32_t pend, uint64_t a, uint64_t b, bool& on,
-                                             uint32_t& i0, uint32_t& i1)
+__device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, uint32_t pbegin, uint32_t pend, const uint64_t (&a)[kPivotGroups],
+                                             const uint64_t (&b)[kPivotGroups], bool (&on)[kPivotGroups], uint32_t (&i0)[kPivotGroups],
+                                             uint32_t (&i1)[kPivotGroups])
 {
-    const unsigned long long m = __ballot(on);
-    i0 = i1 = 0;
-    if (!m) return;
-    const int first = __ffsll((long long)m) - 1, last = 63 - __clzll((long long)m);
-    const uint64_t amin = uniform(__shfl(a, first)), bmax = uniform(__shfl(b, last));
-    const uint32_t lo = wave_kary_lower_bound(P, pbegin, pend, amin);
-    const uint32_t hi = bmax == ~0ull ? pend : wave_kary_lower_bound(P, lo, pend, bmax + 1);
-    if (on) {
-        const uint32_t j0 = lower_bound_dev(P, lo, hi, a);
-        const uint32_t j1 = gallop_lower_bound(P, j0, hi, b + 1);
-        i0 = j0 - pbegin; i1 = j1 - pbegin;
-        on = j0 < j1;
+    constexpr uint32_t G = kPivotGroups;
+    const uint32_t lane = threadIdx.x & 63;
+    // ---- brackets: searches 0..G-1 for min a, G..2G-1 for max b + 1, over the whole list ------------------------
+    uint64_t key[2 * G];
+    uint32_t A[2 * G], B[2 * G];
+    bool any[G];
+#pragma unroll
+    for (uint32_t g = 0; g < G; ++g) {
+        const unsigned long long m = __ballot(on[g]);
+        any[g] = m != 0;
+        const int first = m ? __ffsll((long long)m) - 1 : 0, last = m ? 63 - __clzll((long long)m) : 0;
+        key[g] = uniform(__shfl(a[g], first));
+        const uint64_t bmax = uniform(__shfl(b[g], last));
+        key[G + g] = bmax == ~0ull ? ~0ull : bmax + 1;
+        A[g] = A[G + g] = pbegin;
+        B[g] = B[G + g] = any[g] ? pend : pbegin;           // nothing to search for an empty group
+    }
+    for (;;) {
+        bool more = false;
+#pragma unroll
+        for (uint32_t s = 0; s < 2 * G; ++s) more |= B[s] - A[s] > 64;
+        if (!more) break;
+        uint64_t v[2 * G];
+        bool in[2 * G];
+#pragma unroll
+        for (uint32_t s = 0; s < 2 * G; ++s) {
+            const uint32_t step = (B[s] - A[s] + 63) / 64;
+            const uint64_t idx = (uint64_t)A[s] + (uint64_t)(lane + 1) * step - 1;
+            in[s] = B[s] - A[s] > 64 && idx < B[s];
+            v[s] = in[s] ? (uint64_t)P[idx] : 0;
+        }
+#pragma unroll
+        for (uint32_t s = 0; s < 2 * G; ++s) {
+            if (B[s] - A[s] > 64) {
+                const uint32_t step = (B[s] - A[s] + 63) / 64;
+                const uint32_t c = (uint32_t)__popcll(__ballot(in[s] && v[s] < key[s]));
+                const uint64_t na = (uint64_t)A[s] + (uint64_t)c * step, nb = (uint64_t)A[s] + (uint64_t)(c + 1) * step - 1;
+                A[s] = (uint32_t)na;
+                B[s] = nb < B[s] ? (uint32_t)nb : B[s];
+            }
+        }
+    }
+    uint32_t lo[G], hi[G];
+    {
+        uint64_t v[2 * G];
+        bool in[2 * G];
+#pragma unroll
+        for (uint32_t s = 0; s < 2 * G; ++s) { in[s] = A[s] + lane < B[s]; v[s] = in[s] ? (uint64_t)P[A[s] + lane] : 0; }
+#pragma unroll
+        for (uint32_t s = 0; s < 2 * G; ++s) {
+            const uint32_t r = A[s] + (uint32_t)__popcll(__ballot(in[s] && v[s] < key[s]));
+            if (s < G) lo[s] = r; else hi[s - G] = r;
+        }
+    }
+    // ---- every lane inside its group's bracket: lower bounds of a and of b + 1 -------------------------------------
+    uint32_t l0[G], r0[G], l1[G], r1[G];
+    uint32_t widest = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < G; ++g) {
+        if (hi[g] < lo[g]) hi[g] = lo[g];
+        l0[g] = l1[g] = lo[g];
+        r0[g] = r1[g] = on[g] ? hi[g] : lo[g];
+        widest = hi[g] - lo[g] > widest ? hi[g] - lo[g] : widest;
+    }
+    for (uint32_t w = uniform(widest); w; w >>= 1) {        // bit_width(widest) rounds bisect any range of that size
+        uint64_t v0[G], v1[G];
+        uint32_t m0[G], m1[G];
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            m0[g] = l0[g] + ((r0[g] - l0[g]) >> 1);
+            m1[g] = l1[g] + ((r1[g] - l1[g]) >> 1);
+            v0[g] = l0[g] < r0[g] ? (uint64_t)P[m0[g]] : 0;
+            v1[g] = l1[g] < r1[g] ? (uint64_t)P[m1[g]] : 0;
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            if (l0[g] < r0[g]) { if (v0[g] < a[g]) l0[g] = m0[g] + 1; else r0[g] = m0[g]; }
+            if (l1[g] < r1[g]) { if (v1[g] <= b[g]) l1[g] = m1[g] + 1; else r1[g] = m1[g]; }
+        }
+    }
+#pragma unroll
+    for (uint32_t g = 0; g < G; ++g) {
+        i0[g] = l0[g] - pbegin;
+        i1[g] = l1[g] - pbegin;
+        on[g] = on[g] && l0[g] < l1[g];
     }
 }
 
 // Pivot mode: when one list of the query is much shorter than the others, the survivors are found from its elements
-// outwards instead of streaming the long lists.  A lane takes one element of the pivot list and follows it level by
-// level: the elements of the neighbouring list inside its gap window form an index range (two binary searches), which is
-// marked in that list's activity bits; the hull of the range's positions is the "element" followed to the next level
-// (a superset of what the exact windows would mark, which is all the filter needs).
+// outwards instead of streaming the long lists.  A lane takes one element of the pivot list (kPivotGroups of them, one per
+// 64-element group of the wave's run) and follows it level by level: the elements of the neighbouring list inside its gap
+// window form an index range, which is marked in that list's activity bits; the hull of the range's positions is the
+// "element" followed to the next level (a superset of what the exact windows would mark, which is all the filter needs).
 struct PTask { uint32_t seg0, k, p, pad; };          // first segment of the query, sub-patterns, pivot level
-constexpr uint32_t kPivotRun = 256;                   // pivot elements per wave
+constexpr uint32_t kPivotRun = 64 * kPivotGroups;     // pivot elements per wave
 
 template <typename pos_t>
 __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restrict__ P, const RSeg* __restrict__ segs,
                                                            const PTask* __restrict__ tasks, const uint64_t* __restrict__ task_run0,
                                                            uint32_t ntasks, uint64_t* __restrict__ abits)
 {
+    constexpr uint32_t G = kPivotGroups;
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t run = uniform(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (run >= task_run0[ntasks]) return;
@@ -1597,47 +1674,69 @@ __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restri
     const uint64_t len = pv.pend - pv.pbegin;
     const uint64_t off0 = (run - task_run0[t]) * kPivotRun;
     const uint64_t off1 = off0 + kPivotRun < len ? off0 + kPivotRun : len;
-    for (uint64_t base = off0; base < off1; base += 64) {
-        const uint64_t i = base + lane;
-        const bool on0 = i < off1;
-        const uint64_t x = on0 ? (uint64_t)P[pv.pbegin + i] : 0;
-        if (pv.abit != ~0ull) {                                               // every element of the pivot list stays
-            const unsigned long long m = __ballot(on0);
-            if (lane == 0) abits[(pv.abit + base) >> 6] = m;
+    uint64_t x[G];
+    bool on0[G];
+#pragma unroll
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint64_t i = off0 + 64 * g + lane;
+        on0[g] = i < off1;
+        x[g] = on0[g] ? (uint64_t)P[pv.pbegin + i] : 0;
+        if (pv.abit != ~0ull && off0 + 64 * g < off1) {                       // every element of the pivot list stays
+            const unsigned long long m = __ballot(on0[g]);
+            if (lane == 0) abits[(pv.abit + off0 + 64 * g) >> 6] = m;
         }
-        // towards the first sub-pattern
-        uint64_t lo_pos = x, hi_pos = x;
-        bool on = on0;
+    }
+    // the marks of one level ascend over the groups: one MarkRun per level collects them
+    auto follow = [&](const RSeg& sg, const uint64_t (&a)[G], const uint64_t (&b)[G], bool (&on)[G], uint64_t (&lo_pos)[G], uint64_t (&hi_pos)[G],
+                      bool more_levels) {
+        uint32_t i0[G], i1[G];
+        pivot_ranges(P, sg.pbegin, sg.pend, a, b, on, i0, i1);
+        MarkRun mr;
+        mr.bm = abits + (sg.abit >> 6);
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) mr.add(i0[g], i1[g] - 1, on[g]);
+        mr.flush();
+        if (more_levels) {
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g) if (on[g]) { lo_pos[g] = P[sg.pbegin + i0[g]]; hi_pos[g] = P[sg.pbegin + i1[g] - 1]; }
+        }
+    };
+    // towards the first sub-pattern
+    {
+        uint64_t lo_pos[G], hi_pos[G];
+        bool on[G];
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) { lo_pos[g] = hi_pos[g] = x[g]; on[g] = on0[g]; }
         for (int l = (int)tk.p - 1; l >= 0; --l) {
             const RSeg sg = segs[tk.seg0 + l], up = segs[tk.seg0 + l + 1];      // gap bounds between l and l+1 belong to l+1
-            uint32_t i0 = 0, i1 = 0;
-            uint64_t a = 0, b = 0;
-            if (on) {
-                if (hi_pos < up.lo) on = false;
-                else { a = lo_pos > up.hi ? lo_pos - up.hi : 0; b = hi_pos - up.lo; }
+            uint64_t a[G], b[G];
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g) {
+                a[g] = b[g] = 0;
+                if (on[g]) {
+                    if (hi_pos[g] < up.lo) on[g] = false;
+                    else { a[g] = lo_pos[g] > up.hi ? lo_pos[g] - up.hi : 0; b[g] = hi_pos[g] - up.lo; }
+                }
             }
-            pivot_ranges(P, sg.pbegin, sg.pend, a, b, on, i0, i1);
-            MarkRun mr;
-            mr.bm = abits + (sg.abit >> 6);
-            mr.add(i0, i1 - 1, on);
-            mr.flush();
-            if (on) { lo_pos = P[sg.pbegin + i0]; hi_pos = P[sg.pbegin + i1 - 1]; }
+            follow(sg, a, b, on, lo_pos, hi_pos, l > 0);
         }
-        // towards the last sub-pattern (which keeps no join state itself)
-        lo_pos = hi_pos = x;
-        on = on0;
+    }
+    // towards the last sub-pattern (which keeps no join state itself)
+    {
+        uint64_t lo_pos[G], hi_pos[G];
+        bool on[G];
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) { lo_pos[g] = hi_pos[g] = x[g]; on[g] = on0[g]; }
         for (uint32_t l = tk.p + 1; l + 1 < tk.k; ++l) {
             const RSeg sg = segs[tk.seg0 + l];
-            uint32_t i0 = 0, i1 = 0;
-            const uint64_t a = sat_add(lo_pos, sg.lo);
-            uint64_t b = sat_add(hi_pos, sg.hi);
-            if (b == ~0ull) b = ~0ull - 1;                                       // (b + 1 below)
-            pivot_ranges(P, sg.pbegin, sg.pend, a, b, on, i0, i1);
-            MarkRun mr;
-            mr.bm = abits + (sg.abit >> 6);
-            mr.add(i0, i1 - 1, on);
-            mr.flush();
-            if (on) { lo_pos = P[sg.pbegin + i0]; hi_pos = P[sg.pbegin + i1 - 1]; }
+            uint64_t a[G], b[G];
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g) {
+                a[g] = sat_add(lo_pos[g], sg.lo);
+                b[g] = sat_add(hi_pos[g], sg.hi);
+                if (b[g] == ~0ull) b[g] = ~0ull - 1;                             // (b + 1 is searched)
+            }
+            follow(sg, a, b, on, lo_pos, hi_pos, l + 2 < tk.k);
         }
     }
 }
