@@ -338,8 +338,11 @@ def test_cpp_driver_pipeline_matches_oracle(V, oracle, tmp_path):
     raw = dna_text(200000, 31).tobytes().replace(b"GATTACA", b"GAT\nACA")     # newline -> space like create_collection
     (tmp_path / "raw.txt").write_bytes(raw)
     col = str(tmp_path / "col")
-    subprocess.run([_bin("gm_index_gpu"), "-c", col, "-i", str(tmp_path / "raw.txt")], check=True, capture_output=True)
+    built = subprocess.run([_bin("gm_index_gpu"), "-c", col, "-i", str(tmp_path / "raw.txt"), "-s"], check=True, capture_output=True, text=True).stdout
     text = raw.replace(b"\n", b" ")
+    # -s: the same index in the reference's own csa_wt<wt_huff<>,32,64> format
+    sdsl_file = [l.split(" = ")[1] for l in built.splitlines() if l.startswith("# sdsl_file = ")][0]
+    assert_parts_equal(V.VlgIndex.load_sdsl(sdsl_file).export_parts(), V.VlgIndex.build(text).export_parts())
     rng = np.random.default_rng(8)
     pats = []
     for _ in range(200):
