@@ -1276,7 +1276,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     Pc_out = nullptr;
     pc_cap = 0;
     if (!acc) return VLG_OK;
-    const unsigned bits = bit_width64(idx->hdr.n);
+    const unsigned bits = std::max(1u, bit_width64(idx->hdr.n >= 2 ? idx->hdr.n - 2 : 0));   // the largest position is n - 2 (n - 1 is the sentinel)
     const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (sizeof(pos_t) == 4 ? 32 : 33));
     pos_t* Pa = A.take<pos_t>(acc);
     // scratch of the sweep (20 B per element); the sorted lists Pb reuse it once locate is done
