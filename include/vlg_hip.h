@@ -299,8 +299,6 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
  * lists (they are in no match); "filter_min" (default 2^16) = join slots below which a query is joined as it is;
  * "filter_pivot" (default 1): filter outwards from the shortest list of a query when it is >= 12x shorter than all of
  * them together ("filter_pivot_ratio", default 12), otherwise (or with 0) by streaming sweeps over block bitmaps.
- * "lazy_join" (default 0, experimental): follow the match chains lazily with tile speculation (queries of up to 8
- * sub-patterns) instead of the dense passes that evaluate every list element; pays only for sparse lists.
  * Results are identical whatever the options. */
 vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* name, int64_t value);
 vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n);

@@ -2,7 +2,7 @@
 index in seconds, but it can adopt the device-built parts and answer a bounded sample of the same queries):
   * every tuple obeys its gap bounds, tuples are ascending and non-overlapping (SURVEY.md Appendix C);
   * every reported position really is an occurrence of its sub-pattern in the text;
-  * interval sharing on/off, sorted-sweep vs random-access locate, lazy vs dense join all give identical results;
+  * interval sharing on/off, sorted-sweep vs random-access locate, the window filter on/off all give identical results;
   * a random sample of queries equals the CPU oracle tuple for tuple."""
 import numpy as np
 import pytest
@@ -52,7 +52,7 @@ def test_c2_properties_and_mode_equivalence(c2):
     assert checked == s["n_matches"]
     assert int(first.astype(np.uint64).sum()) % (1 << 64) == s["checksum"]
     # --- identical results whatever the execution strategy ------------------------------------------------
-    for opts in ({"dedup": 0}, {"sweep": 0}, {"lazy_join": 1}, {"sweep_min": 1, "sweep_tail": 1000}):
+    for opts in ({"dedup": 0}, {"sweep": 0}, {"filter_min": 0}, {"sweep_min": 1, "sweep_tail": 1000}):
         ws = Workspace()
         for k_, v_ in opts.items():
             ws.set_option(k_, v_)

@@ -258,16 +258,14 @@ def test_search_benchmark_dialect_and_bad_queries(V, oracle):
         assert res.tuples(i).tolist() == want.tolist() or (len(want) == 0 and int(res.counts[i]) == 0), q
 
 
-@pytest.mark.parametrize("lazy,cap_mb", [(1, 24), (0, 48)])
-def test_search_chunked_equals_unchunked(V, lazy, cap_mb):
+@pytest.mark.parametrize("cap_mb", [48])
+def test_search_chunked_equals_unchunked(V, cap_mb):
     """A tiny workspace forces many chunks; results must not change."""
     text = TEXTS["dna_50k"]()
     idx = V.VlgIndex.build(text)
     qs = random_queries(text, np.random.default_rng(9), 300, kmax=3, mmax=3)
     from vlg_matching_amd.index import Workspace
     wa, wb = Workspace(), Workspace(max_hbm_bytes=(cap_mb << 20))
-    wa.set_option("lazy_join", lazy)
-    wb.set_option("lazy_join", lazy)
     a = idx.search(qs, workspace=wa)
     b = idx.search(qs, workspace=wb)
     assert b.summary["n_chunks"] > a.summary["n_chunks"]
@@ -371,28 +369,6 @@ def test_cpp_driver_pipeline_matches_oracle(V, oracle, tmp_path):
     assert kv1["num_results"] == kv["num_results"] and kv1["checksum"] == kv["checksum"]
 
 
-@pytest.mark.parametrize("name,seed,kmax", [("dna_50k", 41, 5), ("dna_skew", 42, 8), ("zipf40", 43, 4), ("100a", 44, 3), ("dna_50k", 45, 11)])
-def test_lazy_join_equals_dense_join_and_oracle(V, oracle, name, seed, kmax):
-    """The lazy tile-speculative join and the dense passes are two evaluations of the same least fixed points."""
-    from vlg_matching_amd.index import Workspace
-    text = TEXTS[name]()
-    o = oracle.Index.from_text(text)
-    idx = V.VlgIndex.build(text)
-    rng = np.random.default_rng(seed)
-    qs = random_queries(text, rng, 250, kmax=kmax, mmax=3, gapmax=40, gaplo=8)
-    qs += random_queries(text, rng, 60, kmax=2, mmax=1, gapmax=3, gaplo=2)          # dense lists, tight gaps: many tiles, many overlaps
-    ws_d, ws_l = Workspace(), Workspace()
-    ws_d.set_option("lazy_join", 0)
-    ws_l.set_option("lazy_join", 1)
-    a, b = idx.search(qs, workspace=ws_d), idx.search(qs, workspace=ws_l)
-    for k in ("n_matches", "checksum", "n_tuple_values", "logical_occurrences"):
-        assert a.summary[k] == b.summary[k], k
-    for x, y in zip(a.fetch(), b.fetch()):
-        assert (x == y).all()
-    for i in list(range(0, len(qs), 7)) + [len(qs) - 1]:
-        assert b.tuples(i).tolist() == o.search(qs[i]).tolist(), qs[i]
-
-
 @pytest.mark.parametrize("name,seed,tail", [("dna_50k", 71, 16), ("zipf40", 72, 1), ("100a", 73, 4), ("dna_skew", 74, 1000), ("abracadabra", 75, 1)])
 def test_locate_trail_sharing_equals_plain_locate_and_oracle(V, oracle, name, seed, tail):
     """Sorted sweep with shared LF trails (an element stops where another one has stood and takes its position plus the
@@ -490,12 +466,13 @@ def test_join_many_tiles_single_pattern(V, oracle):
     idx = V.VlgIndex.build(text)
     from vlg_matching_amd.index import Workspace
     qs = ["a", "ab", "aba", "a.{0,0}?b", "a.{1,3}?a", "b.{0,5}?a.{0,2}?b", "ab.{2,2}?ab", "a.{0,1}?a.{0,1}?a.{0,1}?a"]
-    for lazy in (0, 1):
+    for filt in (0, 1):
         ws = Workspace()
-        ws.set_option("lazy_join", lazy)
+        ws.set_option("filter", filt)
+        ws.set_option("filter_min", 0)
         res = idx.search(qs, workspace=ws)
         for i, qq in enumerate(qs):
-            assert res.tuples(i).tolist() == o.search(qq).tolist(), (qq, lazy)
+            assert res.tuples(i).tolist() == o.search(qq).tolist(), (qq, filt)
 
 
 @pytest.mark.parametrize("nbits", [0, 1, 62, 63, 64, 2015, 2016, 2017, 4096, 100000, 1 << 20])
@@ -683,16 +660,15 @@ def test_64bit_position_kernels(torch_cuda, V, oracle, monkeypatch):
     assert idx2.info()["pos_bytes"] == 8
     rng = np.random.default_rng(77)
     qs = random_queries(text, rng, 250, kmax=5, mmax=4)
-    for lazy, sweep_min in ((0, 1 << 22), (1, 1 << 22), (0, 1)):            # dense / lazy join; random-access / sorted-sweep locate
+    for sweep_min in (1 << 22, 1):                                           # random-access / sorted-sweep locate
         ws = Workspace()
-        ws.set_option("lazy_join", lazy)
         ws.set_option("sweep_min", sweep_min)
         ws.set_option("sweep_tail", 64)
         ws.set_option("dedup", 0)
         res = idx.search(qs, workspace=ws)
         occ = np.zeros(4, dtype=np.uint64)
         for i, q in enumerate(qs):
-            assert res.tuples(i).tolist() == o.search(q, stats=occ).tolist(), (q, lazy, sweep_min)
+            assert res.tuples(i).tolist() == o.search(q, stats=occ).tolist(), (q, sweep_min)
         assert res.summary["logical_occurrences"] == int(occ[0]) == res.summary["located_occurrences"]
         assert res.summary["lf_steps"] == int(occ[1]) and res.summary["wt_levels_locate"] == int(occ[2])
     # the batch-level shortcuts on 64-bit positions: shared intervals, shared LF trails, one-pass sort, window filter (both modes)

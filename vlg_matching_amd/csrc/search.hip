@@ -262,10 +262,6 @@ struct vlg_workspace {
     bool profile = false;
     bool dedup = true;
     bool sweep = true;          // sorted-sweep locate (n <= 2^32) instead of the random-access persistent kernel
-    bool lazy_join = false;     // experimental: follow the match chains lazily (k <= 8) instead of evaluating every list element.
-                                // Measured on C3 (dense lists): spec 1.5 s + stitch 18.5 s per step vs 1.6 s for the dense passes --
-                                // chains that enter a tile out of phase with the speculated one never merge when almost every
-                                // element is feasible, so the stitch pass degenerates to a serial walk.  Kept for sparse batches.
     bool trail = true;          // sorted-sweep locate: elements that step onto an SA index another element has visited share its LF trail
                                 // (needs dedup; with dedup off every occurrence walks its own LF steps like the reference)
     bool filter = true;         // window filter: drop the list elements that can be in no match before the join
@@ -412,7 +408,6 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!ws || !name) return fail(VLG_E_INVALID, "null argument");
     if (!strcmp(name, "dedup")) { ws->dedup = value != 0; return VLG_OK; }
     if (!strcmp(name, "sweep")) { ws->sweep = value != 0; return VLG_OK; }
-    if (!strcmp(name, "lazy_join")) { ws->lazy_join = value != 0; return VLG_OK; }
     if (!strcmp(name, "sweep_min")) { ws->sweep_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "global_sort_min")) { ws->global_sort_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "trail")) { ws->trail = value != 0; return VLG_OK; }
@@ -2287,330 +2282,6 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     return VLG_OK;
 }
 
-// =============================================================================================
-// Lazy join (option "lazy_join", off by default, k <= kLazyK).  Only a small fraction of the elements of list 0 ever start a match (the
-// non-overlap rule skips everything a match spans), so instead of evaluating every slot the chains are followed
-// directly: a match is the least fixed point of the gap constraints above a start bound, found by the galloping
-// form of the reference's own pointer loop (first_match).  Parallelism comes from speculation over tiles of list 0:
-//   spec   : one lane per tile follows the chain from the tile's first element as if the chain entered there and
-//            records (match start, restart bound it was found from);
-//   stitch : one lane per query walks tile to tile with the true entry; as soon as the true chain meets a recorded
-//            element -- or restarts from a bound at or after the bound a recorded element was found from -- the rest
-//            of the tile is the recorded suffix (least fixed points are monotone in the start bound);
-//   emit   : one lane per tile copies the recorded suffix behind the elements the stitch pass found itself;
-//   gather : one lane per match re-derives the tuple from its start.
-// Results are exactly those of the dense passes above.
-// =============================================================================================
-constexpr uint32_t kLazyK = 8;
-constexpr uint32_t kLazyTile = 2048;
-constexpr uint32_t kEndMark = 0xFFFFFFFFu;
-
-struct LSeg { uint32_t pbegin, pend; uint64_t lo, hi; };
-struct LQuery {
-    uint32_t seg0, k;           // first LSeg, number of sub-patterns (0 = dead)
-    uint32_t tile0, n_tiles;    // tiles of list 0
-    uint32_t slot0, n0;         // base of its level-0 slots in the chunk, |list 0|
-    uint64_t end_len;
-    uint64_t out_first, out_tuple;
-};
-struct TileOut { uint32_t cnt, exit_a, exit_m, pad; };     // recorded matches; restart bound and next match start after the tile
-struct TileFix { uint32_t j, n_new, off, visited; };        // stitch result: recorded suffix [j,cnt) after n_new own elements at offset off
-
-struct Cursor { uint32_t p[kLazyK]; };
-
-// Least tuple (p0 >= c.p[0], p_i >= c.p[i]) satisfying every gap constraint; false if none exists (then none exists for
-// any larger start either).  Pointers only move forward, each raise is forced by a constraint, as in index_sasearch.hpp:87-101.
-template <typename pos_t>
-__device__ __forceinline__ bool first_match(const pos_t* __restrict__ P, const LSeg* __restrict__ sg, uint32_t k, Cursor& c)
-{
-    const uint32_t end0 = sg[0].pend;
-    for (;;) {
-        if (c.p[0] >= end0) return false;
-        uint64_t prev = P[c.p[0]];
-        bool restart = false;
-#pragma unroll
-        for (uint32_t i = 1; i < kLazyK; ++i) {
-            if (i >= k) break;
-            const LSeg g = sg[i];
-            uint32_t j = gallop_lower_bound(P, c.p[i], g.pend, prev + g.lo);
-            c.p[i] = j;
-            if (j >= g.pend) return false;
-            uint64_t v = P[j];
-            if (v > prev + g.hi) {                       // too far: the previous list must advance to reach v
-                const uint32_t pe = (i == 1) ? end0 : sg[i - 1].pend;
-                c.p[i - 1] = gallop_lower_bound(P, c.p[i - 1] + 1, pe, v - g.hi);
-                restart = true;
-                break;
-            }
-            prev = v;
-        }
-        if (!restart) return true;
-    }
-}
-
-__device__ __forceinline__ uint32_t query_of_tile(const LQuery* __restrict__ lq, uint32_t nq, uint32_t tile)
-{
-    uint32_t lo = 0, hi = nq;                            // last q with tile0[q] <= tile (dead queries have n_tiles = 0)
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lq[mid].tile0 <= tile) lo = mid; else hi = mid; }
-    return lo;
-}
-
-template <typename pos_t>
-__global__ void __launch_bounds__(256) lazy_spec_kernel(const pos_t* __restrict__ P, const LSeg* __restrict__ segs, const LQuery* __restrict__ lq,
-                                                        uint32_t nq, uint32_t n_tiles, uint2* __restrict__ spec /* per slot */,
-                                                        TileOut* __restrict__ tout)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    uint32_t q = query_of_tile(lq, nq, t);
-    while (lq[q].n_tiles == 0 || t >= lq[q].tile0 + lq[q].n_tiles) ++q;      // skip dead / empty queries sharing tile0
-    const LQuery Q = lq[q];
-    const LSeg* sg = segs + Q.seg0;
-    const uint32_t tl = t - Q.tile0;
-    const uint32_t b0 = sg[0].pbegin;
-    const uint32_t a_lo = b0 + tl * kLazyTile;
-    const uint32_t a_hi = min(a_lo + kLazyTile, sg[0].pend);
-    uint2* area = spec + Q.slot0 + (uint64_t)tl * kLazyTile;
-    Cursor c;
-#pragma unroll
-    for (uint32_t i = 0; i < kLazyK; ++i) c.p[i] = (i < Q.k) ? sg[i].pbegin : 0;
-    c.p[0] = a_lo;
-    uint32_t cnt = 0;
-    TileOut o{0, kEndMark, kEndMark, 0};
-    for (;;) {
-        const uint32_t a = c.p[0];
-        if (!first_match(P, sg, Q.k, c)) { o.exit_a = a - b0; o.exit_m = kEndMark; break; }
-        if (c.p[0] >= a_hi) { o.exit_a = a - b0; o.exit_m = c.p[0] - b0; break; }
-        area[cnt++] = make_uint2(c.p[0] - b0, a - b0);
-        const uint64_t endv = (uint64_t)P[c.p[Q.k - 1]] + Q.end_len;
-        c.p[0] = gallop_lower_bound(P, c.p[0] + 1, sg[0].pend, endv);
-    }
-    o.cnt = cnt;
-    tout[t] = o;
-}
-
-// first recorded entry of the tile with start >= a (entries ascend by start and by bound)
-__device__ __forceinline__ uint32_t spec_lower_bound(const uint2* __restrict__ area, uint32_t cnt, uint32_t a)
-{
-    uint32_t lo = 0, hi = cnt;
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (area[mid].x < a) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
-template <typename pos_t>
-__global__ void lazy_stitch_kernel(const pos_t* __restrict__ P, const LSeg* __restrict__ segs, const LQuery* __restrict__ lq, uint32_t nq,
-                                   const uint2* __restrict__ spec, const TileOut* __restrict__ tout, TileFix* __restrict__ tfix,
-                                   uint32_t* __restrict__ mfinal, unsigned long long* __restrict__ counts)
-{
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    const LQuery Q = lq[q];
-    unsigned long long off = 0;
-    if (Q.k && Q.n_tiles) {
-        const LSeg* sg = segs + Q.seg0;
-        const uint32_t b0 = sg[0].pbegin;
-        uint32_t tl = 0;
-        uint32_t m = kEndMark;            // known match start (list-relative) the chain enters the tile with; kEndMark = "from the tile's first record"
-        bool first = true;
-        for (;;) {
-            const uint32_t t = Q.tile0 + tl;
-            const TileOut o = tout[t];
-            const uint2* area = spec + Q.slot0 + (uint64_t)tl * kLazyTile;
-            const uint32_t tile_end = min((tl + 1) * kLazyTile, Q.n0);          // list-relative
-            TileFix f{o.cnt, 0, (uint32_t)off, 1};
-            uint32_t ex_m;
-            if (first) { f.j = 0; ex_m = o.exit_m; first = false; }             // tile 0 was followed from the true start
-            else {
-                uint32_t cur = m;
-                ex_m = kEndMark;
-                for (;;) {
-                    uint32_t j = spec_lower_bound(area, o.cnt, cur);
-                    if (j < o.cnt && area[j].x == cur) { f.j = j; ex_m = o.exit_m; break; }      // met the recorded chain
-                    // cur is a match the recorded chain skipped: keep it and continue from behind its own match
-                    mfinal[Q.slot0 + off + f.n_new] = cur;
-                    ++f.n_new;
-                    Cursor c;
-#pragma unroll
-                    for (uint32_t i = 0; i < kLazyK; ++i) c.p[i] = (i < Q.k) ? sg[i].pbegin : 0;
-                    c.p[0] = b0 + cur;
-                    first_match(P, sg, Q.k, c);                                   // cur is feasible: yields its tuple
-                    const uint64_t endv = (uint64_t)P[c.p[Q.k - 1]] + Q.end_len;
-                    const uint32_t a = gallop_lower_bound(P, b0 + cur + 1, sg[0].pend, endv) - b0;
-                    if (a < tile_end) {
-                        j = spec_lower_bound(area, o.cnt, a);
-                        if (j < o.cnt && area[j].y <= a) { f.j = j; ex_m = o.exit_m; break; }   // recorded from a bound <= a: same least match
-                        if (j >= o.cnt && o.exit_a <= a) { f.j = o.cnt; ex_m = o.exit_m; break; }
-                    }
-                    c.p[0] = b0 + a;
-                    if (!first_match(P, sg, Q.k, c)) { f.j = o.cnt; ex_m = kEndMark; break; }
-                    cur = c.p[0] - b0;
-                    if (cur >= tile_end) { f.j = o.cnt; ex_m = cur; break; }
-                }
-            }
-            tfix[t] = f;
-            off += f.n_new + (o.cnt - f.j);
-            if (ex_m == kEndMark) break;
-            m = ex_m;
-            tl = m / kLazyTile;
-        }
-    }
-    counts[q] = off;
-}
-
-__global__ void lazy_emit_kernel(const LQuery* __restrict__ lq, uint32_t nq, uint32_t n_tiles, const uint2* __restrict__ spec,
-                                 const TileOut* __restrict__ tout, const TileFix* __restrict__ tfix, uint32_t* __restrict__ mfinal)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const TileFix f = tfix[t];
-    if (!f.visited) return;
-    uint32_t q = query_of_tile(lq, nq, t);
-    while (lq[q].n_tiles == 0 || t >= lq[q].tile0 + lq[q].n_tiles) ++q;
-    const LQuery Q = lq[q];
-    const uint2* area = spec + Q.slot0 + (uint64_t)(t - Q.tile0) * kLazyTile;
-    uint32_t* dst = mfinal + Q.slot0 + f.off + f.n_new;
-    const uint32_t cnt = tout[t].cnt;
-    for (uint32_t i = f.j; i < cnt; ++i) dst[i - f.j] = area[i].x;
-}
-
-// one lane per run of kGatherRun consecutive matches: re-derive each tuple from its start (the previous tuple of the
-// same query is a valid fence for the next one) and write the results
-constexpr uint32_t kGatherRun = 8;
-template <typename pos_t>
-__global__ void __launch_bounds__(256) lazy_gather_kernel(const pos_t* __restrict__ P, const LSeg* __restrict__ segs, const LQuery* __restrict__ lq,
-                                                          uint32_t nq, const uint64_t* __restrict__ match_off /* [nq+1] */, uint64_t n_matches,
-                                                          const uint32_t* __restrict__ mfinal, uint64_t* __restrict__ out_first,
-                                                          uint64_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
-{
-    unsigned long long local = 0;
-    const uint64_t n_runs = (n_matches + kGatherRun - 1) / kGatherRun;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t g = r * kGatherRun;
-        const uint64_t g_end = g + kGatherRun < n_matches ? g + kGatherRun : n_matches;
-        uint32_t qi = 0;
-        {
-            uint32_t lo = 0, hi = nq;                    // last q with match_off[q] <= g
-            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (match_off[mid] <= g) lo = mid; else hi = mid; }
-            qi = lo;
-        }
-        bool fresh = true;
-        Cursor c;
-        while (g < g_end) {
-            while (match_off[qi + 1] <= g) { ++qi; fresh = true; }
-            const LQuery Q = lq[qi];
-            const LSeg* sg = segs + Q.seg0;
-            if (fresh) {
-#pragma unroll
-                for (uint32_t i = 0; i < kLazyK; ++i) c.p[i] = (i < Q.k) ? sg[i].pbegin : 0;
-                fresh = false;
-            }
-            const uint64_t t = g - match_off[qi];
-            c.p[0] = sg[0].pbegin + mfinal[Q.slot0 + t];
-            first_match(P, sg, Q.k, c);
-            const uint64_t first = P[c.p[0]];
-            out_first[Q.out_first + t] = first;
-            local += first;
-            uint64_t* tp = out_tuples + Q.out_tuple + t * Q.k;
-#pragma unroll
-            for (uint32_t i = 0; i < kLazyK; ++i) if (i < Q.k) tp[i] = P[c.p[i]];
-            ++g;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(checksum, local);
-}
-
-constexpr uint64_t kLazyBytesPerSlot = 8 + 4;          // recorded (start, bound) pairs + final match list
-
-template <typename pos_t>
-vlg_status run_lazy_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* res, uint64_t q0, uint64_t q1, const Plan& pl,
-                          const std::vector<uint32_t>& poff, const pos_t* P, Arena A, unsigned long long* d_stats)
-{
-    hipStream_t st = ws->stream;
-    const uint32_t nq = (uint32_t)(q1 - q0);
-    ResultPiece piece;
-    piece.q0 = q0; piece.q1 = q1;
-    std::vector<LQuery> lq(nq + 1);
-    std::vector<LSeg> segs;
-    uint64_t slots = 0, tiles = 0;
-    for (uint64_t qi = q0; qi < q1; ++qi) {
-        const uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
-        LQuery& Q = lq[qi - q0];
-        const bool live = k > 0 && pl.occ[q->qsub[qi]] > 0;
-        Q.seg0 = (uint32_t)segs.size(); Q.k = live ? k : 0;
-        Q.tile0 = (uint32_t)tiles; Q.slot0 = (uint32_t)slots;
-        Q.n0 = live ? (uint32_t)pl.occ[q->qsub[qi]] : 0;
-        Q.n_tiles = (Q.n0 + kLazyTile - 1) / kLazyTile;
-        Q.end_len = q->end_len[qi]; Q.out_first = Q.out_tuple = 0;
-        if (live)
-            for (uint32_t i = 0; i < k; ++i) {
-                const uint64_t s = q->qsub[qi] + i;
-                const uint32_t pb = poff[pl.did[s]];
-                segs.push_back(LSeg{pb, pb + (uint32_t)pl.occ[s], q->lo[s], q->hi[s]});
-            }
-        slots += (uint64_t)Q.n_tiles * kLazyTile;
-        tiles += Q.n_tiles;
-    }
-    lq[nq] = LQuery{(uint32_t)segs.size(), 0, (uint32_t)tiles, 0, (uint32_t)slots, 0, 0, 0, 0};
-    if (!tiles) { res->pieces.push_back(piece); res->sum.n_chunks++; return VLG_OK; }
-    const uint32_t n_tiles = (uint32_t)tiles;
-    uint2* spec = A.take<uint2>(slots);
-    uint32_t* mfinal = A.take<uint32_t>(slots);
-    TileOut* tout = A.take<TileOut>(n_tiles);
-    TileFix* tfix = A.take<TileFix>(n_tiles);
-    LQuery* d_lq = A.take<LQuery>(nq + 1);
-    LSeg* d_segs = A.take<LSeg>(segs.size() + 1);
-    unsigned long long* d_counts = A.take<unsigned long long>(nq);
-    uint64_t* d_moff = A.take<uint64_t>(nq + 1);
-    if (!d_moff) return fail(VLG_E_INTERNAL, "arena carve failed (lazy join)");
-    VLG_HIP_TRY(hipMemcpyAsync(d_lq, lq.data(), (nq + 1) * sizeof(LQuery), hipMemcpyHostToDevice, st));
-    VLG_HIP_TRY(hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(LSeg), hipMemcpyHostToDevice, st));
-    VLG_HIP_TRY(hipMemsetAsync(tfix, 0, (uint64_t)n_tiles * sizeof(TileFix), st));
-    uint64_t list_elems = 0;
-    for (const auto& g : segs) list_elems += g.pend - g.pbegin;
-    {
-        Timed t(ws, KS_JOIN_LINK, 8ull * list_elems);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lazy_spec_kernel<pos_t>), dim3((n_tiles + 255) / 256), dim3(256), 0, st, P, d_segs, d_lq, nq, n_tiles, spec, tout);
-    }
-    {
-        Timed t(ws, KS_JOIN_CHAIN, 0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lazy_stitch_kernel<pos_t>), dim3((nq + 63) / 64), dim3(64), 0, st, P, d_segs, d_lq, nq, spec, tout, tfix, mfinal,
-                           d_counts);
-        hipLaunchKernelGGL(lazy_emit_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, st, d_lq, nq, n_tiles, spec, tout, tfix, mfinal);
-    }
-    VLG_HIP_TRY(hipGetLastError());
-    std::vector<unsigned long long> counts(nq);
-    VLG_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, nq * 8, hipMemcpyDeviceToHost, st));
-    VLG_HIP_TRY(hipStreamSynchronize(st));
-    std::vector<uint64_t> moff(nq + 1);
-    uint64_t M = 0, TV = 0;
-    for (uint32_t i = 0; i < nq; ++i) {
-        lq[i].out_first = M; lq[i].out_tuple = TV; moff[i] = M;
-        M += counts[i]; TV += counts[i] * lq[i].k;
-        res->counts[q0 + i] = counts[i];
-    }
-    moff[nq] = M;
-    piece.matches = M; piece.tuple_vals = TV;
-    if (M) {
-        VLG_HIP_TRY(result_alloc(&piece.d_first, M * 8, &piece.first_bytes));
-        VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * 8, &piece.tuple_bytes));
-        res->pieces.push_back(piece);
-        VLG_HIP_TRY(hipMemcpyAsync(d_lq, lq.data(), (nq + 1) * sizeof(LQuery), hipMemcpyHostToDevice, st));
-        VLG_HIP_TRY(hipMemcpyAsync(d_moff, moff.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
-        Timed t(ws, KS_GATHER, 8ull * (M + TV));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lazy_gather_kernel<pos_t>), dim3(grid_for((M + kGatherRun - 1) / kGatherRun, 65536)), dim3(256), 0, st, P, d_segs, d_lq, nq, d_moff, M, mfinal,
-                           piece.d_first, piece.d_tuples, d_stats + 2);
-        VLG_HIP_TRY(hipGetLastError());
-    } else {
-        res->pieces.push_back(piece);
-    }
-    VLG_HIP_TRY(hipStreamSynchronize(st));
-    res->sum.n_matches += M;
-    res->sum.n_tuple_values += TV;
-    res->sum.n_chunks++;
-    return VLG_OK;
-}
-
 // A super-chunk = a run of queries whose distinct occurrence lists fit the physical budget; inside it
 // the queries are joined in chunks bounded by the logical budget.
 template <typename pos_t>
@@ -2650,12 +2321,10 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         }
         ++epoch;
         // ---- arena: physical lists first, filter state and join scratch behind them ---------------------
-        const bool lazy = ws->lazy_join && q->kmax <= kLazyK;
         const bool uniform_k = q->kmin == q->kmax;
         // cost of a query in bytes of join scratch / in join slots, for list lengths given by occ_of(sub-pattern)
         auto bytes_of = [&](uint64_t qi, auto&& occ_of) -> uint64_t {
             uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
-            if (lazy) return (k ? (occ_of(q->qsub[qi]) + kLazyTile - 1) / kLazyTile * kLazyTile : 0) * kLazyBytesPerSlot;   // whole tiles of list 0
             uint64_t t = 0;
             for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += occ_of(q->qsub[qi] + i);
             // list-0 arrays cover the slot range of all lists 0, which is exactly those slots when every query has the same k
@@ -2664,7 +2333,6 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         };
         auto slots_of = [&](uint64_t qi, auto&& occ_of) -> uint64_t {        // slot indices are 32-bit inside a chunk
             uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
-            if (lazy) return k ? (occ_of(q->qsub[qi]) + kLazyTile - 1) / kLazyTile * kLazyTile : 0;
             uint64_t t = 64ull * k;                                           // class alignment slack
             for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += occ_of(q->qsub[qi] + i);
             return t;
@@ -2703,7 +2371,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         const uint64_t group_cap = join_budget / 3;
         std::vector<uint64_t> fbytes(Q1 - Q0, 0);
         uint64_t filter_total = 0;
-        if (!lazy && ws->filter && logical_max_query + group_cap <= join_budget)
+        if (ws->filter && logical_max_query + group_cap <= join_budget)
             for (uint64_t qi = Q0; qi < Q1; ++qi) {
                 uint64_t b = filter_bytes(q, pl, ws, qi, nbw);
                 if (b > group_cap) b = 0;
@@ -2720,8 +2388,8 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             return fail(VLG_E_WORKSPACE, "a query needs " + std::to_string(logical_max_query) + " bytes of join scratch; workspace cap allows " +
                                              std::to_string(cap_bytes));
         const uint64_t want_bytes = std::min<uint64_t>(logical_total, cap_bytes);
-        uint64_t meta = (q->qsub[Q1] - q->qsub[Q0] + 4) * (sizeof(SegMeta) + 48) + (Q1 - Q0 + 4) * (sizeof(QueryMeta) + sizeof(LQuery) + 32) +
-                        (want_bytes / (kLazyTile * 8) + (Q1 - Q0) + 8) * 48 + (1ull << 20);
+        uint64_t meta = (q->qsub[Q1] - q->qsub[Q0] + 4) * (sizeof(SegMeta) + 48) + (Q1 - Q0 + 4) * (sizeof(QueryMeta) + 96) +
+                        (want_bytes / 8192 + (Q1 - Q0) + 8) * 48 + (1ull << 20);
         if (vlg_status s = ws_reserve(ws, phys_bytes + filter_need + want_bytes + meta + fixed)) return s;
         Arena A{ws->arena, ws->arena_bytes};
         pos_t* P = nullptr;
@@ -2768,8 +2436,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
                     T += t; S += sl; C += pc;
                     ++q1;
                 }
-                vlg_status s = lazy ? run_lazy_chunk<pos_t>(q, ws, res, q0, q1, pl, poff, P, GA, d_stats)
-                                    : run_join_chunk<pos_t>(idx, q, ws, res, q0, q1, pl, poff, P, GA, d_stats, fgp, Pc);
+                vlg_status s = run_join_chunk<pos_t>(idx, q, ws, res, q0, q1, pl, poff, P, GA, d_stats, fgp, Pc);
                 if (s) return s;
                 tr.mark("join chunk");
                 q0 = q1;
