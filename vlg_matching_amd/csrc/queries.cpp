@@ -1,0 +1,220 @@
+// Query batches: the two dialects of the reference's pattern syntax parsed on the host, the batch uploaded to HBM.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "common.hpp"
+#include "search_types.hpp"
+
+using namespace vlg;
+
+// =============================================================================================
+// Query batches
+// =============================================================================================
+
+namespace {
+
+// std::stoull on [s,e): optional blanks, optional sign, digits; trailing characters ignored
+bool parse_u64(const char* s, const char* e, uint64_t& out)
+{
+    while (s < e && (*s == ' ' || (*s >= 9 && *s <= 13))) ++s;
+    bool neg = false;
+    if (s < e && (*s == '+' || *s == '-')) { neg = *s == '-'; ++s; }
+    if (s >= e || *s < '0' || *s > '9') return false;
+    uint64_t v = 0;
+    while (s < e && *s >= '0' && *s <= '9') {
+        uint64_t d = (uint64_t)(*s - '0');
+        if (v > (0xFFFFFFFFFFFFFFFFull - d) / 10) return false;
+        v = v * 10 + d;
+        ++s;
+    }
+    out = neg ? (uint64_t)(0 - v) : v;
+    return true;
+}
+
+struct Parsed {
+    std::vector<std::pair<uint64_t, uint64_t>> sub;   // (offset, length) into the query text
+    std::vector<uint64_t> lo, hi;                     // per sub-pattern (entry 0 unused)
+    uint64_t end_len = 0;
+};
+
+// gapped_pattern_query (include/sdsl/vlg_index.hpp:54-105) / gapped_pattern (benchmark utils.hpp:25-70)
+vlg_status parse_one(const char* re, uint64_t len, int dialect, Parsed& out, std::string& why)
+{
+    std::vector<uint64_t> raw_lo(1, 0), raw_hi(1, 0);
+    uint64_t start = 0;
+    for (;;) {
+        uint64_t gp = std::string::npos;
+        for (uint64_t i = start; i + 1 < len; ++i) if (re[i] == '.' && re[i + 1] == '{') { gp = i; break; }
+        if (gp == std::string::npos) break;
+        if (out.sub.size() + 1 >= VLG_MAX_SUBPATTERNS) { why = "too many sub-patterns"; return VLG_E_INVALID; }
+        uint64_t ge = std::string::npos, comma = std::string::npos;
+        for (uint64_t i = gp; i < len; ++i) if (re[i] == '}') { ge = i; break; }
+        if (ge == std::string::npos) { why = "invalid gap description"; return VLG_E_PARSE; }
+        for (uint64_t i = gp; i <= ge; ++i) if (re[i] == ',') { comma = i; break; }
+        uint64_t a = 0, b = 0;
+        if (comma == std::string::npos || !parse_u64(re + gp + 2, re + comma, a) || !parse_u64(re + comma + 1, re + ge, b)) {
+            why = "invalid gap description";
+            return VLG_E_PARSE;
+        }
+        if (a > b) { why = "invalid gap description: min-gap > max-gap"; return VLG_E_PARSE; }           // vlg_index.hpp:92-94
+        // the reference adds |s| modulo 2^64 (vlg_index.hpp:95); bounds that large are rejected instead of wrapped
+        if (b >= (1ull << 62)) { why = "gap bound too large (>= 2^62)"; return VLG_E_INVALID; }
+        out.sub.emplace_back(start, gp - start);
+        raw_lo.push_back(a);
+        raw_hi.push_back(b);
+        if (dialect == VLG_DIALECT_LIBRARY) {
+            if (ge + 1 == len || re[ge + 1] != '?') {                                                   // vlg_index.hpp:97-99
+                why = "invalid gap description: expected '?' (lazy semantics)";
+                return VLG_E_PARSE;
+            }
+            start = ge + 2;
+        } else {
+            start = ge + 1;
+        }
+    }
+    out.sub.emplace_back(start, len - start);
+    for (auto& s : out.sub) if (s.second == 0) { why = "empty sub-pattern"; return VLG_E_INVALID; }
+    size_t k = out.sub.size();
+    out.lo.assign(k, 0);
+    out.hi.assign(k, 0);
+    if (dialect == VLG_DIALECT_LIBRARY) {
+        for (size_t i = 1; i < k; ++i) {                                                                // vlg_index.hpp:95
+            out.lo[i] = raw_lo[i] + out.sub[i - 1].second;
+            out.hi[i] = raw_hi[i] + out.sub[i - 1].second;
+        }
+        out.end_len = out.sub[k - 1].second;                                                            // vlg_index.hpp:262,306
+    } else {
+        for (size_t i = 1; i < k; ++i) {                                                                // index_sasearch.hpp:68-69
+            out.lo[i] = raw_lo[1] + out.sub[0].second;
+            out.hi[i] = raw_hi[1] + out.sub[0].second;
+        }
+        out.end_len = out.sub[0].second;                                                                // index_sasearch.hpp:113
+    }
+    return VLG_OK;
+}
+
+vlg_status upload_queries(vlg_queries* q)
+{
+    q->kmax = 0; q->kmin = 0xFFFFFFFFu;
+    for (uint64_t i = 0; i < q->nq; ++i) {
+        uint32_t k = (uint32_t)(q->qsub[i + 1] - q->qsub[i]);
+        q->kmax = std::max<uint32_t>(q->kmax, k);
+        if (k) q->kmin = std::min<uint32_t>(q->kmin, k);
+    }
+    if (q->kmin == 0xFFFFFFFFu) q->kmin = 0;
+    VLG_HIP_TRY(hipMalloc((void**)&q->d_blob, q->blob.size() + 16));
+    VLG_HIP_TRY(hipMalloc((void**)&q->d_suboff, (q->nsub + 1) * 8));
+    if (!q->blob.empty()) VLG_HIP_TRY(hipMemcpy(q->d_blob, q->blob.data(), q->blob.size(), hipMemcpyHostToDevice));
+    VLG_HIP_TRY(hipMemcpy(q->d_suboff, q->suboff.data(), (q->nsub + 1) * 8, hipMemcpyHostToDevice));
+    return VLG_OK;
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_parse_query(const char* re, uint64_t len, int dialect, vlg_parsed_query* out)
+{
+    if (!out || (len && !re)) return fail(VLG_E_INVALID, "null argument");
+    if (dialect != VLG_DIALECT_LIBRARY && dialect != VLG_DIALECT_BENCHMARK) return fail(VLG_E_INVALID, "unknown dialect");
+    memset(out, 0, sizeof *out);
+    Parsed p;
+    std::string why;
+    vlg_status st = parse_one(re, len, dialect, p, why);
+    if (st) return fail(st, why);
+    out->k = (uint32_t)p.sub.size();
+    for (uint32_t i = 0; i < out->k; ++i) {
+        out->sub_off[i] = p.sub[i].first; out->sub_len[i] = p.sub[i].second;
+        out->lo[i] = p.lo[i]; out->hi[i] = p.hi[i];
+    }
+    out->end_len = p.end_len;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_off, uint64_t n_queries, int dialect, int* h_status,
+                                        vlg_queries** out)
+{
+    if (!out || (n_queries && (!h_text || !h_off))) return fail(VLG_E_INVALID, "null argument");
+    if (dialect != VLG_DIALECT_LIBRARY && dialect != VLG_DIALECT_BENCHMARK) return fail(VLG_E_INVALID, "unknown dialect");
+    *out = nullptr;
+    vlg_queries* q = new vlg_queries();
+    q->nq = n_queries;
+    q->qsub.assign(1, 0);
+    q->suboff.assign(1, 0);
+    vlg_status first_err = VLG_OK;
+    std::string first_why;
+    for (uint64_t i = 0; i < n_queries; ++i) {
+        Parsed p;
+        std::string why;
+        const char* re = h_text + h_off[i];
+        vlg_status st = parse_one(re, h_off[i + 1] - h_off[i], dialect, p, why);
+        if (h_status) h_status[i] = st;
+        if (st) {
+            if (!first_err) { first_err = st; first_why = "query " + std::to_string(i) + ": " + why; }
+        } else {
+            for (size_t s = 0; s < p.sub.size(); ++s) {
+                q->blob.insert(q->blob.end(), re + p.sub[s].first, re + p.sub[s].first + p.sub[s].second);
+                q->suboff.push_back(q->blob.size());
+                q->lo.push_back(p.lo[s]);
+                q->hi.push_back(p.hi[s]);
+            }
+        }
+        q->qsub.push_back(q->suboff.size() - 1);     // a failed query keeps zero sub-patterns
+        q->end_len.push_back(st ? 0 : p.end_len);
+    }
+    q->nsub = q->suboff.size() - 1;
+    if (first_err && !h_status) { delete q; return fail(first_err, first_why); }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete q; return fail(VLG_E_NO_DEVICE, "no HIP device available"); }
+    if (vlg_status st = upload_queries(q)) { vlg_queries_destroy(q); return st; }
+    *out = q;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_queries_create(const uint8_t* h_blob, const uint64_t* h_suboff, const uint64_t* h_qsub, const uint64_t* h_lo,
+                                         const uint64_t* h_hi, const uint64_t* h_end_len, uint64_t n_queries, vlg_queries** out)
+{
+    if (!out || (n_queries && (!h_suboff || !h_qsub || !h_lo || !h_hi || !h_end_len))) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    vlg_queries* q = new vlg_queries();
+    q->nq = n_queries;
+    q->nsub = n_queries ? h_qsub[n_queries] : 0;
+    q->qsub.assign(h_qsub, h_qsub + n_queries + 1);
+    if (!n_queries) q->qsub.assign(1, 0);
+    q->suboff.assign(1, 0);
+    if (q->nsub) q->suboff.assign(h_suboff, h_suboff + q->nsub + 1);
+    for (uint64_t i = 0; i < n_queries; ++i)
+        if (q->qsub[i + 1] < q->qsub[i] || q->qsub[i + 1] - q->qsub[i] > VLG_MAX_SUBPATTERNS) { delete q; return fail(VLG_E_INVALID, "bad query offsets"); }
+    for (uint64_t s = 0; s < q->nsub; ++s)
+        if (q->suboff[s + 1] <= q->suboff[s]) { delete q; return fail(VLG_E_INVALID, "empty sub-pattern"); }
+    if (q->nsub && !h_blob) { delete q; return fail(VLG_E_INVALID, "null argument"); }
+    if (q->nsub) q->blob.assign(h_blob, h_blob + q->suboff[q->nsub]);
+    q->lo.assign(h_lo, h_lo + q->nsub);
+    q->hi.assign(h_hi, h_hi + q->nsub);
+    for (uint64_t i = 0; i < n_queries; ++i)
+        for (uint64_t sidx = q->qsub[i] + 1; sidx < q->qsub[i + 1]; ++sidx)
+            if (q->lo[sidx] > q->hi[sidx] || q->hi[sidx] >= (1ull << 63)) { delete q; return fail(VLG_E_INVALID, "bad gap bounds"); }
+    q->end_len.assign(h_end_len, h_end_len + n_queries);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete q; return fail(VLG_E_NO_DEVICE, "no HIP device available"); }
+    if (vlg_status st = upload_queries(q)) { vlg_queries_destroy(q); return st; }
+    *out = q;
+    return VLG_OK;
+}
+
+extern "C" uint64_t vlg_queries_count(const vlg_queries* q) { return q ? q->nq : 0; }
+extern "C" uint64_t vlg_queries_subpatterns(const vlg_queries* q) { return q ? q->nsub : 0; }
+extern "C" vlg_status vlg_queries_k(const vlg_queries* q, uint32_t* h_k)
+{
+    if (!q || (q->nq && !h_k)) return fail(VLG_E_INVALID, "null argument");
+    for (uint64_t i = 0; i < q->nq; ++i) h_k[i] = (uint32_t)(q->qsub[i + 1] - q->qsub[i]);
+    return VLG_OK;
+}
+extern "C" void vlg_queries_destroy(vlg_queries* q)
+{
+    if (!q) return;
+    if (q->d_blob) (void)hipFree(q->d_blob);
+    if (q->d_suboff) (void)hipFree(q->d_suboff);
+    delete q;
+}
+

@@ -1,0 +1,16 @@
+// Types shared by the translation units of the search path.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+struct vlg_queries {
+    uint64_t nq = 0, nsub = 0;
+    std::vector<uint64_t> qsub;      // [nq+1]
+    std::vector<uint64_t> suboff;    // [nsub+1]
+    std::vector<uint8_t> blob;
+    std::vector<uint64_t> lo, hi;    // [nsub]
+    std::vector<uint64_t> end_len;   // [nq]
+    uint32_t kmax = 0, kmin = 0;     // over queries with at least one sub-pattern
+    uint8_t* d_blob = nullptr;
+    uint64_t* d_suboff = nullptr;
+};
