@@ -314,6 +314,7 @@ def main():
             "logical_occ_per_sec": n_logical * args.steps / dt,
             "logical_occ_per_step": n_logical,
             "matches_per_step": n_matches,
+            "join_slots_per_step_rank0": s["join_slots"],   # list elements the join evaluated (after the window filter)
             "checksum_rank0": s["checksum"],
             "lf_steps_per_occ": s["lf_steps"] / max(s["located_occurrences"], 1),
             "wt_levels_per_lf": s["wt_levels_locate"] / max(s["lf_steps"], 1),

@@ -265,6 +265,8 @@ typedef struct {
     uint64_t n_chunks;
     uint64_t logical_occurrences; /* sum of the list lengths the joins consumed (what the reference
                                      would locate query by query)                                 */
+    uint64_t join_slots;          /* list elements the join passes evaluated: the non-final lists of every live
+                                     query, after the window filter                               */
 } vlg_result_summary;
 
 vlg_status vlg_result_summary_get(const vlg_result* r, vlg_result_summary* s);

@@ -421,6 +421,7 @@ def test_window_filter_equals_unfiltered_join_and_oracle(V, oracle, name, seed, 
     a, b = idx.search(qs, workspace=ws_n), idx.search(qs, workspace=ws_f)
     assert not [k for k, v in ws_n.kernel_stats().items() if k.startswith("filter_") and v["launches"]]
     assert ws_f.kernel_stats()["filter_compact"]["launches"] > 0
+    assert 0 < b.summary["join_slots"] <= a.summary["join_slots"] + 64 * kmax * b.summary["n_chunks"]      # (+ class alignment per chunk)
     for k in ("n_matches", "checksum", "n_tuple_values", "logical_occurrences", "located_occurrences"):
         assert a.summary[k] == b.summary[k], k
     for x, y in zip(a.fetch(), b.fetch()):

@@ -40,7 +40,7 @@ class IndexInfo(C.Structure):
 class ResultSummary(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_queries", "n_matches", "checksum", "n_tuple_values", "located_occurrences",
                                            "lf_steps", "wt_levels_locate", "wt_levels_bsearch", "n_chunks",
-                                           "logical_occurrences")]
+                                           "logical_occurrences", "join_slots")]
 
 
 class ParsedQuery(C.Structure):

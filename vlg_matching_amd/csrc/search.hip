@@ -756,6 +756,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     res->sum.n_matches += M;
     res->sum.n_tuple_values += TV;
     res->sum.n_chunks++;
+    res->sum.join_slots += T;
     return VLG_OK;
 }
 
