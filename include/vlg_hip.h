@@ -300,7 +300,8 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
  * "filter" (default 1): before the join drop the list elements whose gap windows hold no element of the neighbouring
  * lists (they are in no match); "filter_min" (default 2^16) = join slots below which a query is joined as it is;
  * "filter_pivot" (default 1): filter outwards from the shortest list of a query when it is >= 12x shorter than all of
- * them together ("filter_pivot_ratio", default 12), otherwise (or with 0) by streaming sweeps over block bitmaps.
+ * them together ("filter_pivot_ratio", default 12), otherwise (or with 0) by streaming sweeps over block bitmaps;
+ * "filter_group_bytes" (default 0 = a third of the join scratch) caps the filter state of the queries filtered together.
  * Results are identical whatever the options. */
 vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* name, int64_t value);
 vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n);

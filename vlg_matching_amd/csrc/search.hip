@@ -53,6 +53,7 @@ struct vlg_workspace {
     bool filter = true;         // window filter: drop the list elements that can be in no match before the join
     uint64_t filter_min = 1ull << 16;   // queries with fewer join slots are joined as they are
     bool filter_pivot = true;   // filter from the shortest list of a query outwards when it is much shorter than the rest
+    uint64_t filter_group_bytes = 0;    // cap of the filter state of one group of queries (0: a third of the join budget)
     uint64_t filter_pivot_ratio = 12;   // ... i.e. when all lists together are at least this many times longer (measured on C3: 12)
     uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
@@ -201,6 +202,7 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "filter_min")) { ws->filter_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_pivot")) { ws->filter_pivot = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter_pivot_ratio")) { ws->filter_pivot_ratio = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "filter_group_bytes")) { ws->filter_group_bytes = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "sweep_tail")) { ws->sweep_tail = (uint64_t)value; return VLG_OK; }
     return fail(VLG_E_INVALID, std::string("unknown workspace option ") + name);
 }
@@ -846,7 +848,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         // window filter: state of the filtered queries of a group (at most a third of the budget), dropped query by query if it
         // would not leave room for the largest unfiltered join
         const uint64_t nbw = (((idx->hdr.n >> filter_block_shift(idx->hdr.n)) + 1) + 63) / 64;
-        const uint64_t group_cap = join_budget / 3;
+        const uint64_t group_cap = ws->filter_group_bytes ? std::min<uint64_t>(ws->filter_group_bytes, join_budget / 3) : join_budget / 3;
         std::vector<uint64_t> fbytes(Q1 - Q0, 0);
         uint64_t filter_total = 0;
         if (ws->filter && logical_max_query + group_cap <= join_budget)
