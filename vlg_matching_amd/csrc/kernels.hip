@@ -807,8 +807,9 @@ template vlg_status launch_locate<uint64_t>(const IndexView&, uint64_t*, uint64_
 size_t sweep_temp_bytes(uint64_t total, uint32_t sigma, hipStream_t stream)
 {
     size_t tb = 0;
-    uint16_t* k = nullptr; uint64_t* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, tb, k, k, v, v, total, 0, bit_width64(sigma), stream);
+    rocprim::double_buffer<uint16_t> k(nullptr, nullptr);
+    rocprim::double_buffer<uint64_t> v(nullptr, nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, tb, k, v, total, 0, bit_width64(sigma), stream);   // the sweep's own two buffers alternate
     return tb;
 }
 
@@ -854,14 +855,16 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             VLG_HIP_TRY(hipGetLastError());
             size_t tb = temp_bytes;
             if (timer) timer->begin(1);
-            hipError_t se = rocprim::radix_sort_pairs(temp, tb, key_a, key_b, val_a, val_b, alive, 0, bits, stream);
+            rocprim::double_buffer<uint16_t> dk(key_a, key_b);
+            rocprim::double_buffer<uint64_t> dv(val_a, val_b);
+            hipError_t se = rocprim::radix_sort_pairs(temp, tb, dk, dv, alive, 0, bits, stream);
             if (timer) timer->end(1);
             VLG_HIP_TRY(se);
             unsigned long long done = 0;
             VLG_HIP_TRY(hipMemcpyAsync(&done, d_counter, 8, hipMemcpyDeviceToHost, stream));
             VLG_HIP_TRY(hipStreamSynchronize(stream));
-            std::swap(val_a, val_b);
-            std::swap(key_a, key_b);
+            key_a = dk.current(); key_b = dk.alternate();
+            val_a = dv.current(); val_b = dv.alternate();
             alive -= done;
             ++step;
             if (step > 1u << 20) return fail(VLG_E_INTERNAL, "locate sweep did not converge");

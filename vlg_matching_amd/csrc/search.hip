@@ -826,24 +826,32 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         }
         size_t sort_tmp = 0;
         if (phys) {
-            pos_t* np = nullptr; uint32_t* nu = nullptr;
-            VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, np, np, (unsigned)phys, (unsigned)dlist.size(), nu, nu, 0,
-                                                           bit_width64(idx->hdr.n), ws->stream));
+            // the sort build_physical will choose (same condition there): one radix sort of (list, position) keys, or a segmented one
+            const unsigned pos_bits = std::max(1u, bit_width64(idx->hdr.n >= 2 ? idx->hdr.n - 2 : 0));
+            if (phys >= ws->global_sort_min && pos_bits + bit_width64(dlist.size()) <= 64) {
+                rocprim::double_buffer<uint64_t> nk(nullptr, nullptr);
+                VLG_HIP_TRY(rocprim::radix_sort_keys(nullptr, sort_tmp, nk, phys, 0, 64, ws->stream));
+            } else {
+                pos_t* np = nullptr; uint32_t* nu = nullptr;
+                VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, np, np, (unsigned)phys, (unsigned)dlist.size(), nu, nu, 0,
+                                                               pos_bits, ws->stream));
+            }
             if (ws->sweep && phys >= ws->sweep_min)
                 sort_tmp = std::max(sort_tmp, sweep_temp_bytes(phys, idx->hdr.sigma, ws->stream));
-            if (phys >= ws->global_sort_min) {
-                size_t tb = 0;
-                rocprim::double_buffer<uint64_t> nk(nullptr, nullptr);
-                VLG_HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, nk, phys, 0, 64, ws->stream));
-                sort_tmp = std::max(sort_tmp, tb);
-            }
         }
         const bool will_sweep = ws->sweep && phys >= ws->sweep_min;
-        // the trail table (8 B per text position) and the records (8 B per occurrence) must leave most of the workspace to the rest
+        // the trail table (8 B per text position) and the records (8 B per occurrence) must leave room for the joins
         uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup ? (idx->hdr.n + phys) * 8 + 512 : 0;
-        if (trail_bytes > budget / 4) trail_bytes = 0;
+        const uint64_t phys_plain = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20);
+        if (trail_bytes) {
+            const uint64_t left = budget > phys_plain + trail_bytes ? budget - phys_plain - trail_bytes : 0;
+            if (left < std::max<uint64_t>(2 * logical_max_query, budget / 8)) trail_bytes = 0;
+        }
         const bool share_trails = trail_bytes != 0;
-        const uint64_t phys_bytes = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20) + trail_bytes;
+        if (tr.on) fprintf(stderr, "[vlg trace] super-chunk: %llu occurrences, %.1f GB physical, trails %s (%.1f GB), budget %.1f GB, largest join %.1f GB\n",
+                           (unsigned long long)phys, phys_plain / 1e9, share_trails ? "shared" : "not shared",
+                           ((idx->hdr.n + phys) * 8) / 1e9, budget / 1e9, logical_max_query / 1e9);
+        const uint64_t phys_bytes = phys_plain + trail_bytes;
         const uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
         // window filter: state of the filtered queries of a group (at most a third of the budget), dropped query by query if it
         // would not leave room for the largest unfiltered join
