@@ -3,6 +3,7 @@ on the same seeded inputs and against the committed known answers.  Bit-exact ev
 import ctypes as C
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -694,3 +695,15 @@ def test_64bit_position_kernels(torch_cuda, V, oracle, monkeypatch):
         V.capi.check(L.vlg_sa_batch(h._h, d_i.data_ptr(), d_o.data_ptr(), len(ii), None))
         torch.cuda.synchronize()
         assert (host_u64(d_o) == sa[ii.astype(np.int64)]).all()
+
+
+def test_strategy_fuzz_short(V, monkeypatch, capsys):
+    """A few seconds of tools/fuzz_strategies.py: random texts and batches, all shortcuts off vs a random combination of them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_strategies", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                 "tools", "fuzz_strategies.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["fuzz_strategies.py", "8", "20261003"])
+    mod.main()
+    assert "fuzz ok" in capsys.readouterr().out
