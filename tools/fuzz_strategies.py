@@ -15,7 +15,7 @@ from vlg_matching_amd.index import Workspace  # noqa: E402
 
 def make_text(rng):
     kind = int(rng.integers(0, 5))
-    n = int(rng.integers(50, 120000))
+    n = int(rng.integers(50, 120000)) if rng.random() < 0.85 else int(rng.integers(500000, 4000000))      # mostly small, sometimes MBs
     if kind == 0:
         return rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes()
     if kind == 1:
