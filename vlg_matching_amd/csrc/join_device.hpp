@@ -584,21 +584,39 @@ __global__ void chain_walk_kernel(const SegMeta* __restrict__ sm, const QueryMet
     counts[q] = n_match;
 }
 
-__global__ void chain_emit_kernel(const uint32_t* __restrict__ rec_begin, const uint32_t* __restrict__ rec_count,
-                                  const uint2* __restrict__ records, uint32_t total_rec_slots, const uint32_t* __restrict__ rec_query,
-                                  const uint32_t* __restrict__ jump, uint32_t* __restrict__ mlist)
+// A wave per record: the tile's jump targets are staged in LDS with coalesced loads, one lane hops through them there
+// (an LDS read per match instead of a dependent global load), then the wave writes the matches out together.
+__global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restrict__ rec_begin, const uint32_t* __restrict__ rec_count,
+                                                         const uint2* __restrict__ records, uint32_t total_rec_slots,
+                                                         const uint32_t* __restrict__ rec_query, const uint32_t* __restrict__ jump,
+                                                         uint64_t r1 /* end of the slots that have a jump */, uint32_t* __restrict__ mlist)
 {
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < total_rec_slots; r += gridDim.x * blockDim.x) {
-        uint32_t q = rec_query[r];                       // slot r belongs to query q; used only if r - rec_begin[q] < rec_count[q]
-        if (r - rec_begin[q] >= rec_count[q]) continue;
-        uint2 rc = records[r];
-        uint32_t cur = rc.x, out = rc.y;
-        const uint32_t tile_end = (cur / kTile + 1) * kTile;
-        while (cur != kNone && cur < tile_end) {
-            mlist[out++] = cur;
-            cur = jump[cur];
+    __shared__ uint32_t s_jump[4][kTile];
+    __shared__ uint32_t s_list[4][kTile];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t r = uniform((uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (r >= total_rec_slots) return;
+    const uint32_t q = rec_query[r];                         // slot r belongs to query q; used only if r - rec_begin[q] < rec_count[q]
+    if (r - rec_begin[q] >= rec_count[q]) return;
+    const uint2 rc = records[r];
+    const uint64_t tile_base = (uint64_t)(rc.x / kTile) * kTile;
+#pragma unroll
+    for (uint32_t i = 0; i < kTile / 64; ++i) {
+        const uint64_t e = tile_base + lane + 64 * i;
+        s_jump[wv][lane + 64 * i] = e < r1 ? jump[e] : kNone;
+    }
+    wave_sync();
+    uint32_t cnt = 0;
+    if (lane == 0) {
+        uint32_t cur = rc.x;
+        while (cur != kNone && (uint64_t)cur < tile_base + kTile) {
+            s_list[wv][cnt++] = cur;
+            cur = s_jump[wv][cur - (uint32_t)tile_base];
         }
     }
+    wave_sync();
+    cnt = uniform(__shfl(cnt, 0));
+    for (uint32_t i = lane; i < cnt; i += 64) mlist[rc.y + i] = s_list[wv][i];
 }
 
 // tuples of every match: walk the links from the level-0 element.  One thread per (query, match) slot of list 0.

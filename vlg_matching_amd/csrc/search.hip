@@ -725,7 +725,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         hipLaunchKernelGGL(chain_walk_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, d_sm, d_qm, nq, d_qstart, xh, d_recb, d_rec, d_recc,
                            d_counts);
         if (n_rec)
-            hipLaunchKernelGGL(chain_emit_kernel, dim3(grid_for(n_rec)), dim3(256), 0, st, d_recb, d_recc, d_rec, n_rec, d_recq, jump, mlist);
+            hipLaunchKernelGGL(chain_emit_kernel, dim3((n_rec + 3) / 4), dim3(256), 0, st, d_recb, d_recc, d_rec, n_rec, d_recq, jump, lvl0_end, mlist);
     }
     VLG_HIP_TRY(hipGetLastError());
     // ---- sizes of the result, then gather -------------------------------------------------------------
