@@ -588,7 +588,8 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
             else out[v64 >> kShift] = (pos_t)r;
             key[e] = (uint16_t)iv.sigma;
             ++n_fin;
-        } else if (kTrail && trail[i] != 0 && (trail[i] & 0xFFFFu) != step) {        // (an equal step is a twin: same index in two lists)
+        } else if (kTrail && step != 0 && trail[i] != 0 && (trail[i] & 0xFFFFu) != step) {   // round 0: the table is empty; an equal step is a
+                                                                                              // twin (the same index in two lists)
             // someone stood here `delta` steps ago: same text trail, `delta` positions further left when it started
             const uint64_t m = trail[i];
             const uint64_t owner = (m >> 16) - 1, delta = step - (m & 0xFFFFu);
