@@ -69,28 +69,35 @@ __device__ __forceinline__ uint32_t gallop_lower_bound(const pos_t* __restrict__
 // every element before it is smaller than every key.  Lanes still unresolved after kCoopWindows windows fall back
 // to galloping from the last window's end.
 constexpr uint32_t kCoopWindows = 4;
+// Keys and list elements are compared as pos_t (one cross-lane read per step for 32-bit positions); `val` receives the list
+// element at the answer, so the caller needs no load of its own for it.
 template <typename pos_t>
-__device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P, uint32_t wb, uint32_t b, uint64_t key, bool need)
+__device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P, uint32_t wb, uint32_t b, pos_t key, bool need, pos_t& val)
 {
     const uint32_t lane = threadIdx.x & 63;
+    constexpr pos_t kInf = (pos_t)~(pos_t)0;
     uint32_t res = b;
     for (uint32_t it = 0; it < kCoopWindows; ++it) {
         if (!__any(need)) break;
         const uint32_t idx = wb + lane;
-        const uint64_t w = idx < b ? (uint64_t)P[idx] : ~0ull;       // +inf behind the list
-        const uint64_t wlast = __shfl(w, 63);
+        const pos_t w = idx < b ? P[idx] : kInf;                     // +inf behind the list
+        const pos_t wlast = __shfl(w, 63);
         const bool can = need && key <= wlast;
         uint32_t lo = 0, hi = 63;                                    // for `can` lanes w[63] >= key, so the answer is in [0,63]
 #pragma unroll
         for (uint32_t st = 0; st < 6; ++st) {
             const uint32_t mid = (lo + hi) >> 1;
-            const uint64_t v = __shfl(w, (int)mid);
+            const pos_t v = __shfl(w, (int)mid);
             if (v < key) lo = mid + 1; else hi = mid;
         }
-        if (can) { res = wb + lo; need = false; }
+        const pos_t at = __shfl(w, (int)lo);
+        if (can) { res = wb + lo; val = at; need = false; }
         wb += 64;
     }
-    if (need) res = gallop_lower_bound(P, wb < b ? wb : b, b, key);
+    if (need) {
+        res = gallop_lower_bound(P, wb < b ? wb : b, b, (uint64_t)key);
+        if (res < b) val = P[res];
+    }
     return res < b ? res : b;
 }
 
@@ -339,7 +346,7 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
     uint64_t seg_end = seg_begin[s_w + 1];
     SegMeta m = sm[s_w], nx = sm[m.next];
     uint32_t hint_seg = kNone, hint = 0;                           // answer of the last lane of the previous step and its segment
-    uint64_t x_pre = 0;
+    pos_t x_pre = 0;
     bool have_pre = false;
     for (uint64_t base = run_begin; base < run_end; base += 64) {
         if (base >= seg_end) {                                     // entered a new segment (skips empty ones)
@@ -354,20 +361,28 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
         uint32_t j = 0, s_last = s_w;
         if (step_last < seg_end) {
             // ---- fast path: one segment ---------------------------------------------------------------
-            uint64_t x = have_pre ? x_pre : (active ? (uint64_t)P[phys_of(m, (uint32_t)e)] : 0);
+            const pos_t x = have_pre ? x_pre : (active ? P[phys_of(m, (uint32_t)e)] : (pos_t)0);
             const uint64_t en = e + 64;                            // next step's position, in flight during the search
             have_pre = base + 64 < run_end && (base + 127 < run_end ? base + 127 : run_end - 1) < seg_end;
-            if (have_pre) x_pre = en < run_end ? (uint64_t)P[phys_of(m, (uint32_t)en)] : 0;
-            const uint64_t tlo = sat_add(x, nx.lo), thi = sat_add(x, nx.hi);
-            if (hint_seg == s_w) j = wave_lower_bound(P, hint, nx.pend, tlo, active);
-            else if (active) j = gallop_lower_bound(P, nx.pbegin, nx.pend, tlo);
+            if (have_pre) x_pre = en < run_end ? P[phys_of(m, (uint32_t)en)] : (pos_t)0;
+            pos_t tlo, thi, v = 0;
+            const bool want = gap_window<pos_t>((uint64_t)x, nx.lo, nx.hi, tlo, thi) && active;    // false: no position can be in the window
+            j = nx.pend;
+            if (hint_seg == s_w) j = wave_lower_bound(P, hint, nx.pend, tlo, want, v);
+            else if (want) { j = gallop_lower_bound(P, nx.pbegin, nx.pend, (uint64_t)tlo); if (j < nx.pend) v = P[j]; }
+            if (!want) j = nx.pend;
             bool ok = false;
-            if (active) {
+            if (want && j < nx.pend) {
                 if (dist == 1) {                                   // next list is the last one: every element is feasible
-                    if (j < nx.pend) { const uint64_t v = P[j]; ok = v <= thi; if (ok) { link[e] = j; endp[e] = (pos_t)v; } }
-                } else if (j < nx.pend) {
-                    uint32_t ej = next_feasible(fb, (uint64_t)nx.begin + (j - nx.pbegin));   // nearest feasible logical element at or after it
-                    if (ej < nx.end && (uint64_t)P[phys_of(nx, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+                    ok = v <= thi;
+                    if (ok) { link[e] = j; endp[e] = v; }
+                } else {
+                    const uint32_t at = nx.begin + (j - nx.pbegin);
+                    const uint32_t ej = next_feasible(fb, at);     // nearest feasible logical element at or after it
+                    if (ej < nx.end) {
+                        const pos_t pv = ej == at ? v : P[phys_of(nx, ej)];
+                        if (pv <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+                    }
                 }
             }
             const unsigned long long okm = __ballot(ok);
