@@ -240,6 +240,7 @@ def main():
     del text
     q = Queries(queries)                      # parsed + uploaded: resident in HBM before the timed region
     ws = Workspace(int(args.workspace_gb * (1 << 30)))
+    ws.set_option("reserve", int(args.workspace_gb * (1 << 30)))     # scratch allocated before the timed region whatever --warmup is
     for kv in filter(None, os.environ.get("VLG_BENCH_OPTIONS", "").split(",")):      # development: name=value workspace options
         ws.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 

@@ -302,6 +302,7 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
  * "filter_pivot" (default 1): filter outwards from the shortest list of a query when it is >= 12x shorter than all of
  * them together ("filter_pivot_ratio", default 12), otherwise (or with 0) by streaming sweeps over block bitmaps;
  * "filter_group_bytes" (default 0 = a third of the join scratch) caps the filter state of the queries filtered together.
+ * "reserve" = bytes of scratch to allocate right away (at most the workspace's cap) instead of on first use.
  * Results are identical whatever the options. */
 vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* name, int64_t value);
 vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n);

@@ -267,6 +267,7 @@ def test_search_chunked_equals_unchunked(V, cap_mb):
     qs = random_queries(text, np.random.default_rng(9), 300, kmax=3, mmax=3)
     from vlg_matching_amd.index import Workspace
     wa, wb = Workspace(), Workspace(max_hbm_bytes=(cap_mb << 20))
+    wb.set_option("reserve", cap_mb << 20)                # scratch allocated up front instead of on first use
     a = idx.search(qs, workspace=wa)
     b = idx.search(qs, workspace=wb)
     assert b.summary["n_chunks"] > a.summary["n_chunks"]

@@ -203,6 +203,10 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "filter_pivot")) { ws->filter_pivot = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter_pivot_ratio")) { ws->filter_pivot_ratio = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_group_bytes")) { ws->filter_group_bytes = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "reserve")) {                           // allocate the scratch now (+ the per-chunk metadata a batch adds on top of its budget)
+        const uint64_t b = std::min<uint64_t>((uint64_t)value, ws->cap_bytes);
+        return ws_reserve(ws, b + b / 96 + (256ull << 20));
+    }
     if (!strcmp(name, "sweep_tail")) { ws->sweep_tail = (uint64_t)value; return VLG_OK; }
     return fail(VLG_E_INVALID, std::string("unknown workspace option ") + name);
 }
