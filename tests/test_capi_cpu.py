@@ -127,3 +127,49 @@ def test_sdsl_file_reader_on_reference_written_image(V, refmod, tmp_path):
         V.index.read_sdsl_file(tmp_path / "junk.sdsl")
     with pytest.raises(V.VlgError):
         V.index.read_sdsl_file(tmp_path / "dna.sdsl", dens=16)     # wrong density for this file
+
+
+def test_sdsl_file_reader_survives_damaged_files(V, refmod, tmp_path):
+    """Truncated and bit-flipped csa_wt files: vlg_sdsl_file_open either parses them or reports VLG_E_INVALID -- no crash,
+    no runaway allocation.  Run in a child process so that a crash is a test failure."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import bwt_from_sa, dna_text
+    O = refmod
+    text = dna_text(3000, 8).tobytes()
+    tz = np.frombuffer(text + b"\0", dtype=np.uint8)
+    sa = O.suffix_array(tz)
+    good = tmp_path / "good.sdsl"
+    O.RefIndex(bwt_from_sa(tz, sa), sa, 0).write_csa_image(good, sa)
+    script = r'''
+import sys, os, numpy as np
+sys.path.insert(0, sys.argv[1])
+import vlg_matching_amd as V
+raw = bytearray(open(sys.argv[2], "rb").read())
+rng = np.random.default_rng(5)
+tmp = sys.argv[2] + ".bad"
+ok = bad = 0
+cases = [bytes(raw[:n]) for n in list(range(0, 64)) + [int(x) for x in rng.integers(64, len(raw), 150)]]
+for _ in range(400):
+    b = bytearray(raw)
+    for pos in rng.integers(0, len(b), int(rng.integers(1, 4))):
+        b[pos] = int(rng.integers(0, 256))
+    cases.append(bytes(b))
+for i, v in enumerate([0, 1, 2**63, 2**64 - 1, 2**40]):             # absurd sizes in the first header words
+    for off in (0, 8, 16):
+        b = bytearray(raw); b[off:off + 8] = int(v).to_bytes(8, "little"); cases.append(bytes(b))
+for c in cases:
+    open(tmp, "wb").write(c)
+    try:
+        V.index.read_sdsl_file(tmp)
+        ok += 1
+    except V.VlgError:
+        bad += 1
+print("done", ok, bad)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", script, root, str(good)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("done"), (r.returncode, r.stdout[-300:], r.stderr[-600:])
+    ok, bad = (int(x) for x in r.stdout.split()[1:3])
+    assert bad > 200                                          # most damage is detected; a flipped payload bit can still parse
