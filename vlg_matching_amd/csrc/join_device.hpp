@@ -328,43 +328,45 @@ __global__ void __launch_bounds__(256) join_init_kernel(const pos_t* __restrict_
     }
 }
 
-// link pass over the class [r0,r1) of slots that have `dist` sub-patterns after them.
+// link pass over the class [r0,r1) of slots that have `dist` sub-patterns after them (kLast: dist == 1, the next list is the
+// query's last one: all its elements are feasible and it has no join state).
 // Steps that lie inside one segment (almost all of them: lists are long) keep the segment's metadata in registers,
 // search as a wave behind the previous step's answer and have the next step's positions already in flight.
-template <typename pos_t>
+// Slot numbers are 32-bit inside a chunk (r1 <= 0xF0000000 + alignment), so all loop arithmetic is.
+template <typename pos_t, bool kLast>
 __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
-                                                        const SegMeta* __restrict__ sm, uint64_t r0, uint64_t r1, uint32_t dist,
+                                                        const SegMeta* __restrict__ sm, uint32_t r0, uint32_t r1,
                                                         FeasRef fb, uint64_t* __restrict__ fbits_out,
                                                         pos_t* __restrict__ endp, uint32_t* __restrict__ link)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t run_begin = r0 + wave * kRun;
-    if (run_begin >= r1) return;
-    const uint64_t run_end = run_begin + kRun < r1 ? run_begin + kRun : r1;
+    if (wave * kRun >= (uint64_t)(r1 - r0)) return;
+    const uint32_t run_begin = r0 + (uint32_t)wave * kRun;
+    const uint32_t run_end = r1 - run_begin > kRun ? run_begin + kRun : r1;
     uint32_t s_w = seg_find(seg_begin, nseg, run_begin);          // wave-uniform: segment of `base`
-    uint64_t seg_end = seg_begin[s_w + 1];
+    uint32_t seg_end = seg_begin[s_w + 1];
     SegMeta m = sm[s_w], nx = sm[m.next];
     uint32_t hint_seg = kNone, hint = 0;                           // answer of the last lane of the previous step and its segment
     pos_t x_pre = 0;
     bool have_pre = false;
-    for (uint64_t base = run_begin; base < run_end; base += 64) {
+    for (uint32_t base = run_begin; base < run_end; base += 64) {
         if (base >= seg_end) {                                     // entered a new segment (skips empty ones)
             while (seg_begin[s_w + 1] <= base) ++s_w;
             seg_end = seg_begin[s_w + 1];
             m = sm[s_w]; nx = sm[m.next];
             have_pre = false;
         }
-        const uint64_t e = base + lane;
+        const uint32_t e = base + lane;
         const bool active = e < run_end;
-        const uint64_t step_last = base + 63 < run_end ? base + 63 : run_end - 1;
+        const uint32_t step_last = run_end - base > 64 ? base + 63 : run_end - 1;
         uint32_t j = 0, s_last = s_w;
         if (step_last < seg_end) {
             // ---- fast path: one segment ---------------------------------------------------------------
-            const pos_t x = have_pre ? x_pre : (active ? P[phys_of(m, (uint32_t)e)] : (pos_t)0);
-            const uint64_t en = e + 64;                            // next step's position, in flight during the search
-            have_pre = base + 64 < run_end && (base + 127 < run_end ? base + 127 : run_end - 1) < seg_end;
-            if (have_pre) x_pre = en < run_end ? P[phys_of(m, (uint32_t)en)] : (pos_t)0;
+            const pos_t x = have_pre ? x_pre : (active ? P[phys_of(m, e)] : (pos_t)0);
+            const uint32_t en = e + 64;                            // next step's position, in flight during the search
+            have_pre = run_end - base > 64 && (run_end - base > 128 ? base + 127 : run_end - 1) < seg_end;
+            if (have_pre) x_pre = en < run_end ? P[phys_of(m, en)] : (pos_t)0;
             pos_t tlo, thi, v = 0;
             const bool want = gap_window<pos_t>((uint64_t)x, nx.lo, nx.hi, tlo, thi) && active;    // false: no position can be in the window
             j = nx.pend;
@@ -373,7 +375,7 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
             if (!want) j = nx.pend;
             bool ok = false;
             if (want && j < nx.pend) {
-                if (dist == 1) {                                   // next list is the last one: every element is feasible
+                if (kLast) {
                     ok = v <= thi;
                     if (ok) { link[e] = j; endp[e] = v; }
                 } else {
@@ -396,15 +398,15 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
                 while (seg_begin[s + 1] <= e) ++s;
                 const SegMeta ml = sm[s];
                 const SegMeta nl = sm[ml.next];
-                const uint64_t x = P[phys_of(ml, (uint32_t)e)];
+                const uint64_t x = P[phys_of(ml, e)];
                 const uint64_t tlo = sat_add(x, nl.lo), thi = sat_add(x, nl.hi);
                 j = gallop_lower_bound(P, (s == hint_seg) ? hint : nl.pbegin, nl.pend, tlo);
                 if (e < ml.end) {                                  // padding slots between classes belong to no segment
-                    if (dist == 1) {
+                    if (kLast) {
                         ok = j < nl.pend && (uint64_t)P[j] <= thi;
                         if (ok) { link[e] = j; endp[e] = P[j]; }
                     } else if (j < nl.pend) {
-                        uint32_t ej = next_feasible(fb, (uint64_t)nl.begin + (j - nl.pbegin));
+                        const uint32_t ej = next_feasible(fb, (uint64_t)nl.begin + (j - nl.pbegin));
                         if (ej < nl.end && (uint64_t)P[phys_of(nl, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
                     }
                 }

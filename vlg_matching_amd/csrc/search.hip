@@ -715,8 +715,12 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         uint64_t b0 = cls_slot_begin[dist], b1 = cls_slot_end[dist];
         if (b1 > b0) {
             Timed t(ws, KS_JOIN_LINK, 8ull * (b1 - b0));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, d_segb, nlive, d_sm, b0, b1,
-                               dist, fref, lvl_ptr[0], endp, link);
+            if (dist == 1)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t, true>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, d_segb, nlive, d_sm,
+                                   (uint32_t)b0, (uint32_t)b1, fref, lvl_ptr[0], endp, link);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t, false>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, d_segb, nlive, d_sm,
+                                   (uint32_t)b0, (uint32_t)b1, fref, lvl_ptr[0], endp, link);
         }
         if (vlg_status s = summarize_class(dist)) return s;
     }
