@@ -40,7 +40,7 @@ int main(int argc, char* const argv[])
         std::cout << "# index_bytes = " << bytes << std::endl;
         if (sdsl_too) {
             const std::string sdsl_file = col.path + "/index/index-" + idx.name() + ".sdsl";
-            check(vlg_index_save_sdsl(idx.handle(), sdsl_file.c_str()));
+            idx.save_sdsl(sdsl_file);
             std::cout << "# sdsl_file = " << sdsl_file << std::endl;
         }
         vlg_index_info info;

@@ -84,6 +84,14 @@ class index_fm_gpu
         check(vlg_index_from_parts(&p, &m_idx));
     }
 
+    // the reference's own on-disk format of csa_wt<wt_huff<>,32,64> (what store_to_file / load_from_file of stock sdsl use)
+    void save_sdsl(const std::string& path) const { check(vlg_index_save_sdsl(m_idx, path.c_str())); }
+    void load_sdsl(const std::string& path)
+    {
+        if (m_idx) { vlg_index_destroy(m_idx); m_idx = nullptr; }
+        check(vlg_index_load_sdsl(path.c_str(), 32, &m_idx));
+    }
+
     void swap(index_fm_gpu& o)
     {
         std::swap(m_idx, o.m_idx);
