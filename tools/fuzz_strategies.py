@@ -60,7 +60,11 @@ def main():
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     rounds = 0
+    t_say = time.time() + 30
     while time.time() < t_end:
+        if time.time() > t_say:
+            print("... %d batches" % rounds, flush=True)
+            t_say = time.time() + 30
         text = make_text(rng)
         try:
             idx = V.VlgIndex.build(text)
