@@ -62,6 +62,50 @@ __device__ __forceinline__ uint32_t gallop_lower_bound(const pos_t* __restrict__
     return lower_bound_dev(P, lo, hi, key);
 }
 
+// Keys the windows did not reach (the list is much denser than the keys): two-level search.  Lane t reads the LAST element of
+// window t behind the fence -- one round trip covers 64 windows -- every lane ranks its key among these 64 fences through
+// cross-lane reads and then bisects the one window that holds its answer (6 probes inside 256 bytes).  A galloping search
+// would pay ~2 log2(distance) dependent, scattered round trips instead.
+constexpr uint32_t kFarRounds = 4;
+template <typename pos_t>
+__device__ __forceinline__ void wave_far_lower_bound(const pos_t* __restrict__ P, uint32_t wb, uint32_t b, pos_t key, bool need, uint32_t& j, pos_t& val)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    constexpr pos_t kInf = (pos_t)~(pos_t)0;
+    for (uint32_t round = 0; round < kFarRounds && wb < b; ++round) {
+        if (!__any(need)) return;
+        const uint64_t fi = (uint64_t)wb + 64 * lane + 63;
+        const pos_t f = fi < b ? P[fi] : kInf;                       // windows that reach behind the list end with +inf
+        const pos_t flast = __shfl(f, 63);
+        const bool can = need && key <= flast;
+        uint32_t lo = 0, hi = 63;                                    // first window whose last element is >= key
+#pragma unroll
+        for (uint32_t st = 0; st < 6; ++st) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const pos_t v = __shfl(f, (int)mid);
+            if (v < key) lo = mid + 1; else hi = mid;
+        }
+        if (can) {
+            const uint64_t w0 = (uint64_t)wb + 64 * lo;              // the answer is in [w0, w0+63] (or b, in a clipped window)
+            uint32_t pos = 0;
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1) {
+                const uint64_t at = w0 + pos + step - 1;
+                if (at < b && P[at] < key) pos += step;
+            }
+            const uint64_t at = w0 + pos;
+            if (at < b) { j = (uint32_t)at; val = P[at]; } else j = b;
+            need = false;
+        }
+        const uint64_t nwb = (uint64_t)wb + 4096;
+        wb = nwb < b ? (uint32_t)nwb : b;
+    }
+    if (need) {
+        j = gallop_lower_bound(P, wb < b ? wb : b, b, (uint64_t)key);
+        if (j < b) val = P[j]; else j = b;
+    }
+}
+
 // Lower bounds of 64 ascending keys in one sorted list, as a wave: the answers of a step lie just behind the last
 // answer of the previous step, so the wave loads consecutive 64-element windows of the list with ONE coalesced load
 // each and every lane ranks its key inside the window through cross-lane reads (6 steps) -- a merge of two sorted
@@ -94,11 +138,44 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P
         if (can) { res = wb + lo; val = at; need = false; }
         wb += 64;
     }
-    if (need) {
-        res = gallop_lower_bound(P, wb < b ? wb : b, b, (uint64_t)key);
-        if (res < b) val = P[res];
-    }
+    if (__any(need)) wave_far_lower_bound(P, wb < b ? wb : b, b, key, need, res, val);
     return res < b ? res : b;
+}
+
+// Two steps at once: 128 ascending keys (lane i holds keys i and 64+i) share every window load, its fence test and the
+// loop around them, which is most of what a step costs.
+constexpr uint32_t kCoopWindows2 = 6;
+template <typename pos_t>
+__device__ __forceinline__ void wave_lower_bound2(const pos_t* __restrict__ P, uint32_t wb, uint32_t b, pos_t key0, bool need0, pos_t key1,
+                                                  bool need1, uint32_t& j0, pos_t& v0, uint32_t& j1, pos_t& v1)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    constexpr pos_t kInf = (pos_t)~(pos_t)0;
+    j0 = b; j1 = b;
+    for (uint32_t it = 0; it < kCoopWindows2; ++it) {
+        if (!__any(need0 || need1)) break;
+        const uint32_t idx = wb + lane;
+        const pos_t w = idx < b ? P[idx] : kInf;
+        const pos_t wlast = __shfl(w, 63);
+        const bool can0 = need0 && key0 <= wlast, can1 = need1 && key1 <= wlast;
+        uint32_t lo0 = 0, hi0 = 63, lo1 = 0, hi1 = 63;
+#pragma unroll
+        for (uint32_t st = 0; st < 6; ++st) {
+            const uint32_t mid0 = (lo0 + hi0) >> 1, mid1 = (lo1 + hi1) >> 1;
+            const pos_t a0 = __shfl(w, (int)mid0), a1 = __shfl(w, (int)mid1);
+            if (a0 < key0) lo0 = mid0 + 1; else hi0 = mid0;
+            if (a1 < key1) lo1 = mid1 + 1; else hi1 = mid1;
+        }
+        const pos_t at0 = __shfl(w, (int)lo0), at1 = __shfl(w, (int)lo1);
+        if (can0) { j0 = wb + lo0; v0 = at0; need0 = false; }
+        if (can1) { j1 = wb + lo1; v1 = at1; need1 = false; }
+        wb += 64;
+    }
+    if (__any(need0 || need1)) {
+        wb = wb < b ? wb : b;
+        wave_far_lower_bound(P, wb, b, key0, need0, j0, v0);
+        wave_far_lower_bound(P, wb, b, key1, need1, j1, v1);
+    }
 }
 
 // ---- wave-private list tiles -----------------------------------------------------------------------------------
@@ -328,6 +405,29 @@ __global__ void __launch_bounds__(256) join_init_kernel(const pos_t* __restrict_
     }
 }
 
+// what a slot does with its lower bound j (value v) in the next list: the first FEASIBLE element at or after it, if still
+// inside the window, becomes its link
+template <typename pos_t, bool kLast>
+__device__ __forceinline__ bool link_finish(const pos_t* __restrict__ P, const SegMeta& nx, const FeasRef& fb, uint32_t e, bool want, uint32_t j,
+                                            pos_t v, pos_t thi, pos_t* __restrict__ endp, uint32_t* __restrict__ link)
+{
+    bool ok = false;
+    if (want && j < nx.pend) {
+        if (kLast) {
+            ok = v <= thi;
+            if (ok) { link[e] = j; endp[e] = v; }
+        } else {
+            const uint32_t at = nx.begin + (j - nx.pbegin);
+            const uint32_t ej = next_feasible(fb, at);     // nearest feasible logical element at or after it
+            if (ej < nx.end) {
+                const pos_t pv = ej == at ? v : P[phys_of(nx, ej)];
+                if (pv <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+            }
+        }
+    }
+    return ok;
+}
+
 // link pass over the class [r0,r1) of slots that have `dist` sub-patterns after them (kLast: dist == 1, the next list is the
 // query's last one: all its elements are feasible and it has no join state).
 // Steps that lie inside one segment (almost all of them: lists are long) keep the segment's metadata in registers,
@@ -348,15 +448,45 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
     uint32_t seg_end = seg_begin[s_w + 1];
     SegMeta m = sm[s_w], nx = sm[m.next];
     uint32_t hint_seg = kNone, hint = 0;                           // answer of the last lane of the previous step and its segment
-    pos_t x_pre = 0;
-    bool have_pre = false;
+    pos_t x_pre = 0, x_pre1 = 0;
+    bool have_pre = false, have_pre1 = false;
     for (uint32_t base = run_begin; base < run_end; base += 64) {
         if (base >= seg_end) {                                     // entered a new segment (skips empty ones)
             while (seg_begin[s_w + 1] <= base) ++s_w;
             seg_end = seg_begin[s_w + 1];
             m = sm[s_w]; nx = sm[m.next];
-            have_pre = false;
+            have_pre = false; have_pre1 = false;
         }
+        if (run_end - base >= 128 && base + 127 < seg_end) {
+            // ---- two full steps inside one segment: 128 keys per window ---------------------------------
+            const uint32_t e0 = base + lane, e1 = e0 + 64;
+            const pos_t x0 = have_pre ? x_pre : P[phys_of(m, e0)];
+            const pos_t x1 = have_pre1 ? x_pre1 : P[phys_of(m, e1)];
+            const uint32_t left = run_end - base - 128;            // slots of the run behind this pair of steps
+            const uint32_t room = seg_end - base - 128;            // and of the segment
+            have_pre = left > 0 && (left < 64 ? left : 64u) <= room;
+            have_pre1 = left >= 128 && room >= 128;
+            if (have_pre) x_pre = e0 + 128 < run_end ? P[phys_of(m, e0 + 128)] : (pos_t)0;
+            if (have_pre1) x_pre1 = P[phys_of(m, e1 + 128)];
+            pos_t tlo0, thi0, tlo1, thi1, v0 = 0, v1 = 0;
+            const bool want0 = gap_window<pos_t>((uint64_t)x0, nx.lo, nx.hi, tlo0, thi0);
+            const bool want1 = gap_window<pos_t>((uint64_t)x1, nx.lo, nx.hi, tlo1, thi1);
+            uint32_t j0 = nx.pend, j1 = nx.pend;
+            if (hint_seg != s_w)                                   // first step of the run in this segment: the smallest key's bound is the fence
+                hint = wave_kary_lower_bound(P, nx.pbegin, nx.pend, (uint64_t)__shfl(tlo0, 0));
+            wave_lower_bound2(P, hint, nx.pend, tlo0, want0, tlo1, want1, j0, v0, j1, v1);
+            if (!want0) j0 = nx.pend;
+            if (!want1) j1 = nx.pend;
+            const bool ok0 = link_finish<pos_t, kLast>(P, nx, fb, e0, want0, j0, v0, thi0, endp, link);
+            const bool ok1 = link_finish<pos_t, kLast>(P, nx, fb, e1, want1, j1, v1, thi1, endp, link);
+            const unsigned long long okm0 = __ballot(ok0), okm1 = __ballot(ok1);
+            if (lane == 0) { fbits_out[base >> 6] = okm0; fbits_out[(base >> 6) + 1] = okm1; }
+            hint_seg = s_w;
+            hint = __shfl(j1, 63);
+            base += 64;                                            // the loop adds the other 64
+            continue;
+        }
+        have_pre1 = false;
         const uint32_t e = base + lane;
         const bool active = e < run_end;
         const uint32_t step_last = run_end - base > 64 ? base + 63 : run_end - 1;
@@ -370,23 +500,10 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
             pos_t tlo, thi, v = 0;
             const bool want = gap_window<pos_t>((uint64_t)x, nx.lo, nx.hi, tlo, thi) && active;    // false: no position can be in the window
             j = nx.pend;
-            if (hint_seg == s_w) j = wave_lower_bound(P, hint, nx.pend, tlo, want, v);
-            else if (want) { j = gallop_lower_bound(P, nx.pbegin, nx.pend, (uint64_t)tlo); if (j < nx.pend) v = P[j]; }
+            if (hint_seg != s_w) hint = wave_kary_lower_bound(P, nx.pbegin, nx.pend, (uint64_t)__shfl(tlo, 0));
+            j = wave_lower_bound(P, hint, nx.pend, tlo, want, v);
             if (!want) j = nx.pend;
-            bool ok = false;
-            if (want && j < nx.pend) {
-                if (kLast) {
-                    ok = v <= thi;
-                    if (ok) { link[e] = j; endp[e] = v; }
-                } else {
-                    const uint32_t at = nx.begin + (j - nx.pbegin);
-                    const uint32_t ej = next_feasible(fb, at);     // nearest feasible logical element at or after it
-                    if (ej < nx.end) {
-                        const pos_t pv = ej == at ? v : P[phys_of(nx, ej)];
-                        if (pv <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
-                    }
-                }
-            }
+            const bool ok = link_finish<pos_t, kLast>(P, nx, fb, e, want, j, v, thi, endp, link);
             const unsigned long long okm = __ballot(ok);
             if (lane == 0) fbits_out[base >> 6] = okm;
         } else {
