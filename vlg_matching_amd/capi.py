@@ -108,7 +108,8 @@ SYMBOLS = [
 
 
 def library_path():
-    return os.path.join(_HERE, "libvlg_hip.so")
+    """The in-tree library; VLG_HIP_LIBRARY names another build of it (kernel experiments)."""
+    return os.environ.get("VLG_HIP_LIBRARY") or os.path.join(_HERE, "libvlg_hip.so")
 
 
 def build_library(jobs=4):

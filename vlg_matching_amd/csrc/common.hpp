@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <new>
 #include <string>
 #include <vector>
 #include "../../include/vlg_hip.h"
@@ -95,6 +96,42 @@ void release_cached_device_memory();      // result buffers parked for reuse (se
             return ::vlg::fail(_e == hipErrorOutOfMemory ? VLG_E_OOM : VLG_E_NO_DEVICE,          \
                                std::string(#expr) + ": " + hipGetErrorString(_e));               \
     } while (0)
+
+// Host memory the batch path copies from / into.  Pageable vectors there are pinned by the runtime on the fly, and
+// freeing them afterwards (munmap) makes the driver evict and restore the process's GPU queues: tens of ms in which the
+// next kernel does not start.  These vectors live in pinned blocks owned by the workspace instead: handed out bump-style
+// while a batch runs, recycled at the next batch, never unmapped in between.
+struct HostPool {
+    struct Blk { uint8_t* p; size_t cap; };
+    std::vector<Blk> blocks;
+    size_t cur = 0, off = 0;
+    void* take(size_t bytes);              // 64-byte aligned; nullptr when pinned memory cannot be had
+    void reset() { cur = 0; off = 0; }
+    void release();                        // back to the driver (workspace destruction)
+};
+HostPool*& host_pool_slot();               // pool of the batch this thread is running (nullptr outside a batch)
+struct HostPoolScope {
+    HostPool* prev;
+    explicit HostPoolScope(HostPool* p) : prev(host_pool_slot()) { host_pool_slot() = p; p->reset(); }
+    ~HostPoolScope() { host_pool_slot() = prev; }
+};
+template <class T>
+struct StageAlloc {
+    using value_type = T;
+    StageAlloc() = default;
+    template <class U> StageAlloc(const StageAlloc<U>&) {}
+    T* allocate(size_t n)
+    {
+        HostPool* hp = host_pool_slot();
+        void* p = hp ? hp->take(n * sizeof(T)) : nullptr;
+        if (!p) throw std::bad_alloc();
+        return (T*)p;
+    }
+    void deallocate(T*, size_t) noexcept {}
+    template <class U> bool operator==(const StageAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const StageAlloc<U>&) const { return false; }
+};
+template <class T> using svec = std::vector<T, StageAlloc<T>>;   // a vector whose storage is staged for device copies
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 inline uint32_t bit_width64(uint64_t x) { return x ? 64u - (uint32_t)__builtin_clzll(x) : 0u; }

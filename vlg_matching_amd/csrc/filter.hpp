@@ -533,14 +533,14 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
     fg.cidx.assign(nsub, kNone);
     for (uint64_t s = 0; s < nsub; ++s) fg.eff[s] = pl.occ[fg.sub0 + s];
     // ---- segments of the filtered queries ------------------------------------------------------------
-    std::vector<RSeg> segs;
-    std::vector<uint32_t> cseg;                       // segments that keep activity bits, in (query, level) order
-    std::vector<uint64_t> crun0(1, 0);
+    svec<RSeg> segs;
+    svec<uint32_t> cseg;                       // segments that keep activity bits, in (query, level) order
+    svec<uint64_t> crun0(1, 0);
     std::vector<uint32_t> seg_sub;                    // sub-pattern (group relative) of every segment
     uint32_t nfq = 0, kmaxf = 0;
     uint64_t abit = 0;
-    std::vector<PTask> ptasks;                        // queries filtered from a pivot list
-    std::vector<uint64_t> prun0(1, 0);
+    svec<PTask> ptasks;                        // queries filtered from a pivot list
+    svec<uint64_t> prun0(1, 0);
     for (uint64_t qi = fg.g0; qi < fg.g1; ++qi) {
         if (!fg.want[qi - fg.g0]) continue;
         const uint64_t s0 = q->qsub[qi];
@@ -577,8 +577,8 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
     fg.any = !segs.empty();
     if (!fg.any) return VLG_OK;
     fg.ncseg = (uint32_t)cseg.size();
-    fg.crun0 = crun0;
-    fg.cseg = cseg;
+    fg.crun0.assign(crun0.begin(), crun0.end());
+    fg.cseg.assign(cseg.begin(), cseg.end());
     const uint64_t total_runs = crun0.back();
     // ---- device state: what the chunks need first, the bitmaps and task lists (dead after the passes) last ----------
     fg.d_segs = A.take<RSeg>(segs.size());
@@ -611,8 +611,8 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
         if (nfq) VLG_HIP_TRY(hipMemset2DAsync(d_bm + (uint64_t)buf * nbw, 2 * nbw * 8, 0, nbw * 8, nfq, st));
         return VLG_OK;
     };
-    std::vector<uint32_t> task_seg;
-    std::vector<uint64_t> task_run0;
+    svec<uint32_t> task_seg;
+    svec<uint64_t> task_run0;
     auto run_pass = [&](const RPass& ps, auto&& pick) -> vlg_status {
         task_seg.clear(); task_run0.assign(1, 0);
         uint64_t elems = 0;
@@ -658,7 +658,7 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
                            d_segcnt);
     }
     VLG_HIP_TRY(hipGetLastError());
-    std::vector<unsigned long long> segcnt(cseg.size());
+    svec<unsigned long long> segcnt(cseg.size());
     VLG_HIP_TRY(hipMemcpyAsync(segcnt.data(), d_segcnt, cseg.size() * 8, hipMemcpyDeviceToHost, st));
     VLG_HIP_TRY(hipStreamSynchronize(st));
     for (uint32_t c = 0; c < cseg.size(); ++c) fg.eff[seg_sub[cseg[c]]] = segcnt[c];

@@ -15,6 +15,34 @@ vlg_status fail(vlg_status st, const std::string& msg)
 }
 const char* last_error_cstr() { return g_err.c_str(); }
 
+// ---- pinned staging memory of a workspace (common.hpp) ----------------------------------------------------------
+HostPool*& host_pool_slot()
+{
+    static thread_local HostPool* slot = nullptr;
+    return slot;
+}
+void* HostPool::take(size_t bytes)
+{
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (!bytes) bytes = 64;
+    while (cur < blocks.size()) {
+        if (off + bytes <= blocks[cur].cap) { void* p = blocks[cur].p + off; off += bytes; return p; }
+        ++cur; off = 0;                                 // the rest of the block is left unused until the next batch
+    }
+    Blk b{nullptr, std::max<size_t>(bytes, (size_t)64 << 20)};
+    if (hipHostMalloc((void**)&b.p, b.cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    blocks.push_back(b);
+    cur = blocks.size() - 1;
+    off = bytes;
+    return b.p;
+}
+void HostPool::release()
+{
+    for (Blk& b : blocks) (void)hipHostFree(b.p);
+    blocks.clear();
+    cur = off = 0;
+}
+
 // Fill everything of HostTree that follows from t.nodes (reference layout) + char2comp.
 static vlg_status finish_tree(HostTree& t)
 {

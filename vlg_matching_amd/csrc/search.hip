@@ -45,6 +45,7 @@ struct vlg_workspace {
     uint64_t cap_bytes = 0;
     uint8_t* arena = nullptr;
     uint64_t arena_bytes = 0;
+    HostPool host;              // pinned staging memory of the batch in flight
     bool profile = false;
     bool dedup = true;
     bool sweep = true;          // sorted-sweep locate (n <= 2^32) instead of the random-access persistent kernel
@@ -179,6 +180,7 @@ extern "C" void vlg_workspace_destroy(vlg_workspace* ws)
     ws_collect(ws);
     for (hipEvent_t e : ws->free_events) (void)hipEventDestroy(e);
     if (ws->arena) (void)hipFree(ws->arena);
+    ws->host.release();
     delete ws;
 }
 
@@ -406,8 +408,8 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
 {
     hipStream_t st = ws->stream;
     const uint32_t nd = (uint32_t)dlist.size();
-    std::vector<uint64_t> off64(nd + 1), lh(nd);
-    std::vector<uint32_t> off32(nd + 1);
+    svec<uint64_t> off64(nd + 1), lh(nd);
+    svec<uint32_t> off32(nd + 1);
     uint64_t acc = 0;
     for (uint32_t i = 0; i < nd; ++i) {
         off64[i] = acc; off32[i] = (uint32_t)acc; lh[i] = pl.dl[dlist[i]];
@@ -520,7 +522,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     ResultPiece piece;
     piece.q0 = q0; piece.q1 = q1;
     // ---- host-side metadata of the chunk: segments in class-major order (dist descending) -------------
-    std::vector<QueryMeta> qm(nq);
+    svec<QueryMeta> qm(nq);
     uint32_t kmax = 0;
     for (uint64_t qi = q0; qi < q1; ++qi) {
         uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
@@ -538,8 +540,9 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     // classes are stored from the highest dist down to 0
     uint32_t nlive = 0;
     for (int d = (int)kmax - 1; d >= 0; --d) { cls_first[d] = nlive; nlive += cls_count[d]; }
-    std::vector<SegMeta> sm(nlive + 1);
-    std::vector<uint32_t> seg_begin(nlive + 2, 0), fill(kmax + 1, 0);
+    svec<SegMeta> sm(nlive + 1);
+    svec<uint32_t> seg_begin(nlive + 2, 0);
+    std::vector<uint32_t> fill(kmax + 1, 0);
     std::vector<uint32_t> seg_of_sub(nseg, kNone);
     for (uint64_t qi = q0; qi < q1; ++qi) {
         uint32_t k = qm[qi - q0].k;
@@ -603,8 +606,8 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     jt.mark("  chunk: host metadata");
     // ---- private lists: compact the survivors of the chunk's filtered lists behind P ------------------------
     if (!pc_tasks.empty()) {
-        std::vector<uint32_t> t_seg(pc_tasks.size()), t_cidx(pc_tasks.size());
-        std::vector<uint64_t> t_run0(pc_tasks.size() + 1, 0);
+        svec<uint32_t> t_seg(pc_tasks.size()), t_cidx(pc_tasks.size());
+        svec<uint64_t> t_run0(pc_tasks.size() + 1, 0);
         for (size_t i = 0; i < pc_tasks.size(); ++i) {
             const uint32_t c = fg->cidx[pc_tasks[i]];
             t_cidx[i] = c;
@@ -669,7 +672,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     uint32_t* d_segb = A.take<uint32_t>(nlive + 2);
     unsigned long long* d_counts = A.take<unsigned long long>(nq);
     // chain records: one per tile a level-0 list overlaps (upper bound of the tiles its chain can visit)
-    std::vector<uint32_t> rec_begin(nq + 1, 0), rec_query;
+    svec<uint32_t> rec_begin(nq + 1, 0), rec_query;
     for (uint32_t i = 0; i < nq; ++i) {
         uint32_t cnt = 0;
         if (qm[i].seg0 != kNone) {
@@ -737,7 +740,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     }
     VLG_HIP_TRY(hipGetLastError());
     // ---- sizes of the result, then gather -------------------------------------------------------------
-    std::vector<unsigned long long> counts(nq);
+    svec<unsigned long long> counts(nq);
     VLG_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, nq * 8, hipMemcpyDeviceToHost, st));
     VLG_HIP_TRY(hipStreamSynchronize(st));
     jt.mark("  chunk: link + chain");
@@ -977,7 +980,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
             if (vlg_status s = launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_l, d_r, d_stats + 3, st)) return s;
         }
         tr.mark("backward search");
-        std::vector<uint64_t> l(nsub), r(nsub);
+        svec<uint64_t> l(nsub), r(nsub);
         if (nsub) {
             VLG_HIP_TRY(hipMemcpyAsync(l.data(), d_l, nsub * 8, hipMemcpyDeviceToHost, st));
             VLG_HIP_TRY(hipMemcpyAsync(r.data(), d_r, nsub * 8, hipMemcpyDeviceToHost, st));
@@ -1039,7 +1042,12 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         ws->stats[KS_BSEARCH].algorithmic_bytes += 32ull * hs[3];
         return VLG_OK;
     };
-    vlg_status stt = run();
+    vlg_status stt;
+    {
+        HostPoolScope staging(&ws->host);
+        try { stt = run(); }
+        catch (const std::bad_alloc&) { stt = fail(VLG_E_OOM, "out of host memory while planning the batch (pinned staging)"); }
+    }
     tr.mark("statistics");
     if (d_l) (void)hipFree(d_l);
     if (d_r) (void)hipFree(d_r);
