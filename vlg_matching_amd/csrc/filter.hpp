@@ -443,11 +443,17 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __rest
     const uint64_t total = task_run0[ntasks];
     if (r0 >= total) return;
     unsigned long long todo = __ballot(lane < kCompactRuns && r0 + lane < total && run_cnt[r0 + lane] != 0);
+    uint32_t t = 0;
+    uint64_t t_end = 0;                                                          // runs before it belong to task t (or to none yet)
+    RSeg sg;
     while (todo) {
         const uint64_t run = r0 + (uint32_t)(__ffsll((long long)todo) - 1);
         todo &= todo - 1;
-        const uint32_t t = wave_task_find(task_run0, ntasks, run);
-        const RSeg sg = segs[task_seg[t]];
+        if (run >= t_end) {                                                      // neighbouring runs mostly share their task
+            t = wave_task_find(task_run0, ntasks, run);
+            t_end = task_run0[t + 1];
+            sg = segs[task_seg[t]];
+        }
         const uint64_t len = sg.pend - sg.pbegin;
         const uint64_t off0 = (run - task_run0[t]) * kRun;
         const uint64_t off1 = off0 + kRun < len ? off0 + kRun : len;
@@ -459,6 +465,23 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __rest
         for (int o = 1; o < 32; o <<= 1) { const uint32_t v = __shfl_up(before, o); if ((int)lane >= o) before += v; }
         before -= (uint32_t)__popcll(mine);
         const uint32_t out0 = run_off[run];
+        if (uniform(run_cnt[run]) < kRun / 2) {
+            // sparse run (the usual case: few elements survive the filter): every lane moves the survivors of its own half word, so
+            // the loop runs as often as the fullest half word has survivors, not once per word
+            const uint64_t wbits = __shfl(mine, (int)(lane >> 1));
+            uint32_t hb = (uint32_t)(wbits >> (32 * (lane & 1)));
+            const uint32_t cnt = (uint32_t)__popc(hb);
+            uint32_t inc = cnt;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+            uint32_t out = out0 + inc - cnt;
+            const pos_t* __restrict__ src = P + sg.pbegin + off0 + 32ull * lane;
+            while (hb) {
+                const uint32_t b = (uint32_t)__ffs((int)hb) - 1;
+                hb &= hb - 1;
+                Pc[out++] = src[b];
+            }
+            continue;
+        }
         unsigned long long todo_w = __ballot(mine != 0);
         while (todo_w) {
             const int wi = __ffsll((long long)todo_w) - 1;

@@ -862,6 +862,13 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         if (tr.on) fprintf(stderr, "[vlg trace] super-chunk: %llu occurrences, %.1f GB physical, trails %s (%.1f GB), budget %.1f GB, largest join %.1f GB\n",
                            (unsigned long long)phys, phys_plain / 1e9, share_trails ? "shared" : "not shared",
                            ((idx->hdr.n + phys) * 8) / 1e9, budget / 1e9, logical_max_query / 1e9);
+        if (tr.on) {                                                          // where the occurrences are: distinct lists by size class
+            uint64_t cnt[40] = {0}, sum[40] = {0};
+            for (uint32_t d : dlist) { const unsigned b = bit_width64(pl.docc[d]); cnt[b]++; sum[b] += pl.docc[d]; }
+            fprintf(stderr, "[vlg trace] distinct lists by size (2^b: lists/occurrences):");
+            for (unsigned b = 0; b < 40; ++b) if (cnt[b]) fprintf(stderr, " %u:%llu/%llu", b, (unsigned long long)cnt[b], (unsigned long long)sum[b]);
+            fprintf(stderr, "\n");
+        }
         const uint64_t phys_bytes = phys_plain + trail_bytes;
         const uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
         // window filter: state of the filtered queries of a group (at most a third of the budget), dropped query by query if it
