@@ -634,10 +634,11 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
         if (nfq) VLG_HIP_TRY(hipMemset2DAsync(d_bm + (uint64_t)buf * nbw, 2 * nbw * 8, 0, nbw * 8, nfq, st));
         return VLG_OK;
     };
-    svec<uint32_t> task_seg;
-    svec<uint64_t> task_run0;
     auto run_pass = [&](const RPass& ps, auto&& pick) -> vlg_status {
-        task_seg.clear(); task_run0.assign(1, 0);
+        svec<uint32_t> task_seg;                      // fresh pinned storage per pass: the copies below run later, in stream order
+        svec<uint64_t> task_run0(1, 0);
+        task_seg.reserve(segs.size());
+        task_run0.reserve(segs.size() + 1);
         uint64_t elems = 0;
         for (uint32_t i = 0; i < segs.size(); ++i)
             if (pick(segs[i])) {
@@ -655,7 +656,6 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
                                fg.d_segs, d_task_seg, d_task_run0, (uint32_t)task_seg.size(), d_bm, nbw, g, nblocks, fg.d_abits, ps);
         }
         VLG_HIP_TRY(hipGetLastError());
-        VLG_HIP_TRY(hipStreamSynchronize(st));      // the task vectors are rebuilt for the next pass
         return VLG_OK;
     };
     // ---- backward sweep: pass j handles the sub-patterns that have j sub-patterns after them -------------------------

@@ -487,7 +487,8 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         P_out = Pb;
         dead_bytes = acc * kPhysScratchPerElem<pos_t>() - acc * sizeof(pos_t);
     }
-    VLG_HIP_TRY(hipStreamSynchronize(st));        // host staging vectors go out of scope
+    // no wait here: the staging vectors live in the workspace's pinned pool until the batch ends, so the caller plans the
+    // window filter while the sort runs
     {
         const uint64_t pc_first = align_up(acc, 64);
         if (dead_bytes > (pc_first - acc + 64) * sizeof(pos_t) && pc_first < 0xFFFFFF00ull) {
@@ -636,7 +637,6 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
                                dim3(256), 0, st, P, fg->d_segs, d_tseg, d_trun0, (uint32_t)t_seg.size(), fg->d_abits, d_cnt, d_off, Pc);
         }
         VLG_HIP_TRY(hipGetLastError());
-        VLG_HIP_TRY(hipStreamSynchronize(st));        // host task vectors go out of scope
     }
     jt.mark("  chunk: compaction");
     // ---- carve the arena ---------------------------------------------------------------------------
