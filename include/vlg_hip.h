@@ -303,7 +303,10 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
  * them together ("filter_pivot_ratio", default 12), otherwise (or with 0) by streaming sweeps over block bitmaps;
  * "filter_group_bytes" (default 0 = a third of the join scratch) caps the filter state of the queries filtered together.
  * "reserve" = bytes of scratch to allocate right away (at most the workspace's cap) instead of on first use.
- * Results are identical whatever the options. */
+ * "tuples" (default 1): materialise every sub-pattern position of every match (what sdsl::locate returns); 0 = first
+ * positions only, which is all the benchmark's gapped_search_result holds (index_sasearch.hpp:58-118): n_tuple_values
+ * is 0 and vlg_result_fetch refuses a tuples buffer.
+ * Counts, first positions, tuples and the checksum are identical whatever the other options are. */
 vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* name, int64_t value);
 vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n);
 

@@ -400,6 +400,32 @@ def test_locate_trail_sharing_equals_plain_locate_and_oracle(V, oracle, name, se
         assert b.tuples(i).tolist() == o.search(qs[i]).tolist(), qs[i]
 
 
+def test_first_positions_only(V, oracle):
+    """Workspace option "tuples" = 0: what the benchmark's gapped_search_result holds (index_sasearch.hpp:58-118) -- counts,
+    first positions and checksum as with tuples, no tuple values, and a tuples buffer is refused."""
+    from vlg_matching_amd.index import Workspace
+    from vlg_matching_amd.capi import VlgError
+    text = TEXTS["dna_50k"]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    qs = random_queries(text, np.random.default_rng(77), 200, kmax=4, mmax=4)
+    ws_a, ws_b = Workspace(), Workspace()
+    ws_b.set_option("tuples", 0)
+    a, b = idx.search(qs, workspace=ws_a), idx.search(qs, workspace=ws_b)
+    assert b.summary["n_tuple_values"] == 0 and a.summary["n_tuple_values"] > 0
+    for k in ("n_matches", "checksum", "located_occurrences", "logical_occurrences"):
+        assert a.summary[k] == b.summary[k], k
+    assert (a.counts == b.counts).all()
+    for i in range(len(qs)):
+        assert b.positions(i).tolist() == [t[0] for t in o.search(qs[i]).tolist()], qs[i]
+    assert b.summary["n_matches"] > 0
+    with pytest.raises(VlgError):
+        b.tuples(0)
+    from vlg_matching_amd.capi import lib, E_INVALID
+    buf = np.zeros(8, dtype=np.uint64)
+    assert lib().vlg_result_fetch(b._h, None, None, None, buf.ctypes.data) == E_INVALID
+
+
 @pytest.mark.parametrize("pivot", [1, 0])
 @pytest.mark.parametrize("name,seed,kmax,gapmax,cap_mb", [("dna_50k", 61, 3, 300, 0), ("dna_skew", 62, 6, 40, 0), ("zipf40", 63, 4, 2000, 0),
                                                          ("100a", 64, 3, 5, 0), ("dna_50k", 65, 8, 600, 0), ("dna_50k", 66, 3, 300, 40)])

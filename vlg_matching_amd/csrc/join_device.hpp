@@ -784,10 +784,10 @@ __global__ void __launch_bounds__(256) join_gather_kernel(const pos_t* __restric
                 uint64_t first = P[phys_of(m, el)];
                 out_first[Q.out_first + t] = first;
                 local += first;
-                uint64_t* tp = out_tuples + Q.out_tuple + t * Q.k;
-                tp[0] = first;
-                if (Q.k > 1) {
-                    uint32_t cur = link[el];
+                if (out_tuples) {                                      // null: first positions only (workspace option "tuples" = 0)
+                    uint64_t* tp = out_tuples + Q.out_tuple + t * Q.k;
+                    tp[0] = first;
+                    uint32_t cur = Q.k > 1 ? link[el] : 0;
                     uint32_t sg = m.next;
                     for (uint32_t i = 1; i < Q.k; ++i) {
                         const SegMeta mi = sm[sg];

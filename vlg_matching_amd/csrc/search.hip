@@ -49,6 +49,8 @@ struct vlg_workspace {
     bool profile = false;
     bool dedup = true;
     bool sweep = true;          // sorted-sweep locate (n <= 2^32) instead of the random-access persistent kernel
+    bool tuples = true;         // materialise every sub-pattern position of every match (sdsl::locate); off: first positions only, which
+                                // is all the benchmark's gapped_search_result holds (index_sasearch.hpp:58-118)
     bool trail = true;          // sorted-sweep locate: elements that step onto an SA index another element has visited share its LF trail
                                 // (needs dedup; with dedup off every occurrence walks its own LF steps like the reference)
     bool filter = true;         // window filter: drop the list elements that can be in no match before the join
@@ -200,6 +202,7 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "sweep_min")) { ws->sweep_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "global_sort_min")) { ws->global_sort_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "trail")) { ws->trail = value != 0; return VLG_OK; }
+    if (!strcmp(name, "tuples")) { ws->tuples = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter")) { ws->filter = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter_min")) { ws->filter_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_pivot")) { ws->filter_pivot = value != 0; return VLG_OK; }
@@ -330,6 +333,8 @@ extern "C" vlg_status vlg_result_fetch(const vlg_result* r, uint64_t* h_counts, 
         for (uint64_t q = 0; q < nq; ++q) { h_offsets[q] = acc; acc += r->counts[q]; }
         h_offsets[nq] = acc;
     }
+    if (h_tuples && r->sum.n_matches && !r->sum.n_tuple_values)
+        return fail(VLG_E_INVALID, "tuples were not materialised (workspace option \"tuples\" is 0)");
     uint64_t fo = 0, to = 0;
     for (const auto& p : r->pieces) {
         if (h_first && p.matches) VLG_HIP_TRY(hipMemcpy(h_first + fo, p.d_first, p.matches * 8, hipMemcpyDeviceToHost));
@@ -747,13 +752,13 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     uint64_t M = 0, TV = 0;
     for (uint32_t i = 0; i < nq; ++i) {
         qm[i].out_first = M; qm[i].out_tuple = TV;
-        M += counts[i]; TV += counts[i] * qm[i].k;
+        M += counts[i]; TV += ws->tuples ? counts[i] * qm[i].k : 0;
         res->counts[q0 + i] = counts[i];
     }
     piece.matches = M; piece.tuple_vals = TV;
     if (M) {
         VLG_HIP_TRY(result_alloc(&piece.d_first, M * 8, &piece.first_bytes));
-        VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * 8, &piece.tuple_bytes));
+        if (TV) VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * 8, &piece.tuple_bytes));
         res->pieces.push_back(piece);
         jt.mark("  chunk: result malloc");
         VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));

@@ -113,6 +113,7 @@ class index_fm_gpu
                                                    vlg_result_summary* summary = nullptr)
     {
         ensure_ws();
+        check(vlg_workspace_set_option(m_ws, "tuples", 0));      // gapped_search_result holds first positions only
         std::string text;
         std::vector<uint64_t> off(1, 0);
         for (const auto& p : pats) { text += p.raw_regexp; off.push_back(text.size()); }
@@ -139,6 +140,7 @@ class index_fm_gpu
     std::vector<std::vector<uint64_t>> locate(const std::string& query)
     {
         ensure_ws();
+        check(vlg_workspace_set_option(m_ws, "tuples", 1));
         uint64_t off[2] = {0, query.size()};
         vlg_queries* q = nullptr;
         check(vlg_queries_parse(query.data(), off, 1, VLG_DIALECT_LIBRARY, nullptr, &q));

@@ -49,7 +49,9 @@ class SearchResult:
             offsets = np.zeros(nq + 1, dtype=np.uint64)
             first = np.zeros(max(self.summary["n_matches"], 1), dtype=np.uint64)
             tuples = np.zeros(max(self.summary["n_tuple_values"], 1), dtype=np.uint64)
-            check(lib().vlg_result_fetch(self._h, counts.ctypes.data, offsets.ctypes.data, first.ctypes.data, tuples.ctypes.data))
+            has_tuples = self.summary["n_tuple_values"] or not self.summary["n_matches"]       # workspace option "tuples" = 0: none
+            check(lib().vlg_result_fetch(self._h, counts.ctypes.data, offsets.ctypes.data, first.ctypes.data,
+                                         tuples.ctypes.data if has_tuples else None))
             self._fetched = (counts[:nq], offsets, first[: self.summary["n_matches"]], tuples[: self.summary["n_tuple_values"]])
         return self._fetched
 
@@ -63,6 +65,8 @@ class SearchResult:
 
     def tuples(self, q):
         counts, _, _, tup = self.fetch()
+        if self.summary["n_matches"] and not self.summary["n_tuple_values"]:
+            raise VlgError(capi.E_INVALID, "tuples were not materialised (workspace option \"tuples\" is 0)")
         ks = np.asarray(self._ks, dtype=np.uint64)
         toff = np.concatenate([[0], np.cumsum(counts * ks)]).astype(np.int64)
         k = int(ks[q])
