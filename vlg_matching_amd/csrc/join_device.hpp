@@ -418,19 +418,20 @@ __device__ __forceinline__ bool link_finish(const pos_t* __restrict__ P, const S
     if (want && j < nx.pend) {
         if (kLast) {
             ok = v <= thi;
-            if (ok) { link[e] = j; endp[e] = v; }
+            if (ok) { if (link) link[e] = j; endp[e] = v; }
         } else {
             const uint32_t at = nx.begin + (j - nx.pbegin);
             const uint32_t ej = next_feasible(fb, at);     // nearest feasible logical element at or after it
             if (ej < nx.end) {
                 const pos_t pv = ej == at ? v : P[phys_of(nx, ej)];
-                if (pv <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+                if (pv <= thi) { ok = true; if (link) link[e] = ej; endp[e] = endp[ej]; }
             }
         }
     }
     return ok;
 }
 
+// (link == nullptr: only the chain ends are wanted -- first positions without tuples)
 // link pass over the class [r0,r1) of slots that have `dist` sub-patterns after them (kLast: dist == 1, the next list is the
 // query's last one: all its elements are feasible and it has no join state).
 // Steps that lie inside one segment (almost all of them: lists are long) keep the segment's metadata in registers,
@@ -524,10 +525,10 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
                 if (e < ml.end) {                                  // padding slots between classes belong to no segment
                     if (kLast) {
                         ok = j < nl.pend && (uint64_t)P[j] <= thi;
-                        if (ok) { link[e] = j; endp[e] = P[j]; }
+                        if (ok) { if (link) link[e] = j; endp[e] = P[j]; }
                     } else if (j < nl.pend) {
                         const uint32_t ej = next_feasible(fb, (uint64_t)nl.begin + (j - nl.pbegin));
-                        if (ej < nl.end && (uint64_t)P[phys_of(nl, ej)] <= thi) { ok = true; link[e] = ej; endp[e] = endp[ej]; }
+                        if (ej < nl.end && (uint64_t)P[phys_of(nl, ej)] <= thi) { ok = true; if (link) link[e] = ej; endp[e] = endp[ej]; }
                     }
                 }
             }

@@ -645,7 +645,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     }
     jt.mark("  chunk: compaction");
     // ---- carve the arena ---------------------------------------------------------------------------
-    uint32_t* link = A.take<uint32_t>(T);
+    uint32_t* link = ws->tuples ? A.take<uint32_t>(T) : nullptr;      // only the tuples walk the links
     pos_t* endp = A.take<pos_t>(T);
     // feasibility bitset + summaries
     FeasBits fb;
