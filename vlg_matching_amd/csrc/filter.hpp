@@ -278,6 +278,47 @@ __device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, uint32
         r0[g] = r1[g] = on[g] ? hi[g] : lo[g];
         widest = hi[g] - lo[g] > widest ? hi[g] - lo[g] : widest;
     }
+    // wide brackets first shrink 64-fold: lane t reads the last element of the bracket's t-th slice (one load per group), every
+    // lane ranks its two keys among these 64 fences through cross-lane reads and goes on inside one slice
+    if (uniform(widest) > 256) {
+        pos_t fence[G];
+        uint32_t step[G];
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t W = hi[g] - lo[g];
+            step[g] = (W + 63) / 64;
+            const uint64_t at = (uint64_t)lo[g] + (uint64_t)(lane + 1) * step[g] - 1;
+            fence[g] = W > 256 ? P[at < hi[g] ? at : hi[g] - 1] : (pos_t)0;      // slices behind the bracket repeat its last element
+        }
+        widest = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t W = hi[g] - lo[g];
+            if (W > 256) {                                                   // wave-uniform
+                const uint64_t k1 = b[g] + 1;                                    // b < ~0 (the callers see to it)
+                uint32_t s0 = 0, e0 = 64, s1 = 0, e1 = 64;                       // first fence >= a / >= b + 1 (64 = none)
+#pragma unroll
+                for (uint32_t st = 0; st < 7; ++st) {
+                    const uint32_t c0 = (s0 + e0) >> 1, c1 = (s1 + e1) >> 1;
+                    const uint64_t f0 = (uint64_t)__shfl(fence[g], (int)(c0 & 63)), f1 = (uint64_t)__shfl(fence[g], (int)(c1 & 63));
+                    if (s0 < e0) { if (f0 < a[g]) s0 = c0 + 1; else e0 = c0; }
+                    if (s1 < e1) { if (f1 < k1) s1 = c1 + 1; else e1 = c1; }
+                }
+                if (on[g]) {
+                    // the answer is behind fence s-1 and not behind fence s: indices [lo + s step, lo + (s+1) step - 1], clipped to hi
+                    const uint64_t b0 = (uint64_t)lo[g] + (uint64_t)s0 * step[g], b1 = (uint64_t)lo[g] + (uint64_t)s1 * step[g];
+                    l0[g] = b0 < hi[g] ? (uint32_t)b0 : hi[g];
+                    l1[g] = b1 < hi[g] ? (uint32_t)b1 : hi[g];
+                    const uint64_t t0 = b0 + step[g] - 1, t1 = b1 + step[g] - 1;
+                    r0[g] = t0 < hi[g] ? (uint32_t)t0 : hi[g];
+                    r1[g] = t1 < hi[g] ? (uint32_t)t1 : hi[g];
+                }
+                widest = step[g] > widest ? step[g] : widest;
+            } else {
+                widest = W > widest ? W : widest;
+            }
+        }
+    }
     for (uint32_t w = uniform(widest); w; w >>= 1) {        // bit_width(widest) rounds bisect any range of that size
         uint64_t v0[G], v1[G];
         uint32_t m0[G], m1[G];
