@@ -638,6 +638,21 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
         }
         if (!by_pivot) ++nfq;
     }
+    if (getenv("VLG_TRACE")) {                         // pivot work by density: neighbour list length / pivot list length
+        uint64_t h[24] = {0}, total = 0;
+        for (const PTask& t : ptasks) {
+            const uint64_t pl_ = segs[t.seg0 + t.p].pend - segs[t.seg0 + t.p].pbegin;
+            for (uint32_t i = 0; i + 1 < t.k; ++i) {
+                if (i == t.p) continue;
+                const uint64_t nl = segs[t.seg0 + i].pend - segs[t.seg0 + i].pbegin;
+                const unsigned b = bit_width64(pl_ ? nl / pl_ : 0);
+                h[b < 23 ? b : 23] += pl_; total += pl_;
+            }
+        }
+        fprintf(stderr, "[vlg trace] pivot probes by log2(neighbour/pivot) (pivot elements x levels, total %llu):", (unsigned long long)total);
+        for (unsigned b = 0; b < 24; ++b) if (h[b]) fprintf(stderr, " %u:%llu", b, (unsigned long long)h[b]);
+        fprintf(stderr, "\n");
+    }
     fg.any = !segs.empty();
     if (!fg.any) return VLG_OK;
     fg.ncseg = (uint32_t)cseg.size();
