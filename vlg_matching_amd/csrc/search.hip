@@ -537,6 +537,51 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         bool live = k > 0 && eo(q->qsub[qi]) > 0;
         if (live) kmax = std::max(kmax, k);
     }
+    // filtered sub-patterns of the chunk (group relative), in Pc order; their compaction is launched first so that it runs while
+    // the rest of the metadata is built
+    std::vector<uint32_t> pc_tasks;
+    uint64_t pc_total = 0;
+    for (uint64_t qi = q0; qi < q1; ++qi) {
+        const uint32_t k = qm[qi - q0].k;
+        if (!(k > 0 && eo(q->qsub[qi]) > 0)) continue;
+        for (uint32_t i = 0; i < k; ++i) {
+            const uint64_t s = q->qsub[qi] + i;
+            if (filtered(s)) { pc_tasks.push_back((uint32_t)(s - fg->sub0)); pc_total += eo(s); }
+        }
+    }
+    // ---- private lists: compact the survivors of the chunk's filtered lists behind P ------------------------
+    if (!pc_tasks.empty()) {
+        svec<uint32_t> t_seg(pc_tasks.size()), t_cidx(pc_tasks.size());
+        svec<uint64_t> t_run0(pc_tasks.size() + 1, 0);
+        for (size_t i = 0; i < pc_tasks.size(); ++i) {
+            const uint32_t c = fg->cidx[pc_tasks[i]];
+            t_cidx[i] = c;
+            t_seg[i] = fg->cseg[c];
+            t_run0[i + 1] = t_run0[i] + (fg->crun0[c + 1] - fg->crun0[c]);
+        }
+        const uint64_t runs = t_run0.back();
+        uint32_t* d_tseg = A.take<uint32_t>(t_seg.size());
+        uint32_t* d_tcidx = A.take<uint32_t>(t_cidx.size());
+        uint64_t* d_trun0 = A.take<uint64_t>(t_run0.size());
+        uint32_t* d_cnt = A.take<uint32_t>(runs + 1);
+        uint32_t* d_off = A.take<uint32_t>(runs + 1);
+        size_t scan_tmp = 0;
+        VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tmp, d_cnt, d_off, 0u, runs, rocprim::plus<uint32_t>(), st));
+        void* d_scan = A.take<uint8_t>(scan_tmp + 256);
+        if (!d_scan || !d_off) return fail(VLG_E_INTERNAL, "arena carve failed (compaction)");
+        VLG_HIP_TRY(hipMemcpyAsync(d_tseg, t_seg.data(), t_seg.size() * 4, hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemcpyAsync(d_tcidx, t_cidx.data(), t_cidx.size() * 4, hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemcpyAsync(d_trun0, t_run0.data(), t_run0.size() * 8, hipMemcpyHostToDevice, st));
+        {
+            Timed t(ws, KS_FILTER_COMPACT, 2 * pc_total * sizeof(pos_t));
+            hipLaunchKernelGGL(filter_gather_counts_kernel, dim3((uint32_t)((runs + 255) / 256)), dim3(256), 0, st, d_tcidx, d_trun0,
+                               (uint32_t)t_seg.size(), fg->d_crun0, fg->d_runcnt, d_cnt);
+            VLG_HIP_TRY(rocprim::exclusive_scan(d_scan, scan_tmp, d_cnt, d_off, 0u, runs, rocprim::plus<uint32_t>(), st));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_compact_kernel<pos_t>), dim3((uint32_t)(((runs + kCompactRuns - 1) / kCompactRuns + 3) / 4)),
+                               dim3(256), 0, st, P, fg->d_segs, d_tseg, d_trun0, (uint32_t)t_seg.size(), fg->d_abits, d_cnt, d_off, Pc);
+        }
+        VLG_HIP_TRY(hipGetLastError());
+    }
     std::vector<uint32_t> cls_count(kmax + 1, 0), cls_first(kmax + 2, 0);   // segments per dist class
     for (uint64_t qi = q0; qi < q1; ++qi) {
         uint32_t k = qm[qi - q0].k;
@@ -560,7 +605,6 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         qm[qi - q0].seg0 = seg_of_sub[q->qsub[qi] - s0];
     }
     uint64_t pc_used = 0;
-    std::vector<uint32_t> pc_tasks;                              // filtered sub-patterns of the chunk (group relative), in Pc order
     for (uint64_t qi = q0; qi < q1; ++qi) {
         uint32_t k = qm[qi - q0].k;
         if (qm[qi - q0].seg0 == kNone) continue;
@@ -570,8 +614,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
             m.level = i; m.dist = k - 1 - i;
             m.lo = q->lo[s]; m.hi = q->hi[s];
             if (filtered(s)) {                                   // private list of the query: the survivors, compacted behind P
-                m.pbegin = (uint32_t)((Pc - P) + pc_used);
-                pc_tasks.push_back((uint32_t)(s - fg->sub0));
+                m.pbegin = (uint32_t)((Pc - P) + pc_used);                 // the order of pc_tasks
                 pc_used += eo(s);
             } else {
                 m.pbegin = poff[pl.did[s]];
@@ -610,39 +653,6 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         }
     if (lvl0_end <= lvl0_begin) { res->pieces.push_back(piece); return VLG_OK; }
     jt.mark("  chunk: host metadata");
-    // ---- private lists: compact the survivors of the chunk's filtered lists behind P ------------------------
-    if (!pc_tasks.empty()) {
-        svec<uint32_t> t_seg(pc_tasks.size()), t_cidx(pc_tasks.size());
-        svec<uint64_t> t_run0(pc_tasks.size() + 1, 0);
-        for (size_t i = 0; i < pc_tasks.size(); ++i) {
-            const uint32_t c = fg->cidx[pc_tasks[i]];
-            t_cidx[i] = c;
-            t_seg[i] = fg->cseg[c];
-            t_run0[i + 1] = t_run0[i] + (fg->crun0[c + 1] - fg->crun0[c]);
-        }
-        const uint64_t runs = t_run0.back();
-        uint32_t* d_tseg = A.take<uint32_t>(t_seg.size());
-        uint32_t* d_tcidx = A.take<uint32_t>(t_cidx.size());
-        uint64_t* d_trun0 = A.take<uint64_t>(t_run0.size());
-        uint32_t* d_cnt = A.take<uint32_t>(runs + 1);
-        uint32_t* d_off = A.take<uint32_t>(runs + 1);
-        size_t scan_tmp = 0;
-        VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tmp, d_cnt, d_off, 0u, runs, rocprim::plus<uint32_t>(), st));
-        void* d_scan = A.take<uint8_t>(scan_tmp + 256);
-        if (!d_scan || !d_off) return fail(VLG_E_INTERNAL, "arena carve failed (compaction)");
-        VLG_HIP_TRY(hipMemcpyAsync(d_tseg, t_seg.data(), t_seg.size() * 4, hipMemcpyHostToDevice, st));
-        VLG_HIP_TRY(hipMemcpyAsync(d_tcidx, t_cidx.data(), t_cidx.size() * 4, hipMemcpyHostToDevice, st));
-        VLG_HIP_TRY(hipMemcpyAsync(d_trun0, t_run0.data(), t_run0.size() * 8, hipMemcpyHostToDevice, st));
-        {
-            Timed t(ws, KS_FILTER_COMPACT, 2 * pc_used * sizeof(pos_t));
-            hipLaunchKernelGGL(filter_gather_counts_kernel, dim3((uint32_t)((runs + 255) / 256)), dim3(256), 0, st, d_tcidx, d_trun0,
-                               (uint32_t)t_seg.size(), fg->d_crun0, fg->d_runcnt, d_cnt);
-            VLG_HIP_TRY(rocprim::exclusive_scan(d_scan, scan_tmp, d_cnt, d_off, 0u, runs, rocprim::plus<uint32_t>(), st));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_compact_kernel<pos_t>), dim3((uint32_t)(((runs + kCompactRuns - 1) / kCompactRuns + 3) / 4)),
-                               dim3(256), 0, st, P, fg->d_segs, d_tseg, d_trun0, (uint32_t)t_seg.size(), fg->d_abits, d_cnt, d_off, Pc);
-        }
-        VLG_HIP_TRY(hipGetLastError());
-    }
     jt.mark("  chunk: compaction");
     // ---- carve the arena ---------------------------------------------------------------------------
     uint32_t* link = ws->tuples ? A.take<uint32_t>(T) : nullptr;      // only the tuples walk the links
