@@ -537,19 +537,23 @@ template <uint32_t kShift>
 __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t t0, uint64_t total,
                                   uint64_t* __restrict__ val)
 {
+    constexpr uint32_t kPer = 8;                           // elements per thread: one list lookup per 2048 elements
     __shared__ uint64_t s_first;
-    for (uint64_t base = t0 + (uint64_t)blockIdx.x * 256; base < total; base += (uint64_t)gridDim.x * 256) {
+    for (uint64_t base = t0 + (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
         if (threadIdx.x == 0) {
             uint64_t lo = 0, hi = n_pat;
             while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (out_off[mid] <= base) lo = mid; else hi = mid; }
             s_first = lo;
         }
         __syncthreads();
-        uint64_t t = base + threadIdx.x;
-        if (t < total) {
-            uint64_t p = s_first;
-            while (out_off[p + 1] <= t) ++p;
-            val[t - t0] = ((t - t0) << kShift) | (l[p] + (t - out_off[p]));
+        uint64_t p = s_first;
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint64_t t = base + i * 256 + threadIdx.x;
+            if (t < total) {
+                while (out_off[p + 1] <= t) ++p;
+                val[t - t0] = ((t - t0) << kShift) | (l[p] + (t - out_off[p]));
+            }
         }
         __syncthreads();
     }
@@ -831,7 +835,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     for (uint64_t t0 = 0; t0 < total; t0 += batch_max) {
         const uint64_t t1 = std::min(total, t0 + batch_max);
         if (trail) VLG_HIP_TRY(hipMemsetAsync(trail, 0, iv.n * 8, stream));      // steps are counted per sweep: trails are not shared across sweeps
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for(t1 - t0, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for((t1 - t0 + 7) / 8, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
                            t0, t1, val_a);
         VLG_HIP_TRY(hipGetLastError());
         uint64_t alive = t1 - t0;

@@ -380,19 +380,23 @@ template <typename pos_t>
 __global__ void sort_compose_kernel(const pos_t* __restrict__ P, const uint64_t* __restrict__ off /* [nd+1] */, uint64_t nd, uint64_t total,
                                     uint32_t pos_bits, uint64_t* __restrict__ keys)
 {
+    constexpr uint32_t kPer = 8;                           // elements per thread: one list lookup per 2048 elements
     __shared__ uint64_t s_first;
-    for (uint64_t base = (uint64_t)blockIdx.x * 256; base < total; base += (uint64_t)gridDim.x * 256) {
+    for (uint64_t base = (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
         if (threadIdx.x == 0) {
             uint64_t lo = 0, hi = nd;                      // last list with off[l] <= base
             while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (off[mid] <= base) lo = mid; else hi = mid; }
             s_first = lo;
         }
         __syncthreads();
-        const uint64_t t = base + threadIdx.x;
-        if (t < total) {
-            uint64_t l = s_first;
-            while (off[l + 1] <= t) ++l;                   // empty lists are skipped too
-            keys[t] = (l << pos_bits) | (uint64_t)P[t];
+        uint64_t l = s_first;
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint64_t t = base + i * 256 + threadIdx.x;
+            if (t < total) {
+                while (off[l + 1] <= t) ++l;               // empty lists are skipped too
+                keys[t] = (l << pos_bits) | (uint64_t)P[t];
+            }
         }
         __syncthreads();
     }
@@ -477,7 +481,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         uint64_t* ka = reinterpret_cast<uint64_t*>(scratch);
         uint64_t* kb = ka + acc;
         Timed t(ws, KS_SORT, 2ull * acc * sizeof(pos_t));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_compose_kernel<pos_t>), dim3(grid_for(acc, 32768)), dim3(256), 0, st, Pa, d_off64, (uint64_t)nd, acc, bits, ka);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_compose_kernel<pos_t>), dim3(grid_for((acc + 7) / 8, 32768)), dim3(256), 0, st, Pa, d_off64, (uint64_t)nd, acc, bits, ka);
         rocprim::double_buffer<uint64_t> keys(ka, kb);
         size_t tb = sort_tmp;
         VLG_HIP_TRY(rocprim::radix_sort_keys(d_tmp, tb, keys, acc, 0, bits + list_bits, st));
