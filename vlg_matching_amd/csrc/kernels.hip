@@ -677,9 +677,12 @@ __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uin
     if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&stats[0], a); if (b) atomicAdd(&stats[1], b); }
 }
 
-// One round of pointer jumping over the records of a trail-sharing sweep: an element that follows another takes over
-// that element's position (done) or its pointer (two hops per round).  Records are single 64-bit words, so a reader
-// sees a valid state of the element it follows whichever round that one is in.
+// Records of a trail-sharing sweep -> positions: every element follows its chain of records (element it follows, steps apart) to
+// the end, at most kResolveHops hops per round, and replaces its record by what it found -- a position, or a shorter pointer for
+// the next round.  Records are single 64-bit words, so a reader sees a valid state of the element it follows whatever that
+// one's own thread is doing; chains collapse as the elements ahead finish (measured on C3: 2 + 2 hops per round over four
+// rounds 24.5 ms, to the end in one round + one checking round 18.6 ms).
+constexpr uint32_t kResolveHops = 64;
 template <typename pos_t>
 __global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict__ rec, uint64_t count, pos_t* __restrict__ out,
                                                             unsigned long long* __restrict__ n_open, uint32_t round)
@@ -690,13 +693,10 @@ __global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t r = rec[e];
         if (r >> kShift) {
-            uint64_t ro = rec[r & kLow];
-            const uint64_t delta = r >> kShift;
-            r = (ro >> kShift) == 0 ? ro + delta : ro + (delta << kShift);
-            if (r >> kShift) {                                                    // second hop
-                ro = rec[r & kLow];
-                const uint64_t d2 = r >> kShift;
-                r = (ro >> kShift) == 0 ? ro + d2 : ro + (d2 << kShift);
+            for (uint32_t h = 0; h < kResolveHops && (r >> kShift); ++h) {
+                const uint64_t ro = rec[r & kLow];
+                const uint64_t delta = r >> kShift;
+                r = (ro >> kShift) == 0 ? ro + delta : ro + (delta << kShift);
             }
             rec[e] = r;
             if ((r >> kShift) == 0) out[e] = (pos_t)r;
