@@ -298,9 +298,10 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
  * "global_sort_min" (default 2^20): from this many occurrences on all lists are sorted by one radix sort of
  * (list, position) keys instead of one segmented sort.
  * "filter" (default 1): before the join drop the list elements whose gap windows hold no element of the neighbouring
- * lists (they are in no match); "filter_min" (default 2^16) = join slots below which a query is joined as it is;
- * "filter_pivot" (default 1): filter outwards from the shortest list of a query when it is >= 12x shorter than all of
- * them together ("filter_pivot_ratio", default 12), otherwise (or with 0) by streaming sweeps over block bitmaps;
+ * lists (they are in no match); "filter_min" (default 2^12) = join slots below which a query is joined as it is
+ * ("filter_stream_min", default 2^16, for the queries filtered by streaming sweeps);
+ * "filter_pivot" (default 1): filter outwards from the shortest list of a query when it is >= 6x shorter than all of
+ * them together ("filter_pivot_ratio", default 6), otherwise (or with 0) by streaming sweeps over block bitmaps;
  * "filter_group_bytes" (default 0 = a third of the join scratch) caps the filter state of the queries filtered together.
  * "reserve" = bytes of scratch to allocate right away (at most the workspace's cap) instead of on first use.
  * "tuples" (default 1): materialise every sub-pattern position of every match (what sdsl::locate returns); 0 = first

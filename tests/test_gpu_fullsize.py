@@ -52,7 +52,7 @@ def test_c2_properties_and_mode_equivalence(c2):
     assert checked == s["n_matches"]
     assert int(first.astype(np.uint64).sum()) % (1 << 64) == s["checksum"]
     # --- identical results whatever the execution strategy ------------------------------------------------
-    for opts in ({"dedup": 0}, {"sweep": 0}, {"filter_min": 0}, {"sweep_min": 1, "sweep_tail": 1000}):
+    for opts in ({"dedup": 0}, {"sweep": 0}, {"filter_min": 0, "filter_stream_min": 0}, {"sweep_min": 1, "sweep_tail": 1000}):
         ws = Workspace()
         for k_, v_ in opts.items():
             ws.set_option(k_, v_)

@@ -444,6 +444,7 @@ def test_window_filter_equals_unfiltered_join_and_oracle(V, oracle, name, seed, 
     ws_f = Workspace(max_hbm_bytes=(cap_mb << 20)) if cap_mb else Workspace()
     ws_n.set_option("filter", 0)
     ws_f.set_option("filter_min", 0)
+    ws_f.set_option("filter_stream_min", 0)
     ws_f.set_option("filter_pivot", pivot)
     ws_f.set_option("global_sort_min", 1 if pivot else 1 << 40)      # all lists sorted at once / one sort per list
     if seed in (62, 65):
@@ -481,6 +482,7 @@ def test_window_filter_extreme_gaps(V, oracle, pivot):
     ws_n, ws_f = Workspace(), Workspace()
     ws_n.set_option("filter", 0)
     ws_f.set_option("filter_min", 0)
+    ws_f.set_option("filter_stream_min", 0)
     ws_f.set_option("filter_pivot", pivot)
     ra, rb = idx.search(qs, workspace=ws_n), idx.search(qs, workspace=ws_f)
     assert ws_f.kernel_stats()["filter_compact"]["launches"] > 0
@@ -501,6 +503,7 @@ def test_join_many_tiles_single_pattern(V, oracle):
         ws = Workspace()
         ws.set_option("filter", filt)
         ws.set_option("filter_min", 0)
+        ws.set_option("filter_stream_min", 0)
         res = idx.search(qs, workspace=ws)
         for i, qq in enumerate(qs):
             assert res.tuples(i).tolist() == o.search(qq).tolist(), (qq, filt)
@@ -706,7 +709,7 @@ def test_64bit_position_kernels(torch_cuda, V, oracle, monkeypatch):
     want = [o.search(q).tolist() for q in qs]
     for pivot in (1, 0):
         ws = Workspace()
-        for k_, v_ in (("sweep_min", 1), ("sweep_tail", 16), ("global_sort_min", 1), ("filter_min", 0), ("filter_pivot", pivot)):
+        for k_, v_ in (("sweep_min", 1), ("sweep_tail", 16), ("global_sort_min", 1), ("filter_min", 0), ("filter_stream_min", 0), ("filter_pivot", pivot)):
             ws.set_option(k_, v_)
         res = idx.search(qs, workspace=ws)
         assert ws.kernel_stats()["filter_compact"]["launches"] > 0 and ws.kernel_stats()["locate_resolve"]["launches"] > 0

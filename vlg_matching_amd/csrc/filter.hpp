@@ -570,7 +570,8 @@ inline int filter_mode(const vlg_queries* q, const Plan& pl, const vlg_workspace
     if (slots < ws->filter_min || !slots) return 0;
     if (pivot) *pivot = p;
     // two binary searches per pivot element and level against a pass (or two) over every element of every list
-    return ws->filter_pivot && best * ws->filter_pivot_ratio <= all ? 2 : 1;
+    if (ws->filter_pivot && best * ws->filter_pivot_ratio <= all) return 2;
+    return slots >= ws->filter_stream_min ? 1 : 0;         // the block bitmaps of a streamed query are a fixed cost (2 x n / 2^g bits)
 }
 
 // Bytes of filter state a query needs (0 = the query is not filtered).

@@ -54,10 +54,13 @@ struct vlg_workspace {
     bool trail = true;          // sorted-sweep locate: elements that step onto an SA index another element has visited share its LF trail
                                 // (needs dedup; with dedup off every occurrence walks its own LF steps like the reference)
     bool filter = true;         // window filter: drop the list elements that can be in no match before the join
-    uint64_t filter_min = 1ull << 16;   // queries with fewer join slots are joined as they are
+    uint64_t filter_min = 1ull << 12;   // queries with fewer join slots are joined as they are (C3, ms per batch: 2^18 271, 2^16 247, 2^14 240,
+                                        // 2^12 237.7, 2^10 237.6, 2^7 239)
+    uint64_t filter_stream_min = 1ull << 16;   // ... and so are those below this that would be filtered by streaming sweeps
     bool filter_pivot = true;   // filter from the shortest list of a query outwards when it is much shorter than the rest
     uint64_t filter_group_bytes = 0;    // cap of the filter state of one group of queries (0: a third of the join budget)
-    uint64_t filter_pivot_ratio = 12;   // ... i.e. when all lists together are at least this many times longer (measured on C3: 12)
+    uint64_t filter_pivot_ratio = 6;    // ... i.e. when all lists together are at least this many times longer (C3, ms per batch: 24 -> 262,
+                                        // 12 -> 251, 6 -> 246.6, 4 -> 246.4, <= 3 -> 248: the probes win wherever a list is clearly the shortest)
     uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
     uint64_t sweep_tail = 1ull << 20;   // stragglers of a sweep are finished one lane each
@@ -207,6 +210,7 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "filter_min")) { ws->filter_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_pivot")) { ws->filter_pivot = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter_pivot_ratio")) { ws->filter_pivot_ratio = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "filter_stream_min")) { ws->filter_stream_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_group_bytes")) { ws->filter_group_bytes = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "reserve")) {                           // allocate the scratch now (+ the per-chunk metadata a batch adds on top of its budget)
         const uint64_t b = std::min<uint64_t>((uint64_t)value, ws->cap_bytes);
