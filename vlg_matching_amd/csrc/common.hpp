@@ -102,10 +102,10 @@ void release_cached_device_memory();      // result buffers parked for reuse (se
 // next kernel does not start.  These vectors live in pinned blocks owned by the workspace instead: handed out bump-style
 // while a batch runs, recycled at the next batch, never unmapped in between.
 struct HostPool {
-    struct Blk { uint8_t* p; size_t cap; };
+    struct Blk { uint8_t* p; size_t cap; bool pinned; };
     std::vector<Blk> blocks;
     size_t cur = 0, off = 0;
-    void* take(size_t bytes);              // 64-byte aligned; nullptr when pinned memory cannot be had
+    void* take(size_t bytes);              // 64-byte aligned; pageable blocks (kept just as long) when pinned memory cannot be had
     void reset() { cur = 0; off = 0; }
     void release();                        // back to the driver (workspace destruction)
 };

@@ -1,6 +1,7 @@
 // Host-side logic of the library: error text, the prefix-code tree, HBM block layout planning.
 #include "common.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <queue>
 
@@ -29,8 +30,15 @@ void* HostPool::take(size_t bytes)
         if (off + bytes <= blocks[cur].cap) { void* p = blocks[cur].p + off; off += bytes; return p; }
         ++cur; off = 0;                                 // the rest of the block is left unused until the next batch
     }
-    Blk b{nullptr, std::max<size_t>(bytes, (size_t)64 << 20)};
-    if (hipHostMalloc((void**)&b.p, b.cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    Blk b{nullptr, std::max<size_t>(bytes, (size_t)64 << 20), true};
+    if (hipHostMalloc((void**)&b.p, b.cap, hipHostMallocDefault) != hipSuccess) {
+        // no pinned memory to be had: a pageable block that also stays until the workspace goes (what must not happen is an
+        // unmap between batches)
+        (void)hipGetLastError();
+        b.pinned = false;
+        b.p = (uint8_t*)malloc(b.cap);
+        if (!b.p) return nullptr;
+    }
     blocks.push_back(b);
     cur = blocks.size() - 1;
     off = bytes;
@@ -38,7 +46,7 @@ void* HostPool::take(size_t bytes)
 }
 void HostPool::release()
 {
-    for (Blk& b : blocks) (void)hipHostFree(b.p);
+    for (Blk& b : blocks) { if (b.pinned) (void)hipHostFree(b.p); else free(b.p); }
     blocks.clear();
     cur = off = 0;
 }
