@@ -144,10 +144,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P
 
 // Two steps at once: 128 ascending keys (lane i holds keys i and 64+i) share every window load, its fence test and the
 // loop around them, which is most of what a step costs.
-#ifndef VLG_COOP2
-#define VLG_COOP2 6
-#endif
-constexpr uint32_t kCoopWindows2 = VLG_COOP2;
+constexpr uint32_t kCoopWindows2 = 6;            // measured on C3: 2 -> 35.2, 3 -> 33.8, 4 -> 33.2, 6 -> 31.9, 8..16 -> 33..34 ms
 template <typename pos_t>
 __device__ __forceinline__ void wave_lower_bound2(const pos_t* __restrict__ P, uint32_t wb, uint32_t b, pos_t key0, bool need0, pos_t key1,
                                                   bool need1, uint32_t& j0, pos_t& v0, uint32_t& j1, pos_t& v1)
