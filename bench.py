@@ -1,69 +1,129 @@
 #!/usr/bin/env python3
 """bench.py -- VLG queries/s + located occurrences/s of the MI355X hot path (BASELINE.json metric).
 
-A "step" is one pass of the whole hot path (backward search -> locate -> sort -> gap join) over one batch
-of synthetic queries, index and query batch already resident in HBM.  At N=1 the workload is SURVEY.md 8(d)
-config C3 (1 GiB english-like text, 100k 3-sub-pattern queries, gap <= 1000).  With N GPUs the read-only
-index is built on rank 0 and broadcast over RCCL, every rank runs its own batch (weak scaling, no data-path
-collective); the timed region is bracketed by barrier + synchronize and the max over ranks is reported.
+A "step" is one pass of the whole hot path (backward search -> locate -> sort -> window filter -> gap join) over one batch
+of synthetic queries, index and parsed query batch already resident in HBM.  At N=1 the workload is SURVEY.md 8(d) config C3
+(1 GiB english-like text, 100k 3-sub-pattern queries, gap <= 1000).
+
+N GPUs = N processes, one per GPU: launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, or by
+this script itself when it is started plainly with --gpus N > 1 (the parent then only spawns and waits: it never touches a
+GPU).  The read-only index is built on rank 0 and broadcast over RCCL (vlg_matching_amd.dist.replicate_index), then
+  * weak scaling (the printed `value`): every rank runs its own 100k-query batch;
+  * strong scaling (reported beside it as `strong_scaling`): THE batch of rank 0 is cut into contiguous slices of equal
+    work (sum of SA-interval sizes from one backward-search pass, vlg_matching_amd.dist.shard_by_work) -- the query loop of
+    gm_search.cpp:91-121 sharded.
+No collective on the data path; the timed regions are bracketed by barrier + synchronize and the max over ranks is reported.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--scale 1.0]
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-
-# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/*_pmc_*.csv; FETCH_SIZE + WRITE_SIZE,
-# KiB -> bytes); filled in by tools/pmc_summary.py.  None = not measured for that kernel.
-PMC_TRAFFIC, PMC_DETAIL = {}, {}
-try:
-    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as _f:
-        for _k, _v in json.load(_f).items():
-            PMC_TRAFFIC[_k] = _v["bytes_per_launch"]
-            # FETCH_SIZE is exact for the 64-byte requests of block reads (tools/k1_bench.py) and reads half of a wide
-            # coalesced streaming read on gfx950 (MI355X_MICROARCH.md, HBM): both readings are kept next to the raw sum
-            PMC_DETAIL[_k] = {"read_raw": _v["read_bytes_per_launch_raw"], "read_if_all_wide_streaming": _v["read_bytes_per_launch_x2_if_streaming"],
-                              "write": _v["write_bytes_per_launch"], "source": "profiles/pmc_traffic.json (" + _v.get("tag", "") + ")"}
-except Exception:
-    pass
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=450000, budget_s=25.0, threads=16):
-    """The CPU oracle (restatement of the reference path, reference data layout) timed on this host, one thread,
-    on a bounded seeded sample of the same query batch."""
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start N child processes (one per device) and wait.  Decided before this process has
+    made any GPU call (it never makes one): a process that has initialised the GPU must not be replaced or forked."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:                                                   # a rank that died leaves the others in a collective: end them
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
+def load_pmc():
+    """HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json, written by
+    tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes).  Empty when the file is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+# kernel class (vlg_workspace_kernel_stats) -> (display name, kernels of profiles/pmc_traffic.json that make it up,
+#                                               what its algorithmic bytes are)
+CLASSES = {
+    "backward_search": ("backward_search_kernel", ["backward_search_kernel"], "32 B per wavelet-tree level of every rank (SURVEY 8d K2)"),
+    "expand": ("expand_kernel", [], ""),
+    "locate": ("sweep_step_kernel", ["sweep_step_kernel", "sweep_tail_kernel"], "32 B per tree level actually walked + one SA sample per occurrence (SURVEY 8d K3)"),
+    "locate_partition": ("sweep_partition_kernel", ["sweep_hist_kernel", "sweep_scatter_kernel", "sweep_partition_kernel"],
+                         "per element of the round: key + value read once, written once (2 x 10 B)"),
+    "locate_resolve": ("trail_resolve_kernel", ["trail_resolve_kernel", "trail_resolve_round_kernel"], "8 B record read + 4..8 B position written per occurrence"),
+    "sort": ("radix sort of (list, position) keys", ["sort_compose_kernel", "sort_narrow_kernel"], "one read + one write of every position (2 x 4 B); the radix passes in between are overhead"),
+    "filter_pivot": ("filter_pivot_kernel", ["filter_pivot_kernel"], "16 B per (pivot element, level): two lower bounds"),
+    "filter_pass": ("filter_pass_kernel", ["filter_pass_kernel"], "4 B per list element streamed"),
+    "filter_compact": ("filter_compact_kernel", ["filter_compact_kernel", "filter_count_runs_kernel", "filter_gather_counts_kernel"],
+                       "activity bits read + every survivor read and written (2 x 4 B)"),
+    "join_init": ("join_init_kernel", ["join_init_kernel"], ""),
+    "join_link": ("join_link_kernel", ["join_link_kernel"], "8 B per join slot (SURVEY 8d K5: list element read + link state written)"),
+    "join_scan": ("bits_summary_kernel", ["bits_summary_kernel"], ""),
+    "join_chain": ("join_jump + chain_tiles/walk/emit", ["join_jump_kernel", "chain_tiles_kernel", "chain_walk_kernel", "chain_emit_kernel"],
+                   "8 B per slot of every first list"),
+    "gather": ("join_gather_kernel", ["join_gather_kernel"], "8 B per match (and per tuple value) written"),
+    "join": ("vlg_join_batch", [], ""),
+}
+
+
+def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=1200000, budget_s=45.0, min_queries=100):
+    """The CPU oracle (restatement of the reference path, reference data layout) timed on this host, ONE thread (the
+    reference is single-threaded, gm_search.cpp:91), on a bounded seeded sample of the same query batch; then the same
+    code on nproc threads over disjoint query shards, for disclosure."""
     from oracle import oracle as O
+    import numpy as np
     parts = idx.export_parts()
     o = O.Index.from_parts(parts)
     rng = np.random.default_rng(12345)
     order = rng.permutation(len(queries))
+    occ_of = {}
+
+    def need_of(qi):
+        if qi not in occ_of:
+            subs, _, _, _ = O.query_fields(O.parse(queries[qi]))
+            occs = [o.backward_search(sp)[0] for sp in subs]
+            occ_of[qi] = 0 if min(occs) == 0 else sum(occs)
+        return occ_of[qi]
+    # the sample: queries in random order whose lists fit what is left of the occurrence budget -- at least min_queries of them,
+    # each capped so that no single heavy query eats the budget (a 10^6-occurrence query costs 40 s on one core)
     stats = np.zeros(4, dtype=np.uint64)
     done, dt, remaining = 0, 0.0, budget_occ
+    per_query_cap = budget_occ // min_queries * 4
     for qi in order:
-        subs, _, _, _ = O.query_fields(O.parse(queries[qi]))
-        occs = [o.backward_search(sp)[0] for sp in subs]
-        need = 0 if min(occs) == 0 else sum(occs)
-        if need > remaining:                      # keeps the sample bounded: heavy queries cost minutes on one core
+        need = need_of(int(qi))
+        if need > remaining or need > per_query_cap:
             continue
         t0 = time.perf_counter()
         o.search(queries[qi], stats=stats)
         dt += time.perf_counter() - t0
         done += 1
         remaining -= need
-        if dt > budget_s or remaining < 1000 or done >= 2000:
+        if (dt > budget_s and done >= min_queries) or remaining < 1000 or done >= 5000 or dt > 3 * budget_s:
             break
     occ_rate = float(stats[0]) / dt if dt > 0 else 0.0
     # a sample's queries/s depends on which heavy queries it happened to draw; the stable figure is located
@@ -73,20 +133,18 @@ def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=450000, budget_s=2
            "located_occ_per_sec": occ_rate, "sample_queries": done, "sample_seconds": dt,
            "sample_located_occ": int(stats[0]), "sample_lf_steps": int(stats[1]),
            "sample": "%d queries of the same batch, drawn in random order (seed 12345) while their occurrence lists fit a "
-                     "%d-occurrence budget; %.1f s on one core; queries/s = sample occurrences/s / mean occurrences "
-                     "per query of the full batch (%.0f)" % (done, budget_occ, dt, occ_per_query_mean)}
-    # disclosure: the same restatement on T threads over disjoint query shards
+                     "%d-occurrence budget (at most %d per query); %.1f s on one core; queries/s = sample occurrences/s / mean "
+                     "occurrences per query of the full batch (%.0f)" % (done, budget_occ, per_query_cap, dt, occ_per_query_mean)}
+    # disclosure: the same restatement on T = nproc threads over disjoint query shards
     # (the C library is re-entrant and ctypes releases the GIL); the reference itself is single-threaded.
-    T = threads
+    T = max(1, os.cpu_count() or 1)
     if T > 1:
         import concurrent.futures as cf
         light = []
         for qi in order:
-            subs, _, _, _ = O.query_fields(O.parse(queries[qi]))
-            occs = [o.backward_search(sp)[0] for sp in subs]
-            if min(occs) and sum(occs) <= budget_occ // 8:
+            if 0 < need_of(int(qi)) <= 20000:
                 light.append(queries[qi])
-            if len(light) >= 64 * T:
+            if len(light) >= 24 * T:
                 break
         shards = [light[i::T] for i in range(T)]
 
@@ -95,7 +153,7 @@ def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=450000, budget_s=2
             t0 = time.perf_counter()
             for qq in shard:
                 o.search(qq, stats=st)
-                if time.perf_counter() - t0 > 8.0:
+                if time.perf_counter() - t0 > 10.0:
                     break
             return int(st[0])
         t0 = time.perf_counter()
@@ -104,7 +162,7 @@ def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=450000, budget_s=2
         dt_t = time.perf_counter() - t0
         out["threads_T"] = {"threads": T, "located_occ_per_sec": occ_t / dt_t if dt_t > 0 else 0.0,
                             "queries_per_sec": (occ_t / dt_t) / occ_per_query_mean if dt_t > 0 and occ_per_query_mean > 0 else 0.0,
-                            "sample_seconds": dt_t, "sample_located_occ": occ_t}
+                            "sample_seconds": dt_t, "sample_located_occ": occ_t, "sample_queries": sum(len(s) for s in shards)}
     return out
 
 
@@ -113,6 +171,8 @@ def cpu_sasearch(text, queries, occ_per_query_mean, budget_occ=60000000, budget_
     join (index_sasearch.hpp) -- restated in the oracle, one thread, same random query order.  The suffix array comes from the
     device sorter (vlg_suffix_array_device); building it is not part of the figure, as `load` is not in the reference's."""
     from oracle import oracle as O
+    import numpy as np
+    import torch
     import vlg_matching_amd as V
     n_text = len(text)
     if n_text + 1 >= (1 << 32) - 1:
@@ -161,15 +221,25 @@ def main():
     ap.add_argument("--workspace-gb", type=float, default=160.0)
     ap.add_argument("--bv", choices=["plain", "rrr"], default=None, help="wavelet-tree bit-vectors (default: rrr for C5, else plain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling region")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (parse + H2D + search + D2H) region")
     ap.add_argument("--tuples", action="store_true", help="also materialise every sub-pattern position of every match (sdsl::locate output)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                     # does not return
+
+    import numpy as np
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or plainly "
+                 "without WORLD_SIZE set)" % (args.gpus, world, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     if args.single_device:
         local_rank = 0
@@ -181,16 +251,20 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
         else:
             dist.init_process_group(args.backend)
+        assert dist.get_world_size() == args.gpus
 
     import vlg_matching_amd as V
+    from vlg_matching_amd import dist as vdist
     from vlg_matching_amd import workload
     from vlg_matching_amd.index import Queries, Workspace
     V.capi.check(V.lib().vlg_set_device(local_rank))
+    dev = torch.device("cuda", local_rank)
 
     cfg = workload.config(args.config, args.scale)
-    t_gen = t_build = 0.0
+    t_gen = t_build = t_bcast = 0.0
     # ---- index: built on rank 0, replicated over RCCL (one broadcast of the contiguous HBM image) ----------
     text = None
+    idx = plain_idx = None
     if rank == 0:
         t0 = time.perf_counter()
         text = workload.gen_text(cfg["kind"], cfg["n"], cfg["seed"])
@@ -209,20 +283,15 @@ def main():
             t0 = time.perf_counter()
             plain_idx, idx = idx, idx.compress()
             log("rrr-63 re-encoding on device in %.2f s: %s" % (time.perf_counter() - t0, idx.info()))
-            if args.no_cpu_baseline:
-                del plain_idx
+            if args.no_cpu_baseline or world > 1:
+                plain_idx = None
     if world > 1:
-        nb = torch.tensor([idx.blob_bytes() if rank == 0 else 0], dtype=torch.int64, device="cuda")
-        dist.broadcast(nb, 0)
-        blob = torch.empty(int(nb.item()), dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idx.blob_export(blob.data_ptr(), blob.numel())
-        t0 = time.perf_counter()
-        dist.broadcast(blob, 0)
         torch.cuda.synchronize()
-        log("rank %d: index image %.1f MB broadcast in %.3f s" % (rank, blob.numel() / 1e6, time.perf_counter() - t0))
-        if rank != 0:
-            idx = V.VlgIndex.attach_blob(blob.data_ptr(), blob.numel(), keep=blob)
+        t0 = time.perf_counter()
+        idx = vdist.replicate_index(idx, dist, dev, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+        log("rank %d: index image replicated in %.3f s" % (rank, t_bcast))
     info = idx.info()
 
     # ---- query batches: one per rank (weak scaling), generated where the text is ---------------------------
@@ -248,52 +317,152 @@ def main():
     for kv in filter(None, os.environ.get("VLG_BENCH_OPTIONS", "").split(",")):      # development: name=value workspace options
         ws.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
-    def step():
-        return idx.search(q, workspace=ws)
+    def timed(fn, steps):
+        """barrier + synchronize on both sides, max over ranks -> (seconds, last return value)"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = fn()
+        torch.cuda.synchronize()
+        mine_dt = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, mine_dt, out
 
+    def reduce_sum(vals):
+        t = torch.tensor(vals, dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [int(x) for x in t.tolist()]
+
+    def gather_per_rank(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        if world == 1:
+            return [t.tolist()]
+        outl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outl, t)
+        return [o.tolist() for o in outl]
+
+    # ---- the timed region of the metric: K steps of the whole hot path over this rank's resident batch ------------
     for _ in range(args.warmup):
-        step()
+        idx.search(q, workspace=ws)
     ws.profile(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = None
-    for _ in range(args.steps):
-        res = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, my_dt, res = timed(lambda: idx.search(q, workspace=ws), args.steps)
     s = res.summary
-    tot = torch.tensor([s["n_queries"], s["located_occurrences"], s["n_matches"], s["logical_occurrences"]],
-                       dtype=torch.int64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    n_queries, n_occ, n_matches, n_logical = int(tot[0]), int(tot[1]), int(tot[2]), int(tot[3])
+    n_queries, n_occ, n_matches, n_logical = reduce_sum([s["n_queries"], s["located_occurrences"], s["n_matches"], s["logical_occurrences"]])
     kstats = ws.kernel_stats()
+    ws.profile(False)
+    per_rank = gather_per_rank([my_dt / args.steps * 1e3, s["located_occurrences"], s["n_matches"]])
+
+    # ---- end to end, as SURVEY.md 8(d) words it: parse + H2D of the query batch, search, D2H of counts and first positions
+    #      (pinned host buffers; the index upload is separate, as `load` is in gm_search.cpp:68-83) ---------------------------
+    e2e = None
+    if not args.no_e2e:
+        raws = [r.encode("latin-1") for r in queries]
+        off = np.zeros(len(raws) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in raws])
+        blob = b"".join(raws)                                  # the pattern file's bytes: read before the clock starts, like gm_search.cpp:174
+        nq = len(raws)
+        pin_counts = torch.empty(max(nq, 1), dtype=torch.int64).pin_memory()
+        pin_off = torch.empty(nq + 1, dtype=torch.int64).pin_memory()
+        pin_first = torch.empty(max(s["n_matches"], 1) + 1024, dtype=torch.int64).pin_memory()
+        phases = [0.0, 0.0, 0.0]
+
+        def e2e_step():
+            t0 = time.perf_counter()
+            qq = Queries.from_blob(blob, off)
+            t1 = time.perf_counter()
+            r = idx.search(qq, workspace=ws)
+            t2 = time.perf_counter()
+            assert r.summary["n_matches"] <= pin_first.numel()
+            r.fetch_into(pin_counts.data_ptr(), pin_off.data_ptr(), pin_first.data_ptr(), None)
+            t3 = time.perf_counter()
+            phases[0] += t1 - t0; phases[1] += t2 - t1; phases[2] += t3 - t2
+            return r
+        e2e_step()                                             # pinned pages touched, result buffers recycled
+        phases[:] = [0.0, 0.0, 0.0]
+        dt_e, _, r_e = timed(e2e_step, args.steps)
+        assert r_e.summary["checksum"] == s["checksum"] and r_e.summary["n_matches"] == s["n_matches"]
+        assert int(pin_counts[:nq].sum()) == s["n_matches"]
+        e2e = {"ms_per_step": dt_e / args.steps * 1e3, "queries_per_sec": n_queries * args.steps / dt_e,
+               "parse_and_h2d_ms": phases[0] / args.steps * 1e3, "search_ms": phases[1] / args.steps * 1e3,
+               "d2h_ms": phases[2] / args.steps * 1e3, "h2d_bytes": len(blob) + off.nbytes,
+               "d2h_bytes": int(8 * (2 * nq + 1 + s["n_matches"])),
+               "what": "vlg_queries_parse (host parse + upload) + vlg_search_batch + vlg_result_fetch of counts, offsets and first "
+                       "positions into pinned host memory; rank 0's figures, max over ranks for ms_per_step"}
+        del pin_first
+
+    # ---- strong scaling: THE batch (rank 0's) cut by work, every rank searches its slice ------------------------------------
+    strong = None
+    if world > 1 and not args.no_strong:
+        if rank == 0:
+            w = idx.query_weights(queries)                     # sum of SA-interval sizes per query: one backward-search pass
+            cuts = vdist.shard_by_work(w, world)
+            slices = [queries[b:e] for b, e in cuts]
+        else:
+            cuts, slices = None, None
+        mine = [None]
+        dist.scatter_object_list(mine, slices, src=0)
+        qs = Queries(mine[0])
+        idx.search(qs, workspace=ws)                           # warm-up of the slice's shapes
+        dt_s, my_dt_s, r_s = timed(lambda: idx.search(qs, workspace=ws), args.steps)
+        ss = r_s.summary
+        tq, tocc, tm, tlog = reduce_sum([ss["n_queries"], ss["located_occurrences"], ss["n_matches"], ss["logical_occurrences"]])
+        chk = vdist.reduce_checksum(ss["checksum"], dist, dev)
+        pr = gather_per_rank([my_dt_s / args.steps * 1e3, ss["n_queries"], ss["located_occurrences"], ss["logical_occurrences"]])
+        strong = {"scaling": "strong", "value": tq * args.steps / dt_s, "unit": "queries/s", "ms_per_step": dt_s / args.steps * 1e3,
+                  "queries": tq, "matches": tm, "checksum": chk, "located_occ_per_step_all_ranks": tocc, "logical_occ_per_step": tlog,
+                  "per_rank": [{"ms_per_step": p[0], "queries": int(p[1]), "located_occ": int(p[2]), "logical_occ": int(p[3])} for p in pr],
+                  "note": "the 1-GPU batch sharded by sum of SA-interval sizes; each rank locates the distinct intervals of its own "
+                          "slice, so occurrences shared between slices are located once per rank that needs them (located_occ summed "
+                          "over ranks > the 1-GPU figure): strong scaling of this batch is sub-linear by construction"}
+        if rank == 0:
+            # same batch as the weak region of rank 0: totals must agree
+            assert tq == s["n_queries"] and tm == s["n_matches"] and chk == s["checksum"], (tq, tm, chk, s)
 
     if rank == 0:
-        def roof(name, kernel):
+        pmc = load_pmc()
+        step_ms = dt / args.steps * 1e3
+
+        def roof(name):
             st = kstats[name]
+            disp, members, what = CLASSES.get(name, (name, [], ""))
+            if name == "locate" and not kstats["locate_partition"]["launches"]:
+                disp, members = "locate_kernel", ["locate_kernel"]
             launches = max(st["launches"], 1)
             ms = st["total_ms"] / launches
             alg = st["algorithmic_bytes"] / launches
             ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"bound": "hbm", "kernel": kernel, "kernel_class": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC.get(kernel), "traffic_detail": PMC_DETAIL.get(kernel),
-                    "algorithmic_bytes_per_launch": alg,
-                    "avg_launch_ms": ms, "launches": st["launches"], "ms_per_step": st["total_ms"] / args.steps}
-        names = {"locate": "sweep_step_kernel" if kstats["locate_partition"]["launches"] else "locate_kernel",
-                 "join_link": "join_link_kernel", "join_init": "join_init_kernel", "join_scan": "rocprim scan (reverse min)", "join_chain": "join_jump+chain_tiles/walk/emit",
-                 "gather": "join_gather_kernel", "sort": "rocprim radix_sort_keys on (list, position) keys", "locate_partition": "rocprim radix_sort_pairs",
-                 "backward_search": "backward_search_kernel", "expand": "expand_kernel", "filter_pass": "filter_pass_kernel",
-                 "filter_pivot": "filter_pivot_kernel", "filter_compact": "filter_count_runs + scan + filter_compact_kernel",
-                 "locate_resolve": "trail_resolve_kernel"}
+            # counter traffic of the class per step = sum over its kernels of bytes per launch x launches per step in the PMC run
+            tr = rd = wr = None
+            got = [pmc[m] for m in members if m in pmc]
+            if got:
+                steps_pmc = max(int(pmc.get("_meta", {}).get("steps_profiled", 1)), 1)
+                rd = sum(g["read_bytes_per_launch_raw"] * g["launches"] for g in got) / steps_pmc
+                wr = sum(g["write_bytes_per_launch"] * g["launches"] for g in got) / steps_pmc
+                tr = rd + wr
+            class_ms = st["total_ms"] / args.steps
+            traffic_per_launch = tr / (st["launches"] / args.steps) if tr is not None and st["launches"] else None
+            return {"bound": "hbm", "kernel": disp, "kernel_class": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic_per_launch,
+                    "traffic_detail": None if tr is None else {
+                        "read_raw_per_step": rd, "read_if_all_wide_streaming_per_step": 2 * rd, "write_per_step": wr,
+                        "source": "profiles/pmc_traffic.json (%s)" % got[0].get("tag", ""),
+                        "note": "FETCH_SIZE is exact for 64-byte random requests and reads half of a wide coalesced streaming read on "
+                                "gfx950 (MI355X_MICROARCH.md, HBM): both readings are given"},
+                    "hbm_frac_counter": None if tr is None or class_ms <= 0 else tr / (class_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "hbm_frac_counter_if_streaming": None if tr is None or class_ms <= 0 else (2 * rd + wr) / (class_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic_over_algorithmic": None if tr is None or not st["algorithmic_bytes"] else tr / (st["algorithmic_bytes"] / args.steps),
+                    "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_are": what,
+                    "avg_launch_ms": ms, "launches": st["launches"], "ms_per_step": class_ms, "share_of_step": class_ms / step_ms}
         dominant = max(kstats, key=lambda k: kstats[k]["total_ms"])
         out = {
             "metric": "vlg_queries_per_sec",
@@ -302,7 +471,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -326,11 +495,18 @@ def main():
             "lf_steps_per_occ": s["lf_steps"] / max(s["located_occurrences"], 1),
             "wt_levels_per_lf": s["wt_levels_locate"] / max(s["lf_steps"], 1),
             "chunks_per_step": s["n_chunks"],
-            "index_build_s": t_build, "text_gen_s": t_gen,
+            "index_build_s": t_build, "text_gen_s": t_gen, "index_broadcast_s": t_bcast,
+            "per_rank": [{"ms_per_step": p[0], "located_occ": int(p[1]), "matches": int(p[2])} for p in per_rank],
+            "e2e_ms_per_step": e2e["ms_per_step"] if e2e else None,
+            "e2e": e2e,
+            "strong_scaling": strong,
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kstats.items()},
             "kernels_ms_sum_per_step": sum(v["total_ms"] for v in kstats.values()) / args.steps,
-            "roofline": roof(dominant, names[dominant]),                 # the dominant kernel class of the step
-            "rank_kernel_roofline": roof("locate", names["locate"]),     # the LF / bit-rank kernel the north star names
+            "roofline": roof(dominant),                                  # the dominant kernel class of the step
+            "rank_kernel_roofline": roof("locate"),                      # the LF / bit-rank kernel the north star names
+            # every kernel class that takes at least 5 % of the step
+            "rooflines": [roof(k) for k in sorted(kstats, key=lambda k: -kstats[k]["total_ms"])
+                          if kstats[k]["total_ms"] / args.steps >= 0.05 * step_ms],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(plain_idx if info["bv_kind"] else idx, queries, n_logical / max(n_queries, 1))

@@ -102,7 +102,9 @@ vlg_status vlg_index_build(const uint8_t* h_text, uint64_t n_text, uint32_t sa_s
 vlg_status vlg_index_build_device(const uint8_t* d_text, uint64_t n_text, uint32_t sa_sample_dens,
                                   void* stream, vlg_index** out);
 /* Adopt an index built by the reference (host arrays in its layout) -- replaces
- * `idx.load(istream)` (index_sasearch.hpp:41-45; csa_wt.hpp:395-407). */
+ * `idx.load(istream)` (index_sasearch.hpp:41-45; csa_wt.hpp:395-407).
+ * Limits: n <= 2^36, and no wavelet-tree node may hold 2^32 or more 1-bits (the super-block counts are 32-bit and
+ * node-relative): always true for n <= 2^32, otherwise checked against the symbol counts -> VLG_E_UNSUPPORTED. */
 vlg_status vlg_index_from_parts(const vlg_index_parts* h_parts, vlg_index** out);
 /* Export to the reference layout (two-phase: pass NULL buffers in `out` to get sizes only). -- replaces
  * `idx.serialize(ostream)` (index_sasearch.hpp:33-39).  Buffers in `out` are caller-allocated host arrays. */
@@ -152,6 +154,10 @@ vlg_status vlg_index_load_sdsl(const char* path, uint32_t sa_sample_dens, vlg_in
 vlg_status vlg_index_blob_bytes(const vlg_index* idx, uint64_t* bytes);
 vlg_status vlg_index_blob_export(const vlg_index* idx, void* d_blob, uint64_t bytes, void* stream);
 vlg_status vlg_index_attach_blob(const void* d_blob, uint64_t bytes, vlg_index** out);
+/* The same for ONE process that drives several GPUs of a node (the C++ host's `gm_search_gpu -g N`): a copy of the index in the
+ * HBM of `device`, moved by a peer copy over xGMI; the new handle owns its memory.  Calls on it must run with `device`
+ * current (vlg_set_device is per host thread). */
+vlg_status vlg_index_replicate(const vlg_index* src, int device, vlg_index** out);
 
 /* ------------------------------------------------------------------------------------------
  * K1: batched bit-rank.  rank_support_v<1,1>::rank / rank_support_v5<1,1>::rank
@@ -232,6 +238,10 @@ vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_off, uint64_t
 vlg_status vlg_queries_create(const uint8_t* h_blob, const uint64_t* h_suboff, const uint64_t* h_qsub,
                               const uint64_t* h_lo, const uint64_t* h_hi, const uint64_t* h_end_len,
                               uint64_t n_queries, vlg_queries** out);
+/* sdsl::count(csa, sub-pattern) (include/sdsl/suffix_array_algorithm.hpp:516-529) for every sub-pattern of the batch: one
+ * backward-search pass, h_occ[s] = r + 1 - l (vlg_queries_subpatterns(q) entries, in batch order).  What SURVEY.md 8(e) shards
+ * a batch by: the sum over a query's sub-patterns estimates its locate + join work. */
+vlg_status vlg_queries_occurrences(const vlg_index* idx, const vlg_queries* q, uint64_t* h_occ, void* stream);
 uint64_t vlg_queries_count(const vlg_queries* q);
 uint64_t vlg_queries_subpatterns(const vlg_queries* q);
 /* h_k[q] = number of sub-patterns of query q (0 for a query that failed to parse). */
@@ -251,6 +261,23 @@ void vlg_workspace_destroy(vlg_workspace* ws);
  *   index_sasearch.hpp:58-118) and `sdsl::locate(idx, query)` (include/sdsl/vlg_index.hpp:395-401).
  * Matches are the left-most, lazy, non-overlapping tuples of SURVEY.md Appendix C, bit-exact. */
 vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result** out);
+
+/* K5 on its own: the gap-bounded merge join of benchmark/gapped-matching/include/index_sasearch.hpp:85-116 (semantics of
+ * vlg_iterator, include/sdsl/vlg_index.hpp:227-291) over caller-provided occurrence lists in HBM.
+ *   d_lists      all lists concatenated, u64 positions, every list ascending (what std::sort leaves, index_sasearch.hpp:80);
+ *                a position may not exceed 2^63
+ *   h_list_off   [n_lists+1] element offsets of the lists inside d_lists
+ *   h_join_list  [n_joins+1] join j uses the lists [h_join_list[j], h_join_list[j+1]) as its sub-patterns 0..k-1 (a list may
+ *                not be shared between joins here: pass it twice); k <= VLG_MAX_SUBPATTERNS
+ *   h_lo, h_hi   [n_lists] start-to-start distance bounds between a list and the previous one of its join (the entry of a
+ *                join's first list is ignored); lo <= hi < 2^63
+ *   h_end_len    [n_joins] length added to the last position of a match for the non-overlap rule (|s_{k-1}| for the library,
+ *                |s_0| for index_sasearch.hpp:113)
+ * The result is read like a search result: counts / offsets / first positions / tuples per join.  A join with an empty list
+ * has no match (vlg_index.hpp:315-316).  Uses the workspace's window filter and chunking like vlg_search_batch. */
+vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_list_off, uint64_t n_lists, const uint64_t* h_join_list,
+                          const uint64_t* h_lo, const uint64_t* h_hi, const uint64_t* h_end_len, uint64_t n_joins,
+                          vlg_workspace* ws, vlg_result** out);
 
 typedef struct {
     uint64_t n_queries;

@@ -33,7 +33,7 @@ def _worker(rank, world, port, text, queries, weights, out_q):
         for q in qs:
             t = idx.search(q, stats=st)
             counts.append(len(t))
-            chk = (chk + int(t[:, 0].sum())) % (1 << 63) if len(t) else chk
+            chk = (chk + int(t[:, 0].sum())) % (1 << 64) if len(t) else chk
         return counts, chk, int(st[0])
 
     r = vdist.run_sharded(search_fn, queries, dist, weights)
@@ -58,7 +58,7 @@ def test_two_ranks_equal_one(oracle, by_work):
     st = np.zeros(4, dtype=np.uint64)
     ref = [idx.search(q, stats=st) for q in queries]
     want_counts = [len(t) for t in ref]
-    want_chk = sum(int(t[:, 0].sum()) for t in ref if len(t)) % (1 << 63)
+    want_chk = sum(int(t[:, 0].sum()) for t in ref if len(t)) % (1 << 64)
     weights = None
     if by_work:
         weights = [sum(idx.backward_search(s)[0] for s in oracle.query_fields(oracle.parse(q))[0]) for q in queries]
@@ -89,3 +89,21 @@ def test_shard_bounds_cover_exactly():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(e - b for b, e in parts) - min(e - b for b, e in parts) <= 1
+
+
+def test_shard_by_work_takes_the_nearer_cut():
+    from vlg_matching_amd import dist as vdist
+    assert vdist.shard_by_work([10, 0, 0, 0], 2) == [(0, 1), (1, 4)]          # the heavy head goes to rank 0, not past it
+    assert vdist.shard_by_work([1, 1, 1, 1], 2) == [(0, 2), (2, 4)]
+    assert vdist.shard_by_work([0, 0, 0, 10], 2)[0][1] in (3, 4)
+    for w, world in (([5, 1, 1, 1, 5], 3), ([1] * 7, 8), ([3, 0, 0, 9, 1, 1, 7, 2], 4)):
+        parts = vdist.shard_by_work(w, world)
+        assert parts[0][0] == 0 and parts[-1][1] == len(w) and all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+
+
+def test_checksum_reduction_is_modulo_2_64():
+    from vlg_matching_amd import dist as vdist
+    big = (1 << 64) - 5
+    assert vdist.reduce_checksum(big) == big                                  # single rank: unchanged, no 2^63 folding
+    r = vdist.run_sharded(lambda qs: ([1] * len(qs), big, 7), ["a", "b", "c"])
+    assert r["checksum"] == big and r["num_results"] == 3 and r["located"] == 7

@@ -84,15 +84,34 @@ def test_c2_sample_equals_oracle(c2, oracle):
         assert o.sa(i) == sa
 
 
+def _check_device_suffix_array(text, sa, rng, samples=20000):
+    """The suffix array the SASEARCH restatement runs on comes from the device sorter: it must be a permutation of [0, n] whose
+    neighbouring suffixes ascend (sampled; csa_byte_test.cpp:136-147 checks csa[j] == SA[j] the same way)."""
+    n = len(text) + 1
+    assert len(sa) == n and int(sa[0]) == n - 1                              # the sentinel suffix sorts first
+    seen = np.zeros(n, dtype=bool)
+    seen[sa] = True
+    assert seen.all()
+    del seen
+    for i in rng.integers(1, n - 1, samples):
+        a, b = int(sa[i]), int(sa[i + 1])
+        x, y = text[a: a + 96].tobytes(), text[b: b + 96].tobytes()          # a proper prefix (suffix at the text end) sorts first
+        assert x < y or (x == y and len(x) == 96), (i, a, b)
+
+
 def test_c3_headline_config_modes_and_oracle_sample(oracle):
     """The headline workload (1 GiB english-like text, 100 000 x 3 sub-patterns, gap <= 1000) at full size."""
+    import torch
     import vlg_matching_amd as V
     from vlg_matching_amd import workload
     from vlg_matching_amd.index import Queries, Workspace
     cfg = workload.config("C3")
     text = workload.gen_text(cfg["kind"], cfg["n"], cfg["seed"])
     idx = V.VlgIndex.build(text)
-    queries = workload.gen_queries(text, cfg["nq"], cfg["k"], cfg["m"], cfg["gap"], cfg["qseed"])
+    parts = workload.gen_query_parts(text, cfg["nq"], cfg["k"], cfg["m"], cfg["qseed"])
+    g = ".{%d,%d}?" % cfg["gap"]
+    queries = [g.join(sp.decode("latin-1") for sp in subs) for subs in parts]
+    assert queries == workload.gen_queries(text, cfg["nq"], cfg["k"], cfg["m"], cfg["gap"], cfg["qseed"])
     q = Queries(queries)
     ws = Workspace(100 << 30)
     a = idx.search(q, workspace=ws)
@@ -110,24 +129,139 @@ def test_c3_headline_config_modes_and_oracle_sample(oracle):
         assert c.summary[k] == b.summary[k] and sa[k] * 4 < b.summary[k], k     # shared trails: a fraction of the LF steps
     counts = a.counts
     assert (counts == b.counts).all() and (counts == c.counts).all()
+    del b, c
     kst = ws.kernel_stats()
     assert kst["filter_compact"]["launches"] > 0
-    # bounded oracle sample: light queries only (a heavy one costs minutes on one core)
-    o = oracle.Index.from_parts(idx.export_parts())
+    # ---- structural properties of EVERY match of the batch (as C2 has them) ----------------------------------------------
+    _, offsets, first, tuples = a.fetch()
+    m = cfg["m"]
+    t = tuples.reshape(-1, cfg["k"])
+    assert len(t) == sa["n_matches"] and (t[:, 0] == first).all()
+    for i in range(1, cfg["k"]):
+        d = t[:, i] - t[:, i - 1]                                            # uint64: a negative distance wraps and fails the bound
+        assert int(d.min()) >= m + cfg["gap"][0] and int(d.max()) <= m + cfg["gap"][1]
+    ok = t[1:, 0] >= t[:-1, -1] + np.uint64(m)                               # non-overlapping, left to right, inside every query
+    bnd = offsets[1:-1].astype(np.int64)
+    ok[bnd[(bnd >= 1) & (bnd <= len(t) - 1)] - 1] = True                      # pairs that straddle two queries
+    assert ok.all()
+    del ok, d
+    assert int(first.sum(dtype=np.uint64)) == sa["checksum"]
     rng = np.random.default_rng(5)
+    for mi in rng.integers(0, len(t), 5000):                                # reported positions are real occurrences
+        qi = int(np.searchsorted(offsets, np.uint64(mi), side="right")) - 1
+        for i in range(cfg["k"]):
+            p0 = int(t[mi, i])
+            assert text[p0: p0 + m].tobytes() == parts[qi][i]
+    # ---- oracle: light queries through the FM-index restatement -----------------------------------------------------------
+    o = oracle.Index.from_parts(idx.export_parts())
     done = 0
     for qi in rng.permutation(cfg["nq"]):
         subs, _, _, _ = oracle.query_fields(oracle.parse(queries[qi]))
-        occ = [o.backward_search(s)[0] for s in subs]
+        occ = [o.backward_search(sp)[0] for sp in subs]
         if min(occ) == 0 or sum(occ) > 20000:
             continue
         want = o.search(queries[qi])
-        assert int(counts[qi]) == len(want)
-        assert (a.positions(int(qi)) == want[:, 0]).all() if len(want) else True
+        assert a.tuples(int(qi)).tolist() == want.tolist()
         done += 1
         if done >= 40:
             break
     assert done >= 20
+    del o
+    # ---- oracle: HEAVY queries (the ones that make up the step) through the SASEARCH restatement (index_sasearch.hpp: text + plain
+    #      suffix array, forward_search, sort, the same merge join), on the suffix array of the device sorter --------------------
+    occ_sub, _ = idx.occurrences(q)
+    occ_q = occ_sub.reshape(-1, cfg["k"]).astype(np.int64)
+    assert (occ_q.sum(axis=1)[occ_q.min(axis=1) > 0]).sum() == sa["logical_occurrences"]
+    d_text = torch.from_numpy(text).cuda()
+    d_sa = torch.empty(len(text) + 1, dtype=torch.int32, device="cuda")
+    V.capi.check(V.lib().vlg_suffix_array_device(d_text.data_ptr(), len(text), d_sa.data_ptr(), None))
+    torch.cuda.synchronize()
+    sarr = d_sa.cpu().numpy().view(np.uint32)
+    del d_text, d_sa
+    torch.cuda.empty_cache()
+    _check_device_suffix_array(text, sarr, rng)
+    sas = oracle.SaSearch(np.concatenate([text, np.zeros(1, dtype=np.uint8)]), sarr)
+    heavy = [int(qi) for qi in rng.permutation(cfg["nq"]) if occ_q[qi].min() > 0 and 100000 < occ_q[qi].sum() <= 4000000][:220]
+    assert len(heavy) >= 200
+    n_heavy_matches = 0
+    for qi in heavy:
+        for i in range(cfg["k"]):
+            assert sas.count(parts[qi][i]) == occ_q[qi, i]                   # forward_search on the SA == backward_search on the FM-index
+        want = sas.search(queries[qi])
+        assert int(counts[qi]) == len(want)
+        assert a.tuples(qi).tolist() == want.tolist(), queries[qi]
+        n_heavy_matches += len(want)
+    assert n_heavy_matches > 10000
+
+
+def test_c5_one_gib_dna_rrr_full_size(oracle):
+    """BASELINE config 5 at full size: 2^30 DNA-like characters, csa_wt<wt_huff<rrr_vector<63>>>-equivalent index,
+    100 000 queries x k=2, m=12, gap <= 100."""
+    import vlg_matching_amd as V
+    from vlg_matching_amd import workload
+    from vlg_matching_amd.index import Queries, Workspace
+    cfg = workload.config("C5")
+    text = workload.gen_text(cfg["kind"], cfg["n"], cfg["seed"])
+    plain = V.VlgIndex.build(text)
+    rrr = plain.compress()
+    ip, ir = plain.info(), rrr.info()
+    assert ir["bv_kind"] == 1 and ip["bv_kind"] == 0 and ir["n"] == ip["n"] == cfg["n"] + 1
+    parts = workload.gen_query_parts(text, cfg["nq"], cfg["k"], cfg["m"], cfg["qseed"])
+    # the batch of SURVEY.md 8(d) (every 12-mer occurs ~64 times) plus 300 queries on short, frequent sub-patterns so that long
+    # lists, the sorted sweep and the window filter run on the rrr index too
+    heavy_parts = workload.gen_query_parts(text, 300, 2, 6, cfg["qseed"] + 1)
+    g = ".{%d,%d}?" % cfg["gap"]
+    queries = [g.join(sp.decode() for sp in subs) for subs in parts] + [g.join(sp.decode() for sp in subs) for subs in heavy_parts]
+    parts = parts + heavy_parts
+    q = Queries(queries)
+    ws = Workspace(100 << 30)
+    base = rrr.search(q, workspace=ws)
+    s = base.summary
+    assert s["n_queries"] == len(queries) and s["n_matches"] > 1000 and s["located_occurrences"] > 10 ** 7
+    counts, offsets, first, tuples = base.fetch()
+    # ---- structural properties of every match --------------------------------------------------------------------------------
+    t = tuples.reshape(-1, 2)
+    lens = np.array([len(parts[qi][0]) for qi in range(len(queries))], dtype=np.uint64)
+    len_of_match = np.repeat(lens, counts.astype(np.int64))
+    d = t[:, 1] - t[:, 0] - len_of_match
+    assert int(d.max()) <= cfg["gap"][1]                                     # (uint64: a distance below the minimum wraps to a huge value)
+    ok = t[1:, 0] >= t[:-1, 1] + len_of_match[:-1]
+    bnd = offsets[1:-1].astype(np.int64)
+    ok[bnd[(bnd >= 1) & (bnd <= len(t) - 1)] - 1] = True                      # pairs that straddle two queries
+    assert ok.all()
+    assert int(first.sum(dtype=np.uint64)) == s["checksum"]
+    rng = np.random.default_rng(15)
+    qi_of = np.repeat(np.arange(len(queries)), counts.astype(np.int64))
+    for mi in rng.integers(0, len(t), 4000):
+        subs = parts[qi_of[mi]]
+        for i in range(2):
+            p0 = int(t[mi, i])
+            assert text[p0: p0 + len(subs[i])].tobytes() == subs[i]
+    # ---- identical results: plain index, and the rrr index under every execution strategy -------------------------------------
+    pl = plain.search(q, workspace=ws)
+    assert pl.summary["n_matches"] == s["n_matches"] and pl.summary["checksum"] == s["checksum"]
+    for x, y in zip(pl.fetch(), base.fetch()):
+        assert (x == y).all()
+    for k in ("lf_steps", "wt_levels_locate", "located_occurrences", "wt_levels_bsearch"):
+        assert pl.summary[k] == s[k], k                                      # same walks, only the rank primitive differs
+    del pl
+    for opts in ({"sweep": 0}, {"trail": 0, "filter": 0}, {"dedup": 0}):
+        w2 = Workspace(100 << 30)
+        for k_, v_ in opts.items():
+            w2.set_option(k_, v_)
+        r = rrr.search(q, workspace=w2)
+        assert r.summary["n_matches"] == s["n_matches"] and r.summary["checksum"] == s["checksum"], opts
+        f2 = r.fetch()
+        assert (f2[0] == counts).all() and (f2[3] == tuples).all(), opts
+    # ---- >= 200 sampled queries (and some heavy ones) equal the CPU oracle tuple for tuple -----------------------------------------
+    o = oracle.Index.from_parts(plain.export_parts())
+    sample = list(rng.choice(cfg["nq"], 260, replace=False)) + list(cfg["nq"] + rng.choice(300, 12, replace=False))
+    nonempty = 0
+    for qi in sample:
+        want = o.search(queries[int(qi)])
+        assert base.tuples(int(qi)).tolist() == want.tolist(), queries[int(qi)]
+        nonempty += len(want) > 0
+    assert nonempty >= 5
 
 
 def test_c4_four_gib_text_64bit_positions(oracle):

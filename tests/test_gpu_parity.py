@@ -67,6 +67,12 @@ def test_k1_bitvector_rank(torch_cuda, V, oracle, nbits):
         L.vlgo_rank_v_build(wpad.ctypes.data, nbits, blocks.ctypes.data)
         want = np.array([L.vlgo_rank_v(wpad.ctypes.data, blocks.ctypes.data, int(i)) for i in idx[:3000]], dtype=np.uint64)
         assert (got[:3000] == want).all()
+        # a-4: the same super-block layout replaces rank_support_v5 too (rank_support_v5.hpp:116-134, restated and pinned in the oracle)
+        w5 = np.concatenate([words, np.zeros(40, np.uint64)])
+        blocks5 = np.zeros(2 * ((len(words) >> 5) + 1) + 8, dtype=np.uint64)
+        L.vlgo_rank_v5_build(w5.ctypes.data, nbits, blocks5.ctypes.data)
+        want5 = np.array([L.vlgo_rank_v5(w5.ctypes.data, blocks5.ctypes.data, int(i)) for i in idx[:3000]], dtype=np.uint64)
+        assert (got[:3000] == want5).all()
         truth = np.concatenate([[0], np.cumsum(bits)])[idx.astype(np.int64)]
         assert (got == truth).all()
 
@@ -369,6 +375,12 @@ def test_cpp_driver_pipeline_matches_oracle(V, oracle, tmp_path):
     out1 = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt"), "-1"], check=True, capture_output=True, text=True).stdout
     kv1 = dict(l[2:].split(" = ") for l in out1.splitlines() if l.startswith("# ") and " = " in l)
     assert kv1["num_results"] == kv["num_results"] and kv1["checksum"] == kv["checksum"]
+    # -g N: the pattern file sharded over N device slices (index replicated by a peer copy, slices cut by work, one host thread
+    # each; on a one-GPU box the slices share the device, which still runs replicate + shard + merge)
+    for g in ("2", "3"):
+        outg = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt"), "-g", g], check=True, capture_output=True, text=True).stdout
+        kvg = dict(l[2:].split(" = ") for l in outg.splitlines() if l.startswith("# ") and " = " in l)
+        assert kvg["num_results"] == kv["num_results"] and kvg["checksum"] == kv["checksum"] and kvg["num_gpus"] == g
 
 
 @pytest.mark.parametrize("name,seed,tail", [("dna_50k", 71, 16), ("zipf40", 72, 1), ("100a", 73, 4), ("dna_skew", 74, 1000), ("abracadabra", 75, 1)])
@@ -737,3 +749,184 @@ def test_strategy_fuzz_short(V, monkeypatch, capsys):
     monkeypatch.setattr(sys, "argv", ["fuzz_strategies.py", "8", "20261003"])
     mod.main()
     assert "fuzz ok" in capsys.readouterr().out
+
+
+# ---- K5 on its own: vlg_join_batch on caller-made lists vs the oracle's merge join (index_sasearch.hpp:85-116) ---------------
+def _random_join_case(rng, k, sizes, span, gapmax, dense=False):
+    lists = []
+    for i in range(k):
+        n = int(sizes[i])
+        if n == 0:
+            lists.append(np.zeros(0, np.uint64))
+        elif dense:
+            lists.append(np.sort(rng.integers(0, span, n)).astype(np.uint64))            # duplicates allowed: ascending, not strictly
+        else:
+            lists.append(np.sort(rng.choice(span, size=min(n, span), replace=False)).astype(np.uint64))
+    lo = [int(rng.integers(0, gapmax // 2 + 1)) for _ in range(k - 1)]
+    hi = [l + int(rng.integers(0, gapmax + 1)) for l in lo]
+    return lists, lo, hi, int(rng.integers(1, 9))
+
+
+def _run_join_batch(torch, V, cases, ws):
+    from vlg_matching_amd.index import join_batch
+    flat, list_off, join_list, lo, hi, end_len = [], [0], [0], [], [], []
+    for lists, l, h, e in cases:
+        for i, a in enumerate(lists):
+            flat.append(a)
+            list_off.append(list_off[-1] + len(a))
+            lo.append(0 if i == 0 else l[i - 1])
+            hi.append(0 if i == 0 else h[i - 1])
+        join_list.append(len(list_off) - 1)
+        end_len.append(e)
+    allv = np.concatenate(flat) if flat else np.zeros(0, np.uint64)
+    d = dev_u64(torch, allv if len(allv) else np.zeros(1, np.uint64))
+    return join_batch(d.data_ptr(), list_off, join_list, lo, hi, end_len, ws)
+
+
+@pytest.mark.parametrize("filt", [1, 0])
+def test_join_batch_vs_oracle_join(torch_cuda, V, oracle, filt):
+    from vlg_matching_amd.index import Workspace
+    rng = np.random.default_rng(2024 + filt)
+    cases = []
+    # lists longer than one tile (1024) and one run (2048); k = 1; empty lists in every place; k up to 8; wide and zero gaps
+    cases.append(_random_join_case(rng, 1, [5000], 40000, 10))
+    cases.append(_random_join_case(rng, 2, [7000, 9000], 100000, 30))
+    cases.append(_random_join_case(rng, 3, [300, 20000, 4000], 200000, 500))               # a short pivot list between long ones
+    cases.append(_random_join_case(rng, 3, [20000, 15000, 200], 200000, 300))
+    cases.append(_random_join_case(rng, 2, [0, 50], 1000, 10))
+    cases.append(_random_join_case(rng, 2, [50, 0], 1000, 10))
+    cases.append(_random_join_case(rng, 3, [40, 0, 40], 1000, 10))
+    cases.append(_random_join_case(rng, 1, [0], 1000, 10))
+    cases.append(_random_join_case(rng, 8, [900] * 8, 30000, 60))
+    cases.append(_random_join_case(rng, 5, [3000, 50, 3000, 50, 3000], 60000, 200))
+    cases.append(_random_join_case(rng, 2, [6000, 6000], 8000, 3, dense=True))             # duplicates inside a list
+    cases.append(([np.arange(0, 50000, 5, dtype=np.uint64), np.arange(2, 50000, 5, dtype=np.uint64)], [2], [2], 1))    # every element matches
+    cases.append(([np.array([5, 1 << 40, (1 << 62) + 3], np.uint64), np.array([9, (1 << 40) + 7, (1 << 62) + 4], np.uint64)], [1], [10], 3))
+    for _ in range(40):
+        k = int(rng.integers(1, 6))
+        cases.append(_random_join_case(rng, k, rng.integers(0, 400, k), 5000, 80))
+    ws = Workspace()
+    ws.set_option("filter", filt)
+    ws.set_option("filter_min", 0)
+    ws.set_option("filter_stream_min", 0)
+    res = _run_join_batch(torch_cuda, V, cases, ws)
+    total, chk = 0, 0
+    for j, (lists, lo, hi, e) in enumerate(cases):
+        m, want = oracle.join(lists, lo, hi, e)
+        assert int(res.counts[j]) == m, j
+        assert res.tuples(j).tolist() == want.tolist(), j
+        assert res.positions(j).tolist() == want[:, 0].tolist() if m else len(res.positions(j)) == 0
+        total += m
+        chk = (chk + int(want[:, 0].sum())) % (1 << 64) if m else chk
+    assert res.summary["n_matches"] == total and res.summary["checksum"] == chk
+    # first positions only
+    ws.set_option("tuples", 0)
+    res2 = _run_join_batch(torch_cuda, V, cases, ws)
+    assert (res2.counts == res.counts).all() and res2.summary["checksum"] == chk and res2.summary["n_tuple_values"] == 0
+
+
+def test_join_batch_rejects_bad_input_and_chunks(torch_cuda, V, oracle):
+    from vlg_matching_amd.index import Workspace, join_batch
+    from vlg_matching_amd.capi import VlgError
+    torch = torch_cuda
+    ws = Workspace()
+    d = dev_u64(torch, np.array([5, 3, 9, 1, 2, 3], np.uint64))
+    with pytest.raises(VlgError):                                          # first list not ascending
+        join_batch(d.data_ptr(), [0, 3, 6], [0, 2], [0, 0], [0, 5], [1], ws)
+    d = dev_u64(torch, np.array([1, 3, 9, 1, 2, 3], np.uint64))
+    with pytest.raises(VlgError):                                          # lo > hi
+        join_batch(d.data_ptr(), [0, 3, 6], [0, 2], [0, 7], [0, 5], [1], ws)
+    with pytest.raises(VlgError):                                          # end_len 0: the reference's loop would not advance
+        join_batch(d.data_ptr(), [0, 3, 6], [0, 2], [0, 0], [0, 5], [0], ws)
+    r = join_batch(d.data_ptr(), [0, 3, 6], [0, 2], [0, 0], [0, 5], [1], ws)
+    m, want = oracle.join([np.array([1, 3, 9]), np.array([1, 2, 3])], [0], [5], 1)
+    assert r.tuples(0).tolist() == want.tolist()
+    # a small workspace cap: many chunks, same answers
+    rng = np.random.default_rng(77)
+    cases = [_random_join_case(rng, int(rng.integers(1, 4)), rng.integers(1000, 30000, 3), 400000, 300) for _ in range(60)]
+    big = _run_join_batch(torch, V, cases, Workspace())
+    small_ws = Workspace(40 << 20)
+    small = _run_join_batch(torch, V, cases, small_ws)
+    assert small.summary["n_chunks"] > big.summary["n_chunks"]
+    for x, y in zip(big.fetch(), small.fetch()):
+        assert (x == y).all()
+    for j in (0, 7, 33, 59):
+        lists, lo, hi, e = cases[j]
+        assert big.tuples(j).tolist() == oracle.join(lists, lo, hi, e)[1].tolist()
+
+
+def test_queries_occurrences_equal_oracle_counts(V, oracle):
+    text = TEXTS["dna_50k"]()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    rng = np.random.default_rng(8)
+    qs = random_queries(text, rng, 200) + ["\xfe.{0,3}?A"]
+    occ, q = idx.occurrences(qs)
+    want = []
+    for qq in qs:
+        subs, _, _, _ = oracle.query_fields(oracle.parse(qq))
+        want += [o.backward_search(sp)[0] for sp in subs]
+    assert occ.tolist() == want
+    w = idx.query_weights(qs)
+    assert len(w) == len(qs) and w[-1] == 1.0 and (w >= 1.0).all()
+
+
+# ---- multi-GPU path rehearsed on one device: 2 gloo ranks on cuda:0 --------------------------------------------------------
+def _replica_worker(rank, world, port, text, queries, out_q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import vlg_matching_amd as V
+    from vlg_matching_amd import dist as vdist
+    dev = torch.device("cuda", 0)
+    idx = V.VlgIndex.build(text) if rank == 0 else None
+    # gloo moves CUDA tensors through the host: the calls are the ones the RCCL path makes (broadcast of the blob, attach)
+    idx = vdist.replicate_index(idx, dist, dev, src=0)
+    w = idx.query_weights(queries)                                       # every rank can weigh the batch: the index is replicated
+    b, e = vdist.shard_by_work(w, world)[rank]
+    r = idx.search(queries[b:e])
+    tot = torch.tensor([r.summary["n_matches"], r.summary["located_occurrences"]], dtype=torch.int64)
+    dist.all_reduce(tot)
+    chk = vdist.reduce_checksum(r.summary["checksum"], dist)
+    out_q.put((rank, b, e, [int(c) for c in r.counts], int(tot[0]), chk, idx.info()["hbm_bytes"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicate_index_two_ranks_on_one_device(V, oracle):
+    """SURVEY.md 8(e) on one GPU: rank 0 builds, the blob is broadcast, rank 1 attaches; the batch is sharded by work;
+    totals equal the 1-rank run and the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    text = dna_text(60000, 9).tobytes()
+    rng = np.random.default_rng(19)
+    queries = random_queries(text, rng, 300, kmax=3, mmax=4)
+    one = V.VlgIndex.build(text).search(queries)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, text, queries, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(out_q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][1] == 0 and got[0][2] == got[1][1] and got[1][2] == len(queries)
+    assert got[0][3] + got[1][3] == [int(c) for c in one.counts]
+    for g in got:
+        assert g[4] == one.summary["n_matches"] and g[5] == one.summary["checksum"]
+    assert got[0][6] == got[1][6]
+    o = oracle.Index.from_text(text)
+    for i in (0, 10, 150, 299):
+        assert int(one.counts[i]) == len(o.search(queries[i]))

@@ -11,10 +11,14 @@ from util import (bwt_from_sa, dna_text, naive_occurrences, naive_sa, reference_
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "vlg_known_answers.json")
 CASES = json.load(open(GOLD))["cases"]
 
-# the reference's own tiny fixtures (test/test_cases/*.txt), restated as data
+# Small texts.  The first three are exactly the bytes of the reference's test/test_cases/{one_byte,100a,example01}.txt (data, not
+# code).  The others are this repo's own: the reference's abc_abc_abc.txt (b"abc\0abc\0abc\n") and all_symbols.txt (bytes 0..255)
+# contain zero bytes, which a csa text may not (construct.hpp:36-45), so "abc_abc_abc" and "all_symbols" here are variants
+# without them, and "abracadabra" is the text of examples/vlg_matching.cpp:31.
 FIXTURE_TEXTS = {
     "one_byte": b"a",
     "100a": b"a" * 100,
+    "example01": b"mississippi\n",
     "abc_abc_abc": b"abc abc abc",
     "all_symbols": bytes(range(1, 256)),
     "abracadabra": b"abracadabrasimsalabim",

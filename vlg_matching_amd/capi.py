@@ -76,6 +76,7 @@ SYMBOLS = [
     ("vlg_index_blob_bytes", _I, [_P, C.POINTER(_U64)]),
     ("vlg_index_blob_export", _I, [_P, _P, _U64, _P]),
     ("vlg_index_attach_blob", _I, [_P, _U64, C.POINTER(_P)]),
+    ("vlg_index_replicate", _I, [_P, _I, C.POINTER(_P)]),
     ("vlg_bitvector_create", _I, [_P, _U64, C.POINTER(_P)]),
     ("vlg_bitvector_rank_batch", _I, [_P, _P, _P, _U64, _P]),
     ("vlg_bitvector_hbm_bytes", _U64, [_P]),
@@ -91,6 +92,7 @@ SYMBOLS = [
     ("vlg_parse_query", _I, [C.c_char_p, _U64, _I, C.POINTER(ParsedQuery)]),
     ("vlg_queries_parse", _I, [C.c_char_p, _P, _U64, _I, _P, C.POINTER(_P)]),
     ("vlg_queries_create", _I, [_P, _P, _P, _P, _P, _P, _U64, C.POINTER(_P)]),
+    ("vlg_queries_occurrences", _I, [_P, _P, _P, _P]),
     ("vlg_queries_count", _U64, [_P]),
     ("vlg_queries_subpatterns", _U64, [_P]),
     ("vlg_queries_k", _I, [_P, _P]),
@@ -98,6 +100,7 @@ SYMBOLS = [
     ("vlg_workspace_create", _I, [_U64, _P, C.POINTER(_P)]),
     ("vlg_workspace_destroy", None, [_P]),
     ("vlg_search_batch", _I, [_P, _P, _P, C.POINTER(_P)]),
+    ("vlg_join_batch", _I, [_P, _P, _U64, _P, _P, _P, _P, _U64, _P, C.POINTER(_P)]),
     ("vlg_result_summary_get", _I, [_P, C.POINTER(ResultSummary)]),
     ("vlg_result_fetch", _I, [_P, _P, _P, _P, _P]),
     ("vlg_result_destroy", None, [_P]),

@@ -586,12 +586,13 @@ inline uint64_t filter_bytes(const vlg_queries* q, const Plan& pl, const vlg_wor
 }
 
 template <typename pos_t>
-vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, const Plan& pl, const std::vector<uint32_t>& poff,
-                        const pos_t* P, Arena& A /* advanced past the state the join chunks still need */, FilterGroup& fg)
+vlg_status filter_group(uint64_t n_positions /* every list element is smaller */, const vlg_queries* q, vlg_workspace* ws, const Plan& pl,
+                        const std::vector<uint32_t>& poff /* per sub-pattern: its list inside P */, const pos_t* P,
+                        Arena& A /* advanced past the state the join chunks still need */, FilterGroup& fg)
 {
     hipStream_t st = ws->stream;
-    const uint32_t g = filter_block_shift(idx->hdr.n);
-    const uint64_t nblocks = (idx->hdr.n >> g) + 1, nbw = (nblocks + 63) / 64;
+    const uint32_t g = filter_block_shift(n_positions);
+    const uint64_t nblocks = (n_positions >> g) + 1, nbw = (nblocks + 63) / 64;
     const uint64_t nsub = q->qsub[fg.g1] - q->qsub[fg.g0];
     fg.sub0 = q->qsub[fg.g0];
     fg.eff.resize(nsub);
@@ -621,7 +622,7 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
         for (uint32_t i = 0; i < k; ++i) {
             RSeg r;
             memset(&r, 0, sizeof r);
-            r.pbegin = poff[pl.did[s0 + i]];
+            r.pbegin = poff[s0 + i];
             r.pend = r.pbegin + (uint32_t)pl.occ[s0 + i];
             r.lo = q->lo[s0 + i]; r.hi = q->hi[s0 + i];
             if (i + 1 < k) { r.nlo = q->lo[s0 + i + 1]; r.nhi = q->hi[s0 + i + 1]; }
@@ -673,7 +674,7 @@ vlg_status filter_group(const vlg_index* idx, const vlg_queries* q, vlg_workspac
     uint64_t* d_task_run0 = A.take<uint64_t>(segs.size() + 1);
     PTask* d_ptasks = A.take<PTask>(ptasks.size() + 1);
     uint64_t* d_prun0 = A.take<uint64_t>(prun0.size());
-    if (!d_prun0 || !d_bm) return fail(VLG_E_INTERNAL, "arena carve failed (filter)");
+    if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (filter)");
     VLG_HIP_TRY(hipMemsetAsync(fg.d_abits, 0, (abit / 64 + 1) * 8, st));
     VLG_HIP_TRY(hipMemcpyAsync(fg.d_segs, segs.data(), segs.size() * sizeof(RSeg), hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(fg.d_cseg, cseg.data(), cseg.size() * 4, hipMemcpyHostToDevice, st));

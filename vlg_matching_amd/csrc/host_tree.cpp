@@ -81,9 +81,29 @@ static vlg_status finish_tree(HostTree& t)
         if (nd.child[0] == 0xFFFF) {
             t.c_to_leaf[(uint8_t)nd.bv_pos_rank] = (uint16_t)v;
             t.max_code_len = std::max(t.max_code_len, t.node_depth[v]);
-        } else if (nd.child[0] >= nn || nd.child[1] >= nn) {
-            return fail(VLG_E_INVALID, "child index out of range");
+        } else {
+            // children are appended behind their parent in BFS order (wt_helper.hpp:170-206); anything else (a cycle in a damaged
+            // file) would make the device tree walks spin
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t ch = nd.child[k];
+                if (ch >= nn || ch <= v || t.nodes[ch].parent != v) return fail(VLG_E_INVALID, "child index out of range or not in BFS order");
+            }
         }
+    }
+    // Super-block counts and block_rank() are 32-bit: the 1-bits of an inner node (= the size of its right child) must stay
+    // below 2^32.  Holds for every text of up to 2^32 - 1 bytes; beyond that it depends on the symbol statistics.
+    for (uint32_t v = 0; v < nn; ++v) {
+        const vlg_wt_node& nd = t.nodes[v];
+        if (nd.child[0] == 0xFFFF) continue;
+        const uint32_t c1 = nd.child[1];
+        uint64_t ones;
+        if (t.nodes[c1].child[0] != 0xFFFF) ones = t.node_size[c1];
+        else {
+            const uint32_t comp = t.char2comp[(uint8_t)t.nodes[c1].bv_pos_rank];
+            ones = comp + 1 < t.C.size() ? t.C[comp + 1] - t.C[comp] : 0;
+        }
+        if (ones > 0xFFFFFFFFull || t.node_size[v] > (1ull << 36))
+            return fail(VLG_E_UNSUPPORTED, "a wavelet-tree node holds 2^32 or more 1-bits: the 32-bit node-relative block counts cannot index it");
     }
     // m_path: wt_helper.hpp:219-240
     uint64_t prev_c = 0;

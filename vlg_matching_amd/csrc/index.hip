@@ -412,6 +412,37 @@ extern "C" vlg_status vlg_index_blob_export(const vlg_index* idx, void* d_blob, 
     return VLG_OK;
 }
 
+// One process driving several GPUs (the C++ host's -g N): a second copy of the read-only index on another device of the node,
+// moved by a peer copy (xGMI between the GPUs of one node).  One process per GPU uses export / RCCL broadcast / attach instead.
+extern "C" vlg_status vlg_index_replicate(const vlg_index* src, int device, vlg_index** out)
+{
+    if (!src || !out) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = 0, cur = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VLG_E_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(VLG_E_INVALID, "no such device");
+    VLG_HIP_TRY(hipGetDevice(&cur));
+    hipPointerAttribute_t at;
+    VLG_HIP_TRY(hipPointerGetAttributes(&at, src->d_blob));
+    void* d = nullptr;
+    vlg_index* idx = nullptr;
+    auto run = [&]() -> vlg_status {
+        VLG_HIP_TRY(hipSetDevice(device));
+        VLG_HIP_TRY(hipMalloc(&d, src->hdr.total_bytes));
+        VLG_HIP_TRY(hipMemcpyPeer(d, device, src->d_blob, at.device, src->hdr.total_bytes));
+        VLG_HIP_TRY(hipDeviceSynchronize());
+        if (vlg_status st = vlg_index_attach_blob(d, src->hdr.total_bytes, &idx)) return st;
+        idx->owns_blob = true;
+        return VLG_OK;
+    };
+    vlg_status st = run();
+    if (st && d && !idx) (void)hipFree(d);
+    (void)hipSetDevice(cur);
+    if (st) return st;
+    *out = idx;
+    return VLG_OK;
+}
+
 extern "C" vlg_status vlg_index_attach_blob(const void* d_blob, uint64_t bytes, vlg_index** out)
 {
     if (!d_blob || !out) return fail(VLG_E_INVALID, "null argument");

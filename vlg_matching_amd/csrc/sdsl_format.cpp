@@ -10,6 +10,7 @@
 // Host-only: nothing here touches the GPU.
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include "common.hpp"
@@ -34,14 +35,16 @@ struct Cursor {
     {
         bits = get<uint64_t>();
         width = fixed_width ? fixed_width : get<uint8_t>();
+        if (bits > 8 * (uint64_t)(e - p) || width > 64) { ok = false; return nullptr; }      // also keeps (bits + 63) from wrapping
         return take(((bits + 63) / 64) * 8);
     }
     void skip_int_vector(uint8_t fixed_width) { uint64_t b; uint8_t w; (void)int_vector(fixed_width, b, w); }
     void skip_select_mcl()
     {
         uint64_t arg_cnt = get<uint64_t>();
-        uint64_t sb = (arg_cnt + 4095) >> 12;
         if (!arg_cnt) return;
+        if (arg_cnt > 8 * (uint64_t)(e - p) * 4096) { ok = false; return; }                  // every super-block takes at least a header
+        uint64_t sb = (arg_cnt + 4095) >> 12;
         skip_int_vector(0);                                  // m_superblock
         uint64_t bits; uint8_t w;
         const uint8_t* mol = int_vector(1, bits, w);         // mini_or_long (possibly empty)
@@ -62,21 +65,21 @@ uint64_t read_packed(const uint8_t* words, uint64_t idx, uint8_t width)
 
 }  // namespace
 
-extern "C" vlg_status vlg_sdsl_file_open(const char* path, uint32_t sa_sample_dens, vlg_sdsl_file** out)
+static vlg_status sdsl_file_open_impl(const char* path, uint32_t sa_sample_dens, vlg_sdsl_file** out)
 {
     using namespace vlg;
-    if (!path || !out) return fail(VLG_E_INVALID, "null argument");
-    *out = nullptr;
     FILE* fp = fopen(path, "rb");
     if (!fp) return fail(VLG_E_INVALID, std::string("cannot open ") + path);
-    vlg_sdsl_file* f = new vlg_sdsl_file();
+    std::unique_ptr<FILE, int (*)(FILE*)> fp_guard(fp, fclose);
+    std::unique_ptr<vlg_sdsl_file> holder(new vlg_sdsl_file());
+    vlg_sdsl_file* f = holder.get();
     fseek(fp, 0, SEEK_END);
     long sz = ftell(fp);
     fseek(fp, 0, SEEK_SET);
     f->raw.resize(sz > 0 ? (size_t)sz : 0);
     size_t got = f->raw.empty() ? 0 : fread(f->raw.data(), 1, f->raw.size(), fp);
-    fclose(fp);
-    auto bad = [&](const char* what) { delete f; return fail(VLG_E_INVALID, std::string("not a csa_wt<wt_huff<>> file (") + what + ")"); };
+    fp_guard.reset();
+    auto bad = [&](const char* what) { return fail(VLG_E_INVALID, std::string("not a csa_wt<wt_huff<>> file (") + what + ")"); };
     if (got != f->raw.size()) return bad("short read");
     Cursor c{f->raw.data(), f->raw.data() + f->raw.size()};
     // ---- wavelet tree (wt_pc.hpp:638-652) -----------------------------------------------------------
@@ -129,8 +132,19 @@ extern "C" vlg_status vlg_sdsl_file_open(const char* path, uint32_t sa_sample_de
     // density: t_dens is a template parameter, not stored; n_samples = ceil(n / dens) must hold for the given value
     f->dens = sa_sample_dens ? sa_sample_dens : 32;
     if (f->n_samples != (f->n + f->dens - 1) / f->dens) return bad("SA sample density does not match the file");
-    *out = f;
+    *out = holder.release();
     return VLG_OK;
+}
+
+// No exception may cross the C boundary: a damaged file that asks for absurd sizes ends as a status, not std::terminate.
+extern "C" vlg_status vlg_sdsl_file_open(const char* path, uint32_t sa_sample_dens, vlg_sdsl_file** out)
+{
+    using namespace vlg;
+    if (!path || !out) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    try { return sdsl_file_open_impl(path, sa_sample_dens, out); }
+    catch (const std::bad_alloc&) { return fail(VLG_E_OOM, "out of host memory while reading the index file"); }
+    catch (const std::exception& e) { return fail(VLG_E_INVALID, std::string("not a csa_wt<wt_huff<>> file (") + e.what() + ")"); }
 }
 
 extern "C" vlg_status vlg_sdsl_file_parts(const vlg_sdsl_file* f, vlg_index_parts* p)

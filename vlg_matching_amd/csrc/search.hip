@@ -359,10 +359,11 @@ inline uint32_t grid_for(uint64_t n, uint32_t cap = 16384) { return (uint32_t)st
 
 struct Arena {
     uint8_t* base; uint64_t size; uint64_t used = 0;
+    bool failed = false;         // sticky: one carve that did not fit poisons the arena, so a check after a block of carves sees it
     template <class T> T* take(uint64_t count)
     {
         uint64_t bytes = align_up(count * sizeof(T), 256);
-        if (used + bytes > size) return nullptr;
+        if (failed || bytes > size || used > size - bytes) { failed = true; return nullptr; }
         T* p = reinterpret_cast<T*>(base + used);
         used += bytes;
         return p;
@@ -445,7 +446,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     uint64_t* d_lh = A.take<uint64_t>(nd);
     unsigned long long* d_counter = A.take<unsigned long long>(1);
     void* d_tmp = A.take<uint8_t>(sort_tmp + 256);
-    if (!d_tmp) return fail(VLG_E_INTERNAL, "arena carve failed (physical)");
+    if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (physical)");
     pos_t* Pb = reinterpret_cast<pos_t*>(scratch);
     VLG_HIP_TRY(hipMemcpyAsync(d_off64, off64.data(), (nd + 1) * 8, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_off32, off32.data(), (nd + 1) * 4, hipMemcpyHostToDevice, st));
@@ -457,7 +458,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         if (share_trails) {                                                       // (trails are shared inside one sweep)
             trail = A.take<uint64_t>(idx->hdr.n);
             rec = A.take<uint64_t>(acc);
-            if (!trail || !rec) return fail(VLG_E_INTERNAL, "arena carve failed (trail table)");
+            if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (trail table)");
         }
         uint64_t* val_a = reinterpret_cast<uint64_t*>(scratch);
         uint64_t* val_b = val_a + cap;
@@ -521,11 +522,11 @@ namespace {
 
 // ---- join of the queries [q0,q1) against the physical lists -------------------------------------------
 template <typename pos_t>
-vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result* res, uint64_t q0, uint64_t q1,
-                          const Plan& pl, const std::vector<uint32_t>& poff, const pos_t* P, Arena A /* by value: scratch past P */,
+vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* res, uint64_t q0, uint64_t q1,
+                          const Plan& pl, const std::vector<uint32_t>& poff /* per sub-pattern: its list inside P */, const pos_t* P,
+                          Arena A /* by value: scratch past P */,
                           unsigned long long* d_stats, const FilterGroup* fg, pos_t* Pc /* survivors of filtered lists go here */)
 {
-    (void)idx;
     hipStream_t st = ws->stream;
     PhaseTrace jt(st);
     // list lengths as the join sees them: the survivors of the window filter where it ran
@@ -576,7 +577,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
         size_t scan_tmp = 0;
         VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tmp, d_cnt, d_off, 0u, runs, rocprim::plus<uint32_t>(), st));
         void* d_scan = A.take<uint8_t>(scan_tmp + 256);
-        if (!d_scan || !d_off) return fail(VLG_E_INTERNAL, "arena carve failed (compaction)");
+        if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (compaction)");
         VLG_HIP_TRY(hipMemcpyAsync(d_tseg, t_seg.data(), t_seg.size() * 4, hipMemcpyHostToDevice, st));
         VLG_HIP_TRY(hipMemcpyAsync(d_tcidx, t_cidx.data(), t_cidx.size() * 4, hipMemcpyHostToDevice, st));
         VLG_HIP_TRY(hipMemcpyAsync(d_trun0, t_run0.data(), t_run0.size() * 8, hipMemcpyHostToDevice, st));
@@ -625,7 +626,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
                 m.pbegin = (uint32_t)((Pc - P) + pc_used);                 // the order of pc_tasks
                 pc_used += eo(s);
             } else {
-                m.pbegin = poff[pl.did[s]];
+                m.pbegin = poff[s];
             }
             m.pend = m.pbegin + (uint32_t)eo(s);
             m.next = (i + 1 < k) ? seg_of_sub[s + 1 - s0] : kNone;
@@ -711,7 +712,7 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     uint32_t* d_recc = A.take<uint32_t>(nq);
     uint32_t* d_recq = A.take<uint32_t>(n_rec + 1);
     uint2* d_rec = A.take<uint2>(n_rec + 1);
-    if (!d_rec || !xh_a || !lvl_ptr[kBitLevels - 1]) return fail(VLG_E_INTERNAL, "arena carve failed (join)");
+    if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (join)");
     VLG_HIP_TRY(hipMemcpyAsync(d_recb, rec_begin.data(), (nq + 1) * 4, hipMemcpyHostToDevice, st));
     if (n_rec) VLG_HIP_TRY(hipMemcpyAsync(d_recq, rec_query.data(), n_rec * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemsetAsync(d_qstart, 0xFF, nq * 4, st));
@@ -796,6 +797,135 @@ vlg_status run_join_chunk(const vlg_index* idx, const vlg_queries* q, vlg_worksp
     return VLG_OK;
 }
 
+// ---- planning and running the joins of the queries [Q0,Q1) over lists that are already in P --------------------------------
+// cost of a query in bytes of join scratch / in join slots, for list lengths given by occ_of(sub-pattern)
+template <class F>
+uint64_t join_bytes_of(const vlg_queries* q, uint64_t qi, F&& occ_of)
+{
+    const bool uniform_k = q->kmin == q->kmax;
+    uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += occ_of(q->qsub[qi] + i);
+    // list-0 arrays cover the slot range of all lists 0, which is exactly those slots when every query has the same k
+    uint64_t t0s = k ? (uniform_k ? occ_of(q->qsub[qi]) : t) : 0;
+    return t * kJoinBytesPerSlot + t0s * kJoinBytesPerSlot0;
+}
+template <class F>
+uint64_t join_slots_of(const vlg_queries* q, uint64_t qi, F&& occ_of)        // slot indices are 32-bit inside a chunk
+{
+    uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
+    uint64_t t = 64ull * k;                                           // class alignment slack
+    for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += occ_of(q->qsub[qi] + i);
+    return t;
+}
+
+struct JoinPlan {
+    std::vector<uint64_t> fbytes;        // per query of [Q0,Q1): bytes of filter state (0 = joined on its full lists)
+    uint64_t group_cap = 0;              // filter state of the queries filtered together
+    uint64_t filter_need = 0;            // arena bytes the filter of one group may take
+    uint64_t want_bytes = 0;             // join scratch of one chunk
+    uint64_t logical_max_query = 0;
+    uint64_t meta = 0;                   // per-chunk metadata on top
+};
+
+// join_budget = arena bytes left behind the lists; n_positions bounds every list element (sizes the block bitmaps of the filter)
+vlg_status plan_joins(const vlg_queries* q, const Plan& pl, const vlg_workspace* ws, uint64_t Q0, uint64_t Q1, uint64_t join_budget,
+                      uint64_t n_positions, JoinPlan& jp)
+{
+    auto full = [&](uint64_t s) -> uint64_t { return pl.occ[s]; };
+    uint64_t logical_total = 0;
+    jp.logical_max_query = 0;
+    for (uint64_t qi = Q0; qi < Q1; ++qi) {
+        uint64_t t = join_bytes_of(q, qi, full);
+        logical_total += t;
+        jp.logical_max_query = std::max(jp.logical_max_query, t);
+    }
+    // window filter: state of the filtered queries of a group (at most a third of the budget), dropped query by query if it
+    // would not leave room for the largest unfiltered join
+    const uint64_t nbw = (((n_positions >> filter_block_shift(n_positions)) + 1) + 63) / 64;
+    jp.group_cap = ws->filter_group_bytes ? std::min<uint64_t>(ws->filter_group_bytes, join_budget / 3) : join_budget / 3;
+    jp.fbytes.assign(Q1 - Q0, 0);
+    uint64_t filter_total = 0;
+    if (ws->filter && jp.logical_max_query + jp.group_cap <= join_budget)
+        for (uint64_t qi = Q0; qi < Q1; ++qi) {
+            uint64_t b = filter_bytes(q, pl, ws, qi, nbw);
+            if (b > jp.group_cap) b = 0;
+            jp.fbytes[qi - Q0] = b;
+            filter_total += b;
+        }
+    uint64_t filter_runs = 0;                                             // runs the compaction of one chunk may have to index
+    for (uint64_t qi = Q0; qi < Q1; ++qi)
+        if (jp.fbytes[qi - Q0]) for (uint64_t s = q->qsub[qi]; s + 1 < q->qsub[qi + 1]; ++s) filter_runs += pl.occ[s] / kRun + 1;
+    jp.filter_need = std::min(filter_total, jp.group_cap) + filter_runs * 8;
+    if (jp.filter_need >= join_budget || jp.logical_max_query > join_budget - jp.filter_need) {
+        // the filter state would not leave room for the largest join: these queries are joined on their full lists
+        std::fill(jp.fbytes.begin(), jp.fbytes.end(), 0);
+        jp.filter_need = 0;
+    }
+    const uint64_t cap_bytes = join_budget - jp.filter_need;
+    if (jp.logical_max_query > cap_bytes)
+        return fail(VLG_E_WORKSPACE, "a query needs " + std::to_string(jp.logical_max_query) + " bytes of join scratch; workspace cap allows " +
+                                         std::to_string(cap_bytes));
+    jp.want_bytes = std::min<uint64_t>(logical_total, cap_bytes);
+    jp.meta = (q->qsub[Q1] - q->qsub[Q0] + 4) * (sizeof(SegMeta) + 48) + (Q1 - Q0 + 4) * (sizeof(QueryMeta) + 96) +
+              (jp.want_bytes / 8192 + (Q1 - Q0) + 8) * 48 + (1ull << 20);
+    return VLG_OK;
+}
+
+// groups of queries that share one run of the filter; join chunks inside a group.  A = arena behind the lists; Pc / pc_cap = where
+// (inside the allocation of P) the survivors of filtered lists may go.
+template <typename pos_t>
+vlg_status run_joins(uint64_t n_positions, const vlg_queries* q, vlg_workspace* ws, vlg_result* res, const Plan& pl,
+                     const std::vector<uint32_t>& poff, const pos_t* P, const Arena& A, pos_t* Pc, uint64_t pc_cap, uint64_t Q0, uint64_t Q1,
+                     const JoinPlan& jp, unsigned long long* d_stats, PhaseTrace& tr)
+{
+    const uint64_t max_chunk_slots = 0xF0000000ull;
+    uint64_t g0 = Q0;
+    while (g0 < Q1) {
+        Arena GA = A;
+        FilterGroup fg;
+        fg.g0 = g0; fg.pc_cap = pc_cap;
+        uint64_t fb = 0, g1 = g0;
+        while (g1 < Q1) {
+            const uint64_t b = pc_cap ? jp.fbytes[g1 - Q0] : 0;
+            if (fb + b > jp.group_cap && g1 > g0) break;
+            fb += b;
+            fg.want.push_back(b > 0);
+            ++g1;
+        }
+        fg.g1 = g1;
+        const FilterGroup* fgp = nullptr;
+        if (fb) {
+            if (vlg_status s = filter_group<pos_t>(n_positions, q, ws, pl, poff, P, GA, fg)) return s;
+            if (fg.any) fgp = &fg;
+            tr.mark("filter group");
+        }
+        auto eff = [&](uint64_t s) -> uint64_t { return fgp ? fgp->eff[s - fgp->sub0] : pl.occ[s]; };
+        auto pc_of = [&](uint64_t qi) -> uint64_t {                      // survivors the query puts into Pc
+            uint64_t t = 0;
+            if (fgp) for (uint64_t s = q->qsub[qi]; s < q->qsub[qi + 1]; ++s) if (fgp->cidx[s - fgp->sub0] != kNone) t += fgp->eff[s - fgp->sub0];
+            return t;
+        };
+        uint64_t q0 = g0;
+        while (q0 < g1) {
+            uint64_t T = 0, S = 0, C = 0, q1 = q0;
+            while (q1 < g1) {
+                uint64_t t = join_bytes_of(q, q1, eff), sl = join_slots_of(q, q1, eff), pc = pc_of(q1);
+                if (sl > max_chunk_slots) return fail(VLG_E_WORKSPACE, "a query has more than 2^32 join slots");
+                if (((T + t > jp.want_bytes || S + sl > max_chunk_slots || C + pc > pc_cap) && q1 > q0) || (q1 - q0) >= (1u << 22)) break;
+                T += t; S += sl; C += pc;
+                ++q1;
+            }
+            vlg_status s = run_join_chunk<pos_t>(q, ws, res, q0, q1, pl, poff, P, GA, d_stats, fgp, Pc);
+            if (s) return s;
+            tr.mark("join chunk");
+            q0 = q1;
+        }
+        g0 = g1;
+    }
+    return VLG_OK;
+}
+
 // A super-chunk = a run of queries whose distinct occurrence lists fit the physical budget; inside it
 // the queries are joined in chunks bounded by the logical budget.
 template <typename pos_t>
@@ -810,6 +940,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
     const uint64_t phys_cap = std::min<uint64_t>(budget / 2 / (phys_per + 1), 0xFFFFFF00ull);
     std::vector<uint32_t> stamp(pl.dl.size(), 0xFFFFFFFFu);
     std::vector<uint32_t> poff(pl.dl.size(), 0);
+    std::vector<uint32_t> poff_sub(q->nsub, 0);
     uint64_t Q0 = 0;
     uint32_t epoch = 0;
     PhaseTrace tr(ws->stream);
@@ -835,29 +966,6 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         }
         ++epoch;
         // ---- arena: physical lists first, filter state and join scratch behind them ---------------------
-        const bool uniform_k = q->kmin == q->kmax;
-        // cost of a query in bytes of join scratch / in join slots, for list lengths given by occ_of(sub-pattern)
-        auto bytes_of = [&](uint64_t qi, auto&& occ_of) -> uint64_t {
-            uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
-            uint64_t t = 0;
-            for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += occ_of(q->qsub[qi] + i);
-            // list-0 arrays cover the slot range of all lists 0, which is exactly those slots when every query has the same k
-            uint64_t t0s = k ? (uniform_k ? occ_of(q->qsub[qi]) : t) : 0;
-            return t * kJoinBytesPerSlot + t0s * kJoinBytesPerSlot0;
-        };
-        auto slots_of = [&](uint64_t qi, auto&& occ_of) -> uint64_t {        // slot indices are 32-bit inside a chunk
-            uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
-            uint64_t t = 64ull * k;                                           // class alignment slack
-            for (uint32_t i = 0; i < k; ++i) if (i + 1 < k || k == 1) t += occ_of(q->qsub[qi] + i);
-            return t;
-        };
-        auto full = [&](uint64_t s) -> uint64_t { return pl.occ[s]; };
-        uint64_t logical_total = 0, logical_max_query = 0;
-        for (uint64_t qi = Q0; qi < Q1; ++qi) {
-            uint64_t t = bytes_of(qi, full);
-            logical_total += t;
-            logical_max_query = std::max(logical_max_query, t);
-        }
         size_t sort_tmp = 0;
         if (phys) {
             // the sort build_physical will choose (same condition there): one radix sort of (list, position) keys, or a segmented one
@@ -874,6 +982,9 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
                 sort_tmp = std::max(sort_tmp, sweep_temp_bytes(phys, idx->hdr.sigma, ws->stream));
         }
         const bool will_sweep = ws->sweep && phys >= ws->sweep_min;
+        uint64_t logical_max_query = 0;
+        for (uint64_t qi = Q0; qi < Q1; ++qi)
+            logical_max_query = std::max(logical_max_query, join_bytes_of(q, qi, [&](uint64_t s) -> uint64_t { return pl.occ[s]; }));
         // the trail table (8 B per text position) and the records (8 B per occurrence) must leave room for the joins
         uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup ? (idx->hdr.n + phys) * 8 + 512 : 0;
         const uint64_t phys_plain = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20);
@@ -894,32 +1005,9 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         }
         const uint64_t phys_bytes = phys_plain + trail_bytes;
         const uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
-        // window filter: state of the filtered queries of a group (at most a third of the budget), dropped query by query if it
-        // would not leave room for the largest unfiltered join
-        const uint64_t nbw = (((idx->hdr.n >> filter_block_shift(idx->hdr.n)) + 1) + 63) / 64;
-        const uint64_t group_cap = ws->filter_group_bytes ? std::min<uint64_t>(ws->filter_group_bytes, join_budget / 3) : join_budget / 3;
-        std::vector<uint64_t> fbytes(Q1 - Q0, 0);
-        uint64_t filter_total = 0;
-        if (ws->filter && logical_max_query + group_cap <= join_budget)
-            for (uint64_t qi = Q0; qi < Q1; ++qi) {
-                uint64_t b = filter_bytes(q, pl, ws, qi, nbw);
-                if (b > group_cap) b = 0;
-                fbytes[qi - Q0] = b;
-                filter_total += b;
-            }
-        uint64_t filter_runs = 0;                                             // runs the compaction of one chunk may have to index
-        for (uint64_t qi = Q0; qi < Q1; ++qi)
-            if (fbytes[qi - Q0]) for (uint64_t s = q->qsub[qi]; s + 1 < q->qsub[qi + 1]; ++s) filter_runs += pl.occ[s] / kRun + 1;
-        const uint64_t filter_need = std::min(filter_total, group_cap) + filter_runs * 8;
-        const uint64_t cap_bytes = join_budget - filter_need;
-        const uint64_t max_chunk_slots = 0xF0000000ull;
-        if (logical_max_query > cap_bytes)
-            return fail(VLG_E_WORKSPACE, "a query needs " + std::to_string(logical_max_query) + " bytes of join scratch; workspace cap allows " +
-                                             std::to_string(cap_bytes));
-        const uint64_t want_bytes = std::min<uint64_t>(logical_total, cap_bytes);
-        uint64_t meta = (q->qsub[Q1] - q->qsub[Q0] + 4) * (sizeof(SegMeta) + 48) + (Q1 - Q0 + 4) * (sizeof(QueryMeta) + 96) +
-                        (want_bytes / 8192 + (Q1 - Q0) + 8) * 48 + (1ull << 20);
-        if (vlg_status s = ws_reserve(ws, phys_bytes + filter_need + want_bytes + meta + fixed)) return s;
+        JoinPlan jp;
+        if (vlg_status s = plan_joins(q, pl, ws, Q0, Q1, join_budget, idx->hdr.n, jp)) return s;
+        if (vlg_status s = ws_reserve(ws, phys_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
         Arena A{ws->arena, ws->arena_bytes};
         pos_t* P = nullptr;
         uint64_t Tphys = 0;
@@ -928,50 +1016,8 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         uint64_t pc_cap = 0;
         if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, share_trails)) return s;
         tr.mark("locate + sort");
-        // ---- groups of queries that share one run of the filter; join chunks inside a group -------------------
-        uint64_t g0 = Q0;
-        while (g0 < Q1) {
-            Arena GA = A;
-            FilterGroup fg;
-            fg.g0 = g0; fg.pc_cap = pc_cap;
-            uint64_t fb = 0, g1 = g0;
-            while (g1 < Q1) {
-                const uint64_t b = pc_cap ? fbytes[g1 - Q0] : 0;
-                if (fb + b > group_cap && g1 > g0) break;
-                fb += b;
-                fg.want.push_back(b > 0);
-                ++g1;
-            }
-            fg.g1 = g1;
-            const FilterGroup* fgp = nullptr;
-            if (fb) {
-                if (vlg_status s = filter_group<pos_t>(idx, q, ws, pl, poff, P, GA, fg)) return s;
-                if (fg.any) fgp = &fg;
-                tr.mark("filter group");
-            }
-            auto eff = [&](uint64_t s) -> uint64_t { return fgp ? fgp->eff[s - fgp->sub0] : pl.occ[s]; };
-            auto pc_of = [&](uint64_t qi) -> uint64_t {                      // survivors the query puts into Pc
-                uint64_t t = 0;
-                if (fgp) for (uint64_t s = q->qsub[qi]; s < q->qsub[qi + 1]; ++s) if (fgp->cidx[s - fgp->sub0] != kNone) t += fgp->eff[s - fgp->sub0];
-                return t;
-            };
-            uint64_t q0 = g0;
-            while (q0 < g1) {
-                uint64_t T = 0, S = 0, C = 0, q1 = q0;
-                while (q1 < g1) {
-                    uint64_t t = bytes_of(q1, eff), sl = slots_of(q1, eff), pc = pc_of(q1);
-                    if (sl > max_chunk_slots) return fail(VLG_E_WORKSPACE, "a query has more than 2^32 join slots");
-                    if (((T + t > want_bytes || S + sl > max_chunk_slots || C + pc > pc_cap) && q1 > q0) || (q1 - q0) >= (1u << 22)) break;
-                    T += t; S += sl; C += pc;
-                    ++q1;
-                }
-                vlg_status s = run_join_chunk<pos_t>(idx, q, ws, res, q0, q1, pl, poff, P, GA, d_stats, fgp, Pc);
-                if (s) return s;
-                tr.mark("join chunk");
-                q0 = q1;
-            }
-            g0 = g1;
-        }
+        for (uint64_t s = q->qsub[Q0]; s < q->qsub[Q1]; ++s) poff_sub[s] = pl.occ[s] ? poff[pl.did[s]] : 0;
+        if (vlg_status s = run_joins<pos_t>(idx->hdr.n, q, ws, res, pl, poff_sub, P, A, Pc, pc_cap, Q0, Q1, jp, d_stats, tr)) return s;
         Q0 = Q1;
     }
     return VLG_OK;
@@ -994,7 +1040,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
     uint64_t* d_r = nullptr;
     unsigned long long* d_stats = nullptr;
     PhaseTrace tr(st);
-    static std::chrono::steady_clock::time_point last_end;
+    static thread_local std::chrono::steady_clock::time_point last_end;
     if (tr.on && last_end.time_since_epoch().count())
         fprintf(stderr, "[vlg trace] %-28s %9.3f ms\n", "(between two batches)",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - last_end).count());
@@ -1084,6 +1130,179 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
     if (d_stats) (void)hipFree(d_stats);
     tr.mark("free");
     last_end = std::chrono::steady_clock::now();
+    if (stt) { vlg_result_destroy(res); return stt; }
+    *out = res;
+    return VLG_OK;
+}
+
+// =============================================================================================
+// sdsl::count for every sub-pattern of a batch (what a multi-GPU host shards the batch by)
+// =============================================================================================
+extern "C" vlg_status vlg_queries_occurrences(const vlg_index* idx, const vlg_queries* q, uint64_t* h_occ, void* stream)
+{
+    if (!idx || !q || (q->nsub && !h_occ)) return fail(VLG_E_INVALID, "null argument");
+    const uint64_t nsub = q->nsub;
+    if (!nsub) return VLG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t* d_lr = nullptr;
+    VLG_HIP_TRY(hipMalloc((void**)&d_lr, 2 * nsub * 8));
+    std::vector<uint64_t> lr(2 * nsub);
+    vlg_status s = launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_lr, d_lr + nsub, nullptr, st);
+    hipError_t e = hipSuccess;
+    if (!s) e = hipMemcpyAsync(lr.data(), d_lr, 2 * nsub * 8, hipMemcpyDeviceToHost, st);
+    if (!s && e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_lr);
+    if (s) return s;
+    VLG_HIP_TRY(e);
+    for (uint64_t i = 0; i < nsub; ++i) h_occ[i] = lr[nsub + i] + 1 - lr[i];      // r + 1 - l (suffix_array_algorithm.hpp:325)
+    return VLG_OK;
+}
+
+// =============================================================================================
+// K5 on caller-provided lists
+// =============================================================================================
+namespace {
+
+// flags[0] |= 1 when some list is not ascending; flags[1] = largest element of all lists
+__global__ void lists_check_kernel(const uint64_t* __restrict__ lists, const uint64_t* __restrict__ off, uint64_t n_lists, uint64_t total,
+                                   unsigned long long* __restrict__ flags)
+{
+    constexpr uint32_t kPer = 8;
+    __shared__ uint64_t s_first;
+    bool bad = false;
+    unsigned long long mx = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
+        if (threadIdx.x == 0) {
+            uint64_t lo = 0, hi = n_lists;                 // last list with off[l] <= base
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (off[mid] <= base) lo = mid; else hi = mid; }
+            s_first = lo;
+        }
+        __syncthreads();
+        uint64_t l = s_first;
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint64_t t = base + i * 256 + threadIdx.x;
+            if (t < total) {
+                while (off[l + 1] <= t) ++l;
+                const uint64_t v = lists[t];
+                if (t > off[l] && lists[t - 1] > v) bad = true;
+                mx = v > mx ? v : mx;
+            }
+        }
+        __syncthreads();
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1ull);
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long u = __shfl_xor(mx, o); mx = u > mx ? u : mx; }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&flags[1], mx);
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_list_off, uint64_t n_lists, const uint64_t* h_join_list,
+                                     const uint64_t* h_lo, const uint64_t* h_hi, const uint64_t* h_end_len, uint64_t n_joins,
+                                     vlg_workspace* ws, vlg_result** out)
+{
+    if (!ws || !out || !h_list_off || !h_join_list || (n_lists && (!h_lo || !h_hi)) || (n_joins && !h_end_len))
+        return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VLG_E_NO_DEVICE, "no HIP device available");
+    if (h_list_off[0] != 0 || h_join_list[0] != 0 || h_join_list[n_joins] > n_lists) return fail(VLG_E_INVALID, "bad list / join offsets");
+    for (uint64_t t = 0; t < n_lists; ++t) if (h_list_off[t + 1] < h_list_off[t]) return fail(VLG_E_INVALID, "list offsets must ascend");
+    const uint64_t total = h_list_off[n_lists];
+    if (total && !d_lists) return fail(VLG_E_INVALID, "null argument");
+    if (total > 0xFFFFFF00ull) return fail(VLG_E_UNSUPPORTED, "more than 2^32 list elements in one vlg_join_batch call: split the batch");
+    // the joins as a query batch without patterns: the join passes only look at list lengths, gap bounds and end lengths
+    vlg_queries qq;
+    qq.nq = n_joins;
+    qq.nsub = h_join_list[n_joins];
+    qq.qsub.assign(h_join_list, h_join_list + n_joins + 1);
+    qq.lo.assign(h_lo, h_lo + qq.nsub);
+    qq.hi.assign(h_hi, h_hi + qq.nsub);
+    qq.end_len.assign(h_end_len, h_end_len + n_joins);
+    qq.kmax = 0; qq.kmin = 0xFFFFFFFFu;
+    Plan pl;
+    pl.occ.assign(qq.nsub, 0);
+    pl.did.assign(qq.nsub, 0);
+    std::vector<uint32_t> poff(qq.nsub, 0);
+    for (uint64_t j = 0; j < n_joins; ++j) {
+        if (qq.qsub[j + 1] < qq.qsub[j] || qq.qsub[j + 1] - qq.qsub[j] > VLG_MAX_SUBPATTERNS) return fail(VLG_E_INVALID, "bad join offsets");
+        const uint32_t k = (uint32_t)(qq.qsub[j + 1] - qq.qsub[j]);
+        qq.kmax = std::max(qq.kmax, k);
+        if (k) qq.kmin = std::min(qq.kmin, k);
+        // the reference's loop would not advance with a zero length (index_sasearch.hpp:113)
+        if (k && h_end_len[j] == 0) return fail(VLG_E_INVALID, "end_len must be at least 1");
+        if (h_end_len[j] >= (1ull << 63)) return fail(VLG_E_INVALID, "end_len out of range");
+        bool live = k > 0;
+        for (uint64_t s = qq.qsub[j]; s < qq.qsub[j + 1]; ++s) {
+            if (s > qq.qsub[j] && (h_lo[s] > h_hi[s] || h_hi[s] >= (1ull << 63))) return fail(VLG_E_INVALID, "bad gap bounds");
+            live = live && h_list_off[s + 1] > h_list_off[s];
+        }
+        // a join with an empty list has no match: none of its lists is looked at (vlg_index.hpp:315-316)
+        if (live) for (uint64_t s = qq.qsub[j]; s < qq.qsub[j + 1]; ++s) { pl.occ[s] = h_list_off[s + 1] - h_list_off[s]; poff[s] = (uint32_t)h_list_off[s]; }
+    }
+    if (qq.kmin == 0xFFFFFFFFu) qq.kmin = 0;
+    hipStream_t st = ws->stream;
+    vlg_result* res = new vlg_result();
+    memset(&res->sum, 0, sizeof res->sum);
+    res->sum.n_queries = n_joins;
+    res->counts.assign(n_joins, 0);
+    res->k.resize(n_joins);
+    for (uint64_t j = 0; j < n_joins; ++j) res->k[j] = (uint32_t)(qq.qsub[j + 1] - qq.qsub[j]);
+    for (uint64_t s = 0; s < qq.nsub; ++s) res->sum.logical_occurrences += pl.occ[s];
+    unsigned long long* d_stats = nullptr;
+    auto run = [&]() -> vlg_status {
+        VLG_HIP_TRY(hipMalloc((void**)&d_stats, 6 * 8));
+        VLG_HIP_TRY(hipMemsetAsync(d_stats, 0, 6 * 8, st));
+        PhaseTrace tr(st);
+        const uint64_t fixed = 8ull << 20;
+        if (ws->cap_bytes <= 2 * fixed) return fail(VLG_E_WORKSPACE, "workspace cap too small");
+        const uint64_t budget = ws->cap_bytes - fixed;
+        // arena: [copy of the lists][room for the survivors of the window filter][filter state][join scratch]
+        const uint64_t pc_first = align_up(total, 64);
+        uint64_t pc_cap = ws->filter && total ? std::min<uint64_t>(total, 0xFFFFFF00ull - pc_first) : 0;
+        const uint64_t list_bytes = align_up((pc_first + pc_cap + 64) * 8, 256) + align_up((n_lists + 1) * 8, 256) + 4096;
+        if (list_bytes >= budget) return fail(VLG_E_WORKSPACE, "the lists do not fit the workspace cap");
+        JoinPlan jp;
+        // position bound for the filter's block bitmaps: found on the device below, so plan with the widest bound first
+        uint64_t n_positions = 1ull << 63;
+        if (vlg_status s = plan_joins(&qq, pl, ws, 0, n_joins, budget - list_bytes, n_positions, jp)) return s;
+        if (vlg_status s = ws_reserve(ws, list_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
+        Arena A{ws->arena, ws->arena_bytes};
+        uint64_t* P = A.take<uint64_t>(pc_first + pc_cap + 64);
+        uint64_t* d_off = A.take<uint64_t>(n_lists + 1);
+        if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (join lists)");
+        svec<uint64_t> off_stage(h_list_off, h_list_off + n_lists + 1);
+        VLG_HIP_TRY(hipMemcpyAsync(d_off, off_stage.data(), (n_lists + 1) * 8, hipMemcpyHostToDevice, st));
+        if (total) {
+            VLG_HIP_TRY(hipMemcpyAsync(P, d_lists, total * 8, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(lists_check_kernel, dim3(grid_for((total + 7) / 8, 8192)), dim3(256), 0, st, P, d_off, n_lists, total, d_stats + 4);
+            VLG_HIP_TRY(hipGetLastError());
+        }
+        unsigned long long flags[2] = {0, 0};
+        VLG_HIP_TRY(hipMemcpyAsync(flags, d_stats + 4, sizeof flags, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipStreamSynchronize(st));
+        if (flags[0]) return fail(VLG_E_INVALID, "every list must be ascending");
+        if (flags[1] > (1ull << 63)) return fail(VLG_E_INVALID, "positions above 2^63 are not supported");
+        n_positions = flags[1] + 1;
+        // the plan again with the real bound (smaller bitmaps can only need less than what was reserved)
+        if (vlg_status s = plan_joins(&qq, pl, ws, 0, n_joins, budget - list_bytes, n_positions, jp)) return s;
+        tr.mark("join lists copied + checked");
+        if (vlg_status s = run_joins<uint64_t>(n_positions, &qq, ws, res, pl, poff, P, A, pc_cap ? P + pc_first : nullptr, pc_cap, 0, n_joins, jp,
+                                               d_stats, tr)) return s;
+        unsigned long long hs[4];
+        VLG_HIP_TRY(hipMemcpyAsync(hs, d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipStreamSynchronize(st));
+        res->sum.checksum = hs[2];
+        return VLG_OK;
+    };
+    vlg_status stt;
+    {
+        HostPoolScope staging(&ws->host);
+        try { stt = run(); }
+        catch (const std::bad_alloc&) { stt = fail(VLG_E_OOM, "out of host memory while planning the joins (pinned staging)"); }
+    }
+    if (d_stats) (void)hipFree(d_stats);
     if (stt) { vlg_result_destroy(res); return stt; }
     *out = res;
     return VLG_OK;

@@ -21,7 +21,11 @@ def shard_by_work(weights, world):
     cum = np.cumsum(w)
     cuts = [0]
     for r in range(1, world):
-        cuts.append(max(cuts[-1], int(np.searchsorted(cum, total * r / world, side="left"))))
+        target = total * r / world
+        i = int(np.searchsorted(cum, target, side="left"))          # cum[i-1] < target <= cum[i]: the query that crosses the target
+        if i < len(w) and (cum[i] - target) <= (target - (cum[i - 1] if i else 0.0)):
+            i += 1                                                   # ... goes to the earlier rank when that is the nearer cut
+        cuts.append(min(len(w), max(cuts[-1], i)))
     cuts.append(len(w))
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
@@ -42,6 +46,19 @@ def replicate_index(idx, dist, device, src=0):
     return VlgIndex.attach_blob(blob.data_ptr(), blob.numel(), keep=blob)
 
 
+def reduce_checksum(checksum, dist=None, device=None):
+    """Sum of the ranks' checksums modulo 2^64 (gm_search.cpp:110-114 adds positions into a uint64): reduced as two 32-bit
+    halves so that no partial sum overflows the int64 the collective adds in."""
+    chk = int(checksum) % (1 << 64)
+    if dist is None or dist.get_world_size() == 1:
+        return chk
+    import torch
+    t = torch.tensor([chk & 0xFFFFFFFF, chk >> 32], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    lo, hi = (int(x) for x in t.tolist())
+    return (lo + (hi << 32)) % (1 << 64)
+
+
 def run_sharded(search_fn, queries, dist=None, weights=None):
     """Search this rank's slice of `queries` with search_fn(list) -> (counts[q], checksum, located) and reduce the totals.
     -> dict(local_range, counts (local), num_results, checksum, located)   [totals are global]"""
@@ -49,14 +66,16 @@ def run_sharded(search_fn, queries, dist=None, weights=None):
     world = dist.get_world_size() if dist is not None else 1
     b, e = (shard_by_work(weights, world)[rank] if weights is not None else shard_bounds(len(queries), rank, world))
     counts, checksum, located = search_fn(queries[b:e])
-    tot = np.array([int(np.sum(counts)), int(checksum) % (1 << 63), int(located)], dtype=np.int64)
+    # gm_search's checksum is a sum modulo 2^64 (gm_search.cpp:110-114): it is split into 32-bit halves for the reduction, so that
+    # no partial sum overflows the int64 the collective adds in, and put together modulo 2^64 afterwards
+    chk = int(checksum) % (1 << 64)
+    tot = np.array([int(np.sum(counts)), chk & 0xFFFFFFFF, chk >> 32, int(located)], dtype=np.int64)
     if dist is not None and world > 1:
         import torch
         t = torch.from_numpy(tot.copy())
         if dist.get_backend() == "nccl":
             t = t.cuda()
-        # checksum is a wrapping 64-bit sum; summing the 63-bit residues mod 2^63 keeps it exact below 2^63
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         tot = t.cpu().numpy()
     return {"local_range": (b, e), "counts": np.asarray(counts), "num_results": int(tot[0]),
-            "checksum": int(tot[1]) % (1 << 63), "located": int(tot[2])}
+            "checksum": (int(tot[1]) + (int(tot[2]) << 32)) % (1 << 64), "located": int(tot[3])}

@@ -1,9 +1,11 @@
 // gm_search equivalent for the GPU index (benchmark/gapped-matching/src/gm_search.cpp): same command line (-c, -p),
 // same machine-readable "# key = value" lines on stdout.  Queries are searched as ONE batch; the per-query "TIMING"
-// and quartile lines therefore report the batch time divided by the number of patterns (-1 runs query by query).
+// and quartile lines therefore report the batch time divided by the number of patterns (-1 runs query by query, with real
+// per-query times).  -g N shards the pattern file over N GPUs of the node (index replicated, no exchange between the slices).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <unistd.h>
@@ -29,14 +31,15 @@ int main(int argc, char* const argv[])
 {
     std::string col_dir, pat_file;
     bool one_by_one = false;
-    int op;
-    while ((op = getopt(argc, argv, "c:p:1")) != -1) {
+    int op, n_gpus = 1;
+    while ((op = getopt(argc, argv, "c:p:1g:")) != -1) {
         if (op == 'c') col_dir = optarg;
         else if (op == 'p') pat_file = optarg;
         else if (op == '1') one_by_one = true;
+        else if (op == 'g') n_gpus = atoi(optarg);
     }
-    if (col_dir.empty() || pat_file.empty()) {
-        fprintf(stdout, "%s -c <collection directory> -p <pattern file> [-1]\n", argv[0]);
+    if (col_dir.empty() || pat_file.empty() || n_gpus < 1) {
+        fprintf(stdout, "%s -c <collection directory> -p <pattern file> [-1] [-g <GPUs>]\n", argv[0]);
         return EXIT_FAILURE;
     }
     try {
@@ -60,7 +63,8 @@ int main(int argc, char* const argv[])
                 for (auto pos : r.positions) { checksum += pos; num_results++; }
             }
         } else {
-            auto res = idx.search_batch(pats);
+            const index_fm_gpu& cidx = idx;                       // search is const, as in the reference's bench_index
+            auto res = n_gpus > 1 ? cidx.search_batch_devices(pats, n_gpus) : cidx.search_batch(pats);
             for (auto& r : res) for (auto pos : r.positions) { checksum += pos; num_results++; }
         }
         long long total_us = duration_cast<microseconds>(high_resolution_clock::now() - t0).count();
@@ -81,6 +85,7 @@ int main(int argc, char* const argv[])
         for (const char* k : {"total", "min", "qrt_1st", "mean", "median", "qrt_3rd", "max"}) std::cout << "# prep_" << k << "_time_mus = 0" << std::endl;
         std::cout << "# load_time_mus = " << load_us << std::endl;
         std::cout << "# num_patterns = " << pats.size() << std::endl;
+        std::cout << "# num_gpus = " << n_gpus << std::endl;
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << std::endl;
         return EXIT_FAILURE;

@@ -5,6 +5,7 @@
 #pragma once
 #include <iostream>
 #include <memory>
+#include <thread>
 #include "gapped_pattern.hpp"
 
 namespace vlg_host {
@@ -13,11 +14,51 @@ class index_fm_gpu
 {
   private:
     vlg_index* m_idx = nullptr;
-    vlg_workspace* m_ws = nullptr;
+    // search() is const in the reference's concept (index_sasearch.hpp:59, gm_search.cpp:96-105): scratch memory and the
+    // replicas on other devices are caches, not state of the index.  Like the reference's, a const index may be searched by one
+    // host thread at a time.
+    mutable vlg_workspace* m_ws = nullptr;
+    struct replica { int device; vlg_index* idx; vlg_workspace* ws; };
+    mutable std::vector<replica> m_replicas;       // device d = m_replicas[d-1] (device 0 holds m_idx itself)
 
-    void ensure_ws()
+    void ensure_ws() const
     {
         if (!m_ws) check(vlg_workspace_create(0, nullptr, &m_ws));
+    }
+    void drop_replicas() const
+    {
+        for (auto& r : m_replicas) { if (r.ws) vlg_workspace_destroy(r.ws); if (r.idx) vlg_index_destroy(r.idx); }
+        m_replicas.clear();
+    }
+    struct parsed_batch {
+        vlg_queries* q = nullptr;
+        ~parsed_batch() { if (q) vlg_queries_destroy(q); }
+    };
+    static void parse(const std::vector<gapped_pattern>& pats, size_t b, size_t e, int dialect, parsed_batch& out)
+    {
+        std::string text;
+        std::vector<uint64_t> off(1, 0);
+        for (size_t i = b; i < e; ++i) { text += pats[i].raw_regexp; off.push_back(text.size()); }
+        std::vector<int> status(e - b + 1, 0);
+        check(vlg_queries_parse(text.data(), off.data(), e - b, dialect, status.data(), &out.q));
+    }
+    // one pass of the hot path over pats[b,e) on the current device; positions of query i go to out[i]
+    static void search_range(const vlg_index* idx, vlg_workspace* ws, const std::vector<gapped_pattern>& pats, size_t b, size_t e, int dialect,
+                             std::vector<gapped_search_result>& out, vlg_result_summary* summary)
+    {
+        check(vlg_workspace_set_option(ws, "tuples", 0));        // gapped_search_result holds first positions only
+        parsed_batch pb;
+        parse(pats, b, e, dialect, pb);
+        vlg_result* r = nullptr;
+        check(vlg_search_batch(idx, pb.q, ws, &r));
+        vlg_result_summary s;
+        vlg_status st = vlg_result_summary_get(r, &s);
+        std::vector<uint64_t> offsets(e - b + 1), first(st ? 1 : s.n_matches + 1);
+        if (!st) st = vlg_result_fetch(r, nullptr, offsets.data(), first.data(), nullptr);
+        vlg_result_destroy(r);
+        check(st);
+        if (summary) *summary = s;
+        for (size_t i = b; i < e; ++i) out[i].positions.assign(first.begin() + offsets[i - b], first.begin() + offsets[i - b + 1]);
     }
 
   public:
@@ -36,6 +77,7 @@ class index_fm_gpu
     index_fm_gpu& operator=(const index_fm_gpu&) = delete;
     ~index_fm_gpu()
     {
+        drop_replicas();
         if (m_ws) vlg_workspace_destroy(m_ws);
         if (m_idx) vlg_index_destroy(m_idx);
     }
@@ -80,6 +122,7 @@ class index_fm_gpu
         if (!in) throw std::runtime_error("truncated VLG index file");
         vlg_index_parts p{hdr[0], (uint32_t)hdr[1], (uint32_t)hdr[2], c2c.data(), C.data(), bv.data(), hdr[3], nodes.data(), (uint32_t)hdr[4],
                           smp.data(), hdr[5]};
+        drop_replicas();
         if (m_idx) { vlg_index_destroy(m_idx); m_idx = nullptr; }
         check(vlg_index_from_parts(&p, &m_idx));
     }
@@ -88,6 +131,7 @@ class index_fm_gpu
     void save_sdsl(const std::string& path) const { check(vlg_index_save_sdsl(m_idx, path.c_str())); }
     void load_sdsl(const std::string& path)
     {
+        drop_replicas();
         if (m_idx) { vlg_index_destroy(m_idx); m_idx = nullptr; }
         check(vlg_index_load_sdsl(path.c_str(), 32, &m_idx));
     }
@@ -96,13 +140,14 @@ class index_fm_gpu
     {
         std::swap(m_idx, o.m_idx);
         std::swap(m_ws, o.m_ws);
+        std::swap(m_replicas, o.m_replicas);
     }
 
     std::string info(const gapped_pattern&) const { return ""; }
     void prepare(const gapped_pattern&) {}
 
     // idx.search(pat): one query (index_sasearch.hpp:58-118).  Per-query calls cannot feed a GPU; use search_batch.
-    gapped_search_result search(const gapped_pattern& pat)
+    gapped_search_result search(const gapped_pattern& pat) const
     {
         std::vector<gapped_search_result> r = search_batch({pat});
         return r[0];
@@ -110,34 +155,80 @@ class index_fm_gpu
 
     // all patterns in one pass of the hot path; results[i].positions = first sub-pattern starts of query i
     std::vector<gapped_search_result> search_batch(const std::vector<gapped_pattern>& pats, int dialect = VLG_DIALECT_BENCHMARK,
-                                                   vlg_result_summary* summary = nullptr)
+                                                   vlg_result_summary* summary = nullptr) const
     {
         ensure_ws();
-        check(vlg_workspace_set_option(m_ws, "tuples", 0));      // gapped_search_result holds first positions only
-        std::string text;
-        std::vector<uint64_t> off(1, 0);
-        for (const auto& p : pats) { text += p.raw_regexp; off.push_back(text.size()); }
-        std::vector<int> status(pats.size() + 1, 0);
-        vlg_queries* q = nullptr;
-        check(vlg_queries_parse(text.data(), off.data(), pats.size(), dialect, status.data(), &q));
-        vlg_result* r = nullptr;
-        vlg_status st = vlg_search_batch(m_idx, q, m_ws, &r);
-        vlg_queries_destroy(q);
-        check(st);
-        vlg_result_summary s;
-        check(vlg_result_summary_get(r, &s));
-        if (summary) *summary = s;
-        std::vector<uint64_t> offsets(pats.size() + 1), first(s.n_matches + 1);
-        st = vlg_result_fetch(r, nullptr, offsets.data(), first.data(), nullptr);
-        vlg_result_destroy(r);
-        check(st);
         std::vector<gapped_search_result> out(pats.size());
-        for (size_t i = 0; i < pats.size(); ++i) out[i].positions.assign(first.begin() + offsets[i], first.begin() + offsets[i + 1]);
+        search_range(m_idx, m_ws, pats, 0, pats.size(), dialect, out, summary);
+        return out;
+    }
+
+    // The query loop of gm_search.cpp:91-121 sharded over the GPUs of the node: the index is replicated once
+    // (peer copies over xGMI), the batch is cut into contiguous slices of equal estimated work -- the sum of the SA-interval sizes
+    // of a query's sub-patterns, from one backward-search pass -- and one host thread per device searches its slice.  Queries are
+    // independent, so nothing is exchanged; results come back in batch order.  A device count above the node's wraps around
+    // (several slices on one GPU: only useful to rehearse the path on a smaller machine).
+    std::vector<gapped_search_result> search_batch_devices(const std::vector<gapped_pattern>& pats, int n_devices,
+                                                           int dialect = VLG_DIALECT_BENCHMARK, std::vector<vlg_result_summary>* summaries = nullptr) const
+    {
+        int ndev = 0;
+        check(vlg_device_count(&ndev));
+        if (n_devices < 1 || ndev < 1) throw std::runtime_error("search_batch_devices: no device");
+        ensure_ws();
+        check(vlg_set_device(0));
+        while ((int)m_replicas.size() + 1 < n_devices) {
+            replica r{(int)(m_replicas.size() + 1) % ndev, nullptr, nullptr};
+            check(vlg_index_replicate(m_idx, r.device, &r.idx));
+            m_replicas.push_back(r);
+        }
+        // weights: one backward-search pass over the whole batch on device 0
+        std::vector<uint64_t> cut(n_devices + 1, pats.size());
+        cut[0] = 0;
+        {
+            parsed_batch pb;
+            parse(pats, 0, pats.size(), dialect, pb);
+            std::vector<uint32_t> k(pats.size() + 1);
+            std::vector<uint64_t> occ(vlg_queries_subpatterns(pb.q) + 1);
+            check(vlg_queries_k(pb.q, k.data()));
+            check(vlg_queries_occurrences(m_idx, pb.q, occ.data(), nullptr));
+            std::vector<double> cum(pats.size() + 1, 0.0);
+            size_t s = 0;
+            for (size_t i = 0; i < pats.size(); ++i) {
+                double w = 0;
+                bool dead = false;
+                for (uint32_t j = 0; j < k[i]; ++j) { w += (double)occ[s + j]; dead |= occ[s + j] == 0; }
+                s += k[i];
+                cum[i + 1] = cum[i] + (dead ? 0.0 : w) + 1.0;
+            }
+            for (int d = 1; d < n_devices; ++d) {                 // the nearer of the two cuts around the target
+                const double target = cum.back() * d / n_devices;
+                size_t i = (size_t)(std::lower_bound(cum.begin() + 1, cum.end(), target) - (cum.begin() + 1));
+                if (i < pats.size() && cum[i + 1] - target <= target - cum[i]) ++i;
+                cut[d] = std::max<uint64_t>(cut[d - 1], std::min<uint64_t>(i, pats.size()));
+            }
+        }
+        std::vector<gapped_search_result> out(pats.size());
+        std::vector<std::string> errors(n_devices);
+        if (summaries) summaries->assign(n_devices, vlg_result_summary());
+        std::vector<std::thread> threads;
+        for (int d = 0; d < n_devices; ++d)
+            threads.emplace_back([&, d]() {
+                try {
+                    const int device = d == 0 ? 0 : m_replicas[d - 1].device;
+                    check(vlg_set_device(device));                 // per host thread
+                    vlg_workspace*& ws = d == 0 ? m_ws : m_replicas[d - 1].ws;
+                    if (!ws) check(vlg_workspace_create(0, nullptr, &ws));
+                    search_range(d == 0 ? m_idx : m_replicas[d - 1].idx, ws, pats, cut[d], cut[d + 1], dialect, out,
+                                 summaries ? &(*summaries)[d] : nullptr);
+                } catch (const std::exception& e) { errors[d] = e.what(); }
+            });
+        for (auto& t : threads) t.join();
+        for (int d = 0; d < n_devices; ++d) if (!errors[d].empty()) throw std::runtime_error("device slice " + std::to_string(d) + ": " + errors[d]);
         return out;
     }
 
     // sdsl::locate(idx, query) (include/sdsl/vlg_index.hpp:395-401): every sub-pattern position of every match
-    std::vector<std::vector<uint64_t>> locate(const std::string& query)
+    std::vector<std::vector<uint64_t>> locate(const std::string& query) const
     {
         ensure_ws();
         check(vlg_workspace_set_option(m_ws, "tuples", 1));
@@ -160,7 +251,7 @@ class index_fm_gpu
         for (uint64_t m = 0; m < s.n_matches; ++m) out[m].assign(tuples.begin() + m * k, tuples.begin() + (m + 1) * k);
         return out;
     }
-    uint64_t count(const std::string& query) { return locate(query).size(); }
+    uint64_t count(const std::string& query) const { return locate(query).size(); }
 
     vlg_index* handle() const { return m_idx; }
 };

@@ -55,6 +55,10 @@ class SearchResult:
             self._fetched = (counts[:nq], offsets, first[: self.summary["n_matches"]], tuples[: self.summary["n_tuple_values"]])
         return self._fetched
 
+    def fetch_into(self, counts_ptr, offsets_ptr, first_ptr, tuples_ptr):
+        """vlg_result_fetch into caller-provided host buffers (e.g. pinned memory); any pointer may be None."""
+        check(lib().vlg_result_fetch(self._h, counts_ptr, offsets_ptr, first_ptr, tuples_ptr))
+
     @property
     def counts(self):
         return self.fetch()[0]
@@ -143,6 +147,22 @@ class Queries:
         self._h = h
         self.status = status[: len(raws)]
         self.n = len(raws)
+
+    @classmethod
+    def from_blob(cls, text, off, dialect=capi.DIALECT_LIBRARY):
+        """The regexps already concatenated (query i = text[off[i], off[i+1])): one vlg_queries_parse call, nothing else."""
+        self = cls.__new__(cls)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib().vlg_queries_parse(text, off.ctypes.data, len(off) - 1, dialect, None, C.byref(h)))
+        self._h = h
+        self.n = len(off) - 1
+        self.status = np.zeros(self.n, dtype=np.int32)
+        return self
+
+    def subpattern_range(self):
+        """qsub[nq+1]: query i owns the sub-patterns [qsub[i], qsub[i+1]) of the batch"""
+        return np.concatenate([[0], np.cumsum(self.ks.astype(np.int64))])
 
     @classmethod
     def from_arrays(cls, subpatterns, lo, hi, end_len):
@@ -289,6 +309,29 @@ class VlgIndex:
         check(lib().vlg_index_blob_export(self._h, d_ptr, nbytes, stream))
 
     # -- search -----------------------------------------------------------------------------------
+    def occurrences(self, queries, dialect=capi.DIALECT_LIBRARY):
+        """sdsl::count of every sub-pattern of the batch (one backward-search pass) -> uint64[n sub-patterns]"""
+        q = queries if isinstance(queries, Queries) else Queries(queries, dialect)
+        nsub = int(lib().vlg_queries_subpatterns(q._h))
+        occ = np.zeros(max(nsub, 1), dtype=np.uint64)
+        check(lib().vlg_queries_occurrences(self._h, q._h, occ.ctypes.data, None))
+        return occ[:nsub], q
+
+    def query_weights(self, queries, dialect=capi.DIALECT_LIBRARY):
+        """Estimated work per query = sum of the SA-interval sizes of its sub-patterns (0 when one of them does not occur: such a
+        query locates nothing) -- what vlg_matching_amd.dist.shard_by_work balances."""
+        occ, q = self.occurrences(queries, dialect)
+        qsub = q.subpattern_range()
+        w = np.zeros(q.n, dtype=np.float64)
+        if len(occ):
+            cs = np.concatenate([[0], np.cumsum(occ.astype(np.float64))])
+            w = cs[qsub[1:]] - cs[qsub[:-1]]
+            dead = np.zeros(q.n, dtype=bool)
+            zero = np.concatenate([[0], np.cumsum(occ == 0)])
+            dead = (zero[qsub[1:]] - zero[qsub[:-1]]) > 0
+            w[dead] = 0.0
+        return w + 1.0                                         # every query costs something (parse, plan)
+
     def workspace(self, max_hbm_bytes=0):
         if self._ws is None:
             self._ws = Workspace(max_hbm_bytes)
@@ -301,6 +344,23 @@ class VlgIndex:
         h = C.c_void_p()
         check(lib().vlg_search_batch(self._h, q._h, ws._h, C.byref(h)))
         return SearchResult(h, q.ks)
+
+
+def join_batch(d_lists_ptr, list_off, join_list, lo, hi, end_len, workspace, ks=None):
+    """vlg_join_batch: the gap-bounded merge join (index_sasearch.hpp:85-116) over caller-provided sorted u64 lists in HBM.
+    list_off[n_lists+1], join_list[n_joins+1], lo/hi[n_lists], end_len[n_joins] are host arrays.  -> SearchResult"""
+    a = [np.ascontiguousarray(x, dtype=np.uint64) for x in (list_off, join_list, lo, hi, end_len)]
+    n_lists, n_joins = len(a[0]) - 1, len(a[1]) - 1
+    if len(a[2]) < max(n_lists, 1):
+        a[2] = np.concatenate([a[2], np.zeros(max(n_lists, 1) - len(a[2]), np.uint64)])
+    if len(a[3]) < max(n_lists, 1):
+        a[3] = np.concatenate([a[3], np.zeros(max(n_lists, 1) - len(a[3]), np.uint64)])
+    if len(a[4]) < max(n_joins, 1):
+        a[4] = np.concatenate([a[4], np.ones(max(n_joins, 1) - len(a[4]), np.uint64)])
+    h = C.c_void_p()
+    check(lib().vlg_join_batch(d_lists_ptr, a[0].ctypes.data, n_lists, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                               a[4].ctypes.data, n_joins, workspace._h, C.byref(h)))
+    return SearchResult(h, np.diff(a[1].astype(np.int64)).astype(np.uint32) if ks is None else ks)
 
 
 def locate(idx, query):
