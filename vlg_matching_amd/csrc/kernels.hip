@@ -559,7 +559,8 @@ __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t
     }
 }
 
-// kTrail: LF trails are shared.  trail[i] remembers the first element that stood on SA index i and at which step; an
+// kTrail: LF trails are shared.  trail[i] = generation << 48 | (element + 1) << 16 | step remembers the first element that stood on
+// SA index i in THIS sweep and at which step (the generation stamp spares clearing 8 bytes per text position for every batch); an
 // element that arrives there later has the same future, so it stops and records (that element, steps apart) in rec -- or,
 // when that element has a record already, the record one hop further.  rec[slot]: a position (high bits 0), or
 // delta << kShift | slot of the element it follows; ~0 while the element is still walking.  slot0 = first slot of the sweep.
@@ -568,7 +569,7 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
                                                          uint32_t step, pos_t* __restrict__ out,
                                                          unsigned long long* __restrict__ stats /* lf, levels */,
                                                          unsigned long long* __restrict__ n_done, uint64_t* __restrict__ trail,
-                                                         uint64_t* __restrict__ rec, uint64_t slot0)
+                                                         uint64_t* __restrict__ rec, uint64_t slot0, uint64_t gen /* << 48 */)
 {
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
@@ -592,11 +593,12 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
             else out[v64 >> kShift] = (pos_t)r;
             key[e] = (uint16_t)iv.sigma;
             ++n_fin;
-        } else if (kTrail && step != 0 && trail[i] != 0 && (trail[i] & 0xFFFFu) != step) {   // round 0: the table is empty; an equal step is a
-                                                                                              // twin (the same index in two lists)
-            // someone stood here `delta` steps ago: same text trail, `delta` positions further left when it started
+        } else if (kTrail && step != 0 && (trail[i] >> 48 << 48) == gen && (trail[i] & 0xFFFFu) != step) {
+            // (round 0: nobody has walked yet; an entry of another generation is left over from an earlier sweep; an equal step is a
+            // twin -- the same index in two lists.)  Someone stood here `delta` steps ago: same text trail, `delta` positions further
+            // left when it started
             const uint64_t m = trail[i];
-            const uint64_t owner = (m >> 16) - 1, delta = step - (m & 0xFFFFu);
+            const uint64_t owner = ((m >> 16) & 0xFFFFFFFFull) - 1, delta = step - (m & 0xFFFFu);
             const uint64_t ro = rec[owner];
             uint64_t r;
             if (ro == ~0ull) r = (delta << kShift) | owner;                       // still walking: follow it
@@ -606,7 +608,7 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
             key[e] = (uint16_t)iv.sigma;
             ++n_fin;
         } else {
-            if (kTrail) trail[i] = ((slot0 + (v64 >> kShift) + 1) << 16) | step;
+            if (kTrail) trail[i] = gen | ((slot0 + (v64 >> kShift) + 1) << 16) | step;
             uint32_t v = 0, c;
             uint64_t pos = i;
             for (;;) {                                       // inverse_select: wt_pc.hpp:385-402
@@ -825,7 +827,8 @@ template <typename pos_t>
 vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
                                pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
-                               hipStream_t stream, LaunchTimer* timer, uint64_t* trail /* n words, or null */, uint64_t* rec /* total words */)
+                               hipStream_t stream, LaunchTimer* timer, uint64_t* trail /* n words, or null */, uint64_t* rec /* total words */,
+                               uint32_t* trail_gen /* generation of the last sweep that used this table; 0 = unknown content */)
 {
     constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
     if (iv.n > (1ull << kShift)) return fail(VLG_E_UNSUPPORTED, "sorted sweep: text too long for the packed position");
@@ -834,7 +837,16 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     if (trail) VLG_HIP_TRY(hipMemsetAsync(rec, 0xFF, total * 8, stream));
     for (uint64_t t0 = 0; t0 < total; t0 += batch_max) {
         const uint64_t t1 = std::min(total, t0 + batch_max);
-        if (trail) VLG_HIP_TRY(hipMemsetAsync(trail, 0, iv.n * 8, stream));      // steps are counted per sweep: trails are not shared across sweeps
+        uint64_t gen = 0;
+        if (trail) {                                             // steps are counted per sweep: trails are not shared across sweeps
+            if (total > 0xFFFFFFFFull) return fail(VLG_E_INTERNAL, "trail table: element numbers need 32 bits");
+            if (!trail_gen || *trail_gen == 0 || *trail_gen >= 0xFFFFu) {
+                VLG_HIP_TRY(hipMemsetAsync(trail, 0, iv.n * 8, stream));
+                gen = 1;
+            } else gen = *trail_gen + 1;
+            if (trail_gen) *trail_gen = (uint32_t)gen;
+            gen <<= 48;
+        }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for((t1 - t0 + 7) / 8, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
                            t0, t1, val_a);
         VLG_HIP_TRY(hipGetLastError());
@@ -847,14 +859,14 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             const dim3 grid(grid_for(alive, 4096));
             if (iv.bv_kind == kBvRrr63) {
                 if (trail) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t, true>), grid, dim3(256), 0, stream, iv, val_a, key_a,
-                                              alive, step, out, d_stats, d_counter, trail, rec, t0);
+                                              alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t, false>), grid, dim3(256), 0, stream, iv, val_a, key_a,
-                                        alive, step, out, d_stats, d_counter, trail, rec, t0);
+                                        alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
             } else {
                 if (trail) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t, true>), grid, dim3(256), 0, stream, iv, val_a, key_a,
-                                              alive, step, out, d_stats, d_counter, trail, rec, t0);
+                                              alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t, false>), grid, dim3(256), 0, stream, iv, val_a, key_a,
-                                        alive, step, out, d_stats, d_counter, trail, rec, t0);
+                                        alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
             }
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
@@ -906,10 +918,10 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
 }
 template vlg_status launch_locate_sweep<uint32_t>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint32_t*, uint64_t*,
                                                   uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, uint64_t,
-                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*);
+                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*, uint32_t*);
 template vlg_status launch_locate_sweep<uint64_t>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint64_t*, uint64_t*,
                                                   uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, uint64_t,
-                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*);
+                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*, uint32_t*);
 
 }  // namespace vlg
 

@@ -64,6 +64,9 @@ struct vlg_workspace {
     uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
     uint64_t sweep_tail = 1ull << 20;   // stragglers of a sweep are finished one lane each
+    // trail table of the sorted sweep: it lives at the head of the arena and carries generation stamps, so it is cleared once, not per batch
+    uint32_t trail_gen = 0;             // generation of the last sweep that wrote it; 0 = content unknown
+    uint64_t trail_n = 0;               // text length it was last used for
     vlg_kernel_stat stats[KS_COUNT];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KS_COUNT];
     std::vector<hipEvent_t> free_events;
@@ -152,6 +155,7 @@ void drain_result_cache();
 vlg_status ws_reserve(vlg_workspace* ws, uint64_t bytes)
 {
     if (bytes <= ws->arena_bytes) return VLG_OK;
+    ws->trail_gen = 0;
     if (ws->arena) { (void)hipFree(ws->arena); ws->arena = nullptr; ws->arena_bytes = 0; }
     if (hipMalloc((void**)&ws->arena, bytes) != hipSuccess) {        // parked result buffers may be in the way
         (void)hipGetLastError();
@@ -418,7 +422,8 @@ __global__ void sort_narrow_kernel(const uint64_t* __restrict__ keys, uint64_t t
 template <typename pos_t>
 vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* res, const std::vector<uint32_t>& dlist /* distinct ids */,
                           const Plan& pl, Arena& A, pos_t*& P_out, std::vector<uint32_t>& poff /* per distinct id -> offset (size dl) */,
-                          uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats, pos_t*& Pc_out, uint64_t& pc_cap, bool share_trails)
+                          uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats, pos_t*& Pc_out, uint64_t& pc_cap,
+                          uint64_t* trail /* n words at the head of the arena when trails are shared, else null */)
 {
     hipStream_t st = ws->stream;
     const uint32_t nd = (uint32_t)dlist.size();
@@ -453,12 +458,10 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     VLG_HIP_TRY(hipMemcpyAsync(d_lh, lh.data(), nd * 8, hipMemcpyHostToDevice, st));
     if (use_sweep) {
         const uint64_t cap = std::min<uint64_t>(acc, sweep_batch_max<pos_t>());
-        uint64_t* trail = nullptr;
         uint64_t* rec = nullptr;
-        if (share_trails) {                                                       // (trails are shared inside one sweep)
-            trail = A.take<uint64_t>(idx->hdr.n);
+        if (trail) {                                                              // (trails are shared inside one sweep)
             rec = A.take<uint64_t>(acc);
-            if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (trail table)");
+            if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (trail records)");
         }
         uint64_t* val_a = reinterpret_cast<uint64_t*>(scratch);
         uint64_t* val_b = val_a + cap;
@@ -466,7 +469,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         uint16_t* key_b = key_a + cap;
         SweepTimer timer(ws);
         if (vlg_status s = launch_locate_sweep<pos_t>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b,
-                                               d_tmp, sort_tmp, d_counter, d_stats, ws->sweep_tail, st, &timer, trail, rec)) return s;
+                                               d_tmp, sort_tmp, d_counter, d_stats, ws->sweep_tail, st, &timer, trail, rec, &ws->trail_gen)) return s;
     } else {
         {
             Timed t(ws, KS_EXPAND, 0);
@@ -1005,16 +1008,32 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         }
         const uint64_t phys_bytes = phys_plain + trail_bytes;
         const uint64_t join_budget = budget > phys_bytes ? budget - phys_bytes : 0;
+        // When the arena already holds whatever a plan can ask for (the caller reserved the whole cap), locate + sort are launched
+        // first and the joins are planned while the GPU works; otherwise the plan decides how much to allocate.
+        const uint64_t meta_upper = (q->qsub[Q1] - q->qsub[Q0] + 4) * (sizeof(SegMeta) + 48) + (Q1 - Q0 + 4) * (sizeof(QueryMeta) + 96) +
+                                    (budget / 8192 + (Q1 - Q0) + 8) * 48 + (1ull << 20);
+        const bool launch_first = ws->arena_bytes >= budget + meta_upper + 2 * fixed;
         JoinPlan jp;
-        if (vlg_status s = plan_joins(q, pl, ws, Q0, Q1, join_budget, idx->hdr.n, jp)) return s;
-        if (vlg_status s = ws_reserve(ws, phys_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
+        if (!launch_first) {
+            if (vlg_status s = plan_joins(q, pl, ws, Q0, Q1, join_budget, idx->hdr.n, jp)) return s;
+            if (vlg_status s = ws_reserve(ws, phys_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
+        }
         Arena A{ws->arena, ws->arena_bytes};
+        // the trail table first: at a fixed place, so that what earlier sweeps left there is told apart by its generation stamp
+        uint64_t* trail = nullptr;
+        if (share_trails) {
+            if (ws->trail_n != idx->hdr.n) { ws->trail_gen = 0; ws->trail_n = idx->hdr.n; }
+            trail = A.take<uint64_t>(idx->hdr.n);
+            if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (trail table)");
+        } else ws->trail_gen = 0;                                // other data takes the head of the arena
         pos_t* P = nullptr;
         uint64_t Tphys = 0;
         tr.mark("plan super-chunk");
         pos_t* Pc = nullptr;
         uint64_t pc_cap = 0;
-        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, share_trails)) return s;
+        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, trail)) return s;
+        if (launch_first)
+            if (vlg_status s = plan_joins(q, pl, ws, Q0, Q1, join_budget, idx->hdr.n, jp)) return s;
         tr.mark("locate + sort");
         for (uint64_t s = q->qsub[Q0]; s < q->qsub[Q1]; ++s) poff_sub[s] = pl.occ[s] ? poff[pl.did[s]] : 0;
         if (vlg_status s = run_joins<pos_t>(idx->hdr.n, q, ws, res, pl, poff_sub, P, A, Pc, pc_cap, Q0, Q1, jp, d_stats, tr)) return s;
@@ -1268,6 +1287,7 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
         uint64_t n_positions = 1ull << 63;
         if (vlg_status s = plan_joins(&qq, pl, ws, 0, n_joins, budget - list_bytes, n_positions, jp)) return s;
         if (vlg_status s = ws_reserve(ws, list_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
+        ws->trail_gen = 0;                                       // the lists take the head of the arena
         Arena A{ws->arena, ws->arena_bytes};
         uint64_t* P = A.take<uint64_t>(pc_first + pc_cap + 64);
         uint64_t* d_off = A.take<uint64_t>(n_lists + 1);
