@@ -305,6 +305,42 @@ vlg_status vlg_result_fetch(const vlg_result* r, uint64_t* h_counts, uint64_t* h
                             uint64_t* h_first_positions, uint64_t* h_tuples);
 void vlg_result_destroy(vlg_result* r);
 
+/* ------------------------------------------------------------------------------------------
+ * The paper's index: vlg_index<alphabet_tag, wt_int<>> -- the text plus a wavelet tree over its suffix
+ * array (include/sdsl/vlg_index.hpp:109-198, construct :375-392), searched lazily by vlg_iterator (:209-373): no occurrence list
+ * is ever located or sorted; a match costs a few root-to-leaf walks of the tree, so the first matches of a query come cheaply
+ * however long its lists are.  Byte texts (byte_alphabet_tag) and integer texts (int_alphabet_tag: symbols are uint32_t, a
+ * query's sub-patterns whitespace-separated decimals, vlg_index.hpp:63-69).
+ * On the device the tree is level-contiguous: level l is one rank-enabled bit-vector of 256-bit super-blocks (as K1), nodes are
+ * intervals of it (wt_int, include/sdsl/wt_int.hpp:215-255).  Results equal sdsl::locate(vlg_index, query) -- the same tuples as
+ * vlg_search_batch on the FM-index -- cut after max_matches_per_query matches of each query when that is not 0 (what a caller
+ * that stops iterating early sees, include/sdsl/vlg_index.hpp:357-363).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vlg_wtsa vlg_wtsa;
+typedef struct {
+    uint64_t n;                   /* symbols + 1 (sentinel) = size of the suffix array                */
+    uint32_t symbol_bytes;        /* 1 or 4                                                           */
+    uint32_t levels;              /* bits per suffix-array value = levels of the tree                 */
+    uint64_t blocks_per_level;    /* 32-byte super-blocks per level                                   */
+    uint64_t hbm_bytes;           /* text + tree                                                      */
+} vlg_wtsa_info;
+/* symbol_bytes 1: h_text is uint8_t[n_symbols] without a 0 byte (VLG_E_ZERO_BYTE); 4: uint32_t[n_symbols], any values. */
+vlg_status vlg_wtsa_build(const void* h_text, uint64_t n_symbols, uint32_t symbol_bytes, vlg_wtsa** out);
+vlg_status vlg_wtsa_get_info(const vlg_wtsa* idx, vlg_wtsa_info* info);
+void vlg_wtsa_destroy(vlg_wtsa* idx);
+/* wt[i] (wt_int::operator[], include/sdsl/wt_int.hpp:339-361) = SA[i] for arbitrary indices. */
+vlg_status vlg_wtsa_sa_batch(const vlg_wtsa* idx, const uint64_t* d_i, uint64_t* d_out, uint64_t count, void* stream);
+/* forward_search(text.begin(), text.end(), wt, 0, wt.size()-1, pat.begin(), pat.end(), sp, ep)
+ * (include/sdsl/suffix_array_algorithm.hpp:48-112) for every sub-pattern of the batch: h_sp/h_ep receive the suffix-array
+ * range [sp, ep] (sp = ep + 1: no occurrence). */
+vlg_status vlg_wtsa_ranges(const vlg_wtsa* idx, const vlg_queries* q, uint64_t* h_sp, uint64_t* h_ep, void* stream);
+/* Integer-alphabet query batch: like vlg_queries_parse with VLG_DIALECT_LIBRARY, sub-patterns parsed as the reference parses them
+ * for int_alphabet_tag (whitespace-separated decimals; gaps count symbols).  Only vlg_wtsa_* entry points accept such a batch. */
+vlg_status vlg_queries_parse_int(const char* h_text, const uint64_t* h_off, uint64_t n_queries, int* h_status, vlg_queries** out);
+/* sdsl::locate / count on the batch, at most max_matches_per_query matches each (0 = all). */
+vlg_status vlg_wtsa_search_batch(const vlg_wtsa* idx, const vlg_queries* q, uint64_t max_matches_per_query, vlg_workspace* ws,
+                                 vlg_result** out);
+
 /* Per-kernel accounting of the last calls on this workspace (HIP events on the workspace stream).
  * Enabled with vlg_workspace_profile(ws, 1); reset by vlg_workspace_profile(ws, 1) again. */
 typedef struct {

@@ -48,6 +48,11 @@ class ParsedQuery(C.Structure):
                 ("lo", C.c_uint64 * 64), ("hi", C.c_uint64 * 64), ("end_len", C.c_uint64)]
 
 
+class WtsaInfo(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("symbol_bytes", C.c_uint32), ("levels", C.c_uint32), ("blocks_per_level", C.c_uint64),
+                ("hbm_bytes", C.c_uint64)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_uint64)]
 
@@ -104,6 +109,13 @@ SYMBOLS = [
     ("vlg_result_summary_get", _I, [_P, C.POINTER(ResultSummary)]),
     ("vlg_result_fetch", _I, [_P, _P, _P, _P, _P]),
     ("vlg_result_destroy", None, [_P]),
+    ("vlg_wtsa_build", _I, [_P, _U64, C.c_uint32, C.POINTER(_P)]),
+    ("vlg_wtsa_get_info", _I, [_P, C.POINTER(WtsaInfo)]),
+    ("vlg_wtsa_destroy", None, [_P]),
+    ("vlg_wtsa_sa_batch", _I, [_P, _P, _P, _U64, _P]),
+    ("vlg_wtsa_ranges", _I, [_P, _P, _P, _P, _P]),
+    ("vlg_queries_parse_int", _I, [C.c_char_p, _P, _U64, _P, C.POINTER(_P)]),
+    ("vlg_wtsa_search_batch", _I, [_P, _P, _U64, _P, C.POINTER(_P)]),
     ("vlg_workspace_profile", _I, [_P, _I]),
     ("vlg_workspace_set_option", _I, [_P, C.c_char_p, C.c_int64]),
     ("vlg_workspace_kernel_stats", _I, [_P, C.POINTER(KernelStat), C.c_uint32, C.POINTER(C.c_uint32)]),

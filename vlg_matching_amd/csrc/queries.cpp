@@ -171,6 +171,72 @@ extern "C" vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_of
     return VLG_OK;
 }
 
+// Integer alphabet (gapped_pattern_query<int_alphabet_tag>, include/sdsl/vlg_index.hpp:57-69): a sub-pattern is read with
+// `istringstream >> uint64_t` until the first token that is not a number; gaps count symbols (:95).
+extern "C" vlg_status vlg_queries_parse_int(const char* h_text, const uint64_t* h_off, uint64_t n_queries, int* h_status, vlg_queries** out)
+{
+    if (!out || (n_queries && (!h_text || !h_off))) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    vlg_queries* q = new vlg_queries();
+    q->nq = n_queries;
+    q->sym_bytes = 4;
+    q->qsub.assign(1, 0);
+    q->suboff.assign(1, 0);
+    vlg_status first_err = VLG_OK;
+    std::string first_why;
+    for (uint64_t i = 0; i < n_queries; ++i) {
+        Parsed p;
+        std::string why;
+        const char* re = h_text + h_off[i];
+        vlg_status st = parse_one(re, h_off[i + 1] - h_off[i], VLG_DIALECT_LIBRARY, p, why);
+        std::vector<std::vector<uint32_t>> syms;
+        if (!st) {
+            for (auto& sp : p.sub) {
+                std::vector<uint32_t> v;
+                const char* c = re + sp.first;
+                const char* e = c + sp.second;
+                for (;;) {
+                    while (c < e && (*c == ' ' || (*c >= 9 && *c <= 13))) ++c;
+                    if (c < e && *c == '+') ++c;
+                    if (c >= e || *c < '0' || *c > '9') break;
+                    uint64_t x = 0;
+                    bool over = false;
+                    while (c < e && *c >= '0' && *c <= '9') { if (x > (0xFFFFFFFFFFFFFFFFull - 9) / 10) over = true; x = x * 10 + (uint64_t)(*c - '0'); ++c; }
+                    if (over) break;                                                    // the stream extraction fails: the rest is ignored
+                    if (x > 0xFFFFFFFFull) { st = VLG_E_INVALID; why = "symbol does not fit 32 bits"; break; }
+                    v.push_back((uint32_t)x);
+                }
+                if (!st && v.empty()) { st = VLG_E_INVALID; why = "empty sub-pattern"; }
+                if (st) break;
+                syms.push_back(v);
+            }
+        }
+        if (h_status) h_status[i] = st;
+        if (st) {
+            if (!first_err) { first_err = st; first_why = "query " + std::to_string(i) + ": " + why; }
+        } else {
+            for (size_t s = 0; s < syms.size(); ++s) {
+                const uint8_t* b = reinterpret_cast<const uint8_t*>(syms[s].data());
+                q->blob.insert(q->blob.end(), b, b + syms[s].size() * 4);
+                q->suboff.push_back(q->blob.size());
+                // the parser added the sub-pattern's length in characters; gaps count symbols
+                const uint64_t raw_lo = s ? p.lo[s] - p.sub[s - 1].second : 0, raw_hi = s ? p.hi[s] - p.sub[s - 1].second : 0;
+                q->lo.push_back(s ? raw_lo + syms[s - 1].size() : 0);
+                q->hi.push_back(s ? raw_hi + syms[s - 1].size() : 0);
+            }
+        }
+        q->qsub.push_back(q->suboff.size() - 1);
+        q->end_len.push_back(st ? 0 : syms.back().size());
+    }
+    q->nsub = q->suboff.size() - 1;
+    if (first_err && !h_status) { delete q; return fail(first_err, first_why); }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete q; return fail(VLG_E_NO_DEVICE, "no HIP device available"); }
+    if (vlg_status st = upload_queries(q)) { vlg_queries_destroy(q); return st; }
+    *out = q;
+    return VLG_OK;
+}
+
 extern "C" vlg_status vlg_queries_create(const uint8_t* h_blob, const uint64_t* h_suboff, const uint64_t* h_qsub, const uint64_t* h_lo,
                                          const uint64_t* h_hi, const uint64_t* h_end_len, uint64_t n_queries, vlg_queries** out)
 {

@@ -1048,6 +1048,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
 {
     if (!idx || !q || !ws || !out) return fail(VLG_E_INVALID, "null argument");
     *out = nullptr;
+    if (q->sym_bytes != 1) return fail(VLG_E_INVALID, "integer-alphabet query batch: only the vlg_wtsa_* entry points take it");
     hipStream_t st = ws->stream;
     vlg_result* res = new vlg_result();
     memset(&res->sum, 0, sizeof res->sum);
@@ -1160,6 +1161,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
 extern "C" vlg_status vlg_queries_occurrences(const vlg_index* idx, const vlg_queries* q, uint64_t* h_occ, void* stream)
 {
     if (!idx || !q || (q->nsub && !h_occ)) return fail(VLG_E_INVALID, "null argument");
+    if (q->sym_bytes != 1) return fail(VLG_E_INVALID, "integer-alphabet query batch: only the vlg_wtsa_* entry points take it");
     const uint64_t nsub = q->nsub;
     if (!nsub) return VLG_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -1327,3 +1329,5 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
     *out = res;
     return VLG_OK;
 }
+
+#include "wtsa.hpp"

@@ -11,6 +11,7 @@ struct vlg_queries {
     std::vector<uint64_t> lo, hi;    // [nsub]
     std::vector<uint64_t> end_len;   // [nq]
     uint32_t kmax = 0, kmin = 0;     // over queries with at least one sub-pattern
+    uint32_t sym_bytes = 1;          // 1: byte sub-patterns; 4: integer alphabet (vlg_queries_parse_int), symbols little-endian in blob
     uint8_t* d_blob = nullptr;
     uint64_t* d_suboff = nullptr;
 };

@@ -1,0 +1,507 @@
+// The paper's index on the device: text + wavelet tree over the suffix array, searched lazily.
+// Internal to search.hip's translation unit (results, workspace and timers live there); included exactly once, at its end.
+//   vlg_index<alphabet_tag, wt_int<>>   include/sdsl/vlg_index.hpp:109-198, construct :375-392
+//   wt_int                              include/sdsl/wt_int.hpp:215-255 (level-wise layout), :339-361 (operator[]), :824-939 (expand / ranges)
+//   vlg_iterator                        include/sdsl/vlg_index.hpp:209-373 (relax / next / pull_forward)
+//   forward_search                      include/sdsl/suffix_array_algorithm.hpp:48-112
+//
+// HBM layout: level l of the tree (l = 0: most significant bit of the suffix-array values) is ONE bit-vector of n values, cut into
+// the same 256-bit super-blocks as K1 {7 x u32 data, u32 ones before the block inside the level}; the levels follow each other.
+// A node is an interval [b, b + size) of its level; its children are the intervals [b, b + zeros) and [b + zeros, b + size) of the
+// next level (wt_int.hpp:215-255).  Everything the search needs is two root-to-leaf walks with four rank reads per level:
+//   count_less(l, len, x)   how many of SA[l, l + len) are smaller than x
+//   quantile(l, len, q)     the q-th smallest of SA[l, l + len)
+// so that "the first occurrence of sub-pattern i at or after position p" = quantile(count_less(p)): the sorted occurrence list of a
+// sub-pattern is read by rank without ever being located or sorted.  The reference walks the same tree node by node with a cache of
+// expanded nodes per sub-pattern (wt_range_walker); on the GPU 64 candidates of the first sub-pattern are followed at once, one per
+// lane, each by its own walks.
+#pragma once
+#include "device_rank.hpp"
+
+struct vlg_wtsa {
+    uint64_t n_text = 0, n_vals = 0;       // symbols; suffix-array entries (n_text + 1)
+    uint32_t sym_bytes = 1, levels = 0;
+    uint64_t nb = 0;                       // super-blocks per level
+    vlg::Block* d_blocks = nullptr;        // [levels][nb]
+    void* d_text = nullptr;                // n_text symbols
+};
+
+namespace {
+
+struct WtsaView {
+    const Block* blocks;
+    const void* text;
+    uint64_t nb, n_vals, n_text;
+    uint32_t levels, sym_bytes;
+};
+
+// ---- construction -------------------------------------------------------------------------------------------------------------
+// An integer text is sorted as a byte text: every symbol becomes its five base-255 digits + 1, most significant first -- no zero
+// byte, codes compare like the numbers, all codes equally long -- so the aligned suffixes of the byte text stand in the order of
+// the integer text's suffixes.
+__global__ void wtsa_expand_kernel(const uint32_t* __restrict__ syms, uint64_t n, uint8_t* __restrict__ bytes)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = syms[i];
+        uint8_t d[5];
+#pragma unroll
+        for (int j = 4; j >= 0; --j) { d[j] = (uint8_t)(v % 255u + 1u); v /= 255u; }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) bytes[5 * i + j] = d[j];
+    }
+}
+
+// keep the suffixes that start on a symbol: flags, then (after a scan) the compaction
+__global__ void wtsa_aligned_flags_kernel(const uint32_t* __restrict__ sa, uint64_t n, uint32_t* __restrict__ flag)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) flag[i] = sa[i] % 5u == 0 ? 1u : 0u;
+}
+__global__ void wtsa_aligned_compact_kernel(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ pos /* exclusive scan of the flags */,
+                                            uint64_t n, uint32_t* __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (sa[i] % 5u == 0) out[pos[i]] = sa[i] / 5u;
+}
+
+// stable-sort keys of a level: the top `bits` bits of every value (the arrangement of level l is the suffix array stably sorted by
+// the top l bits: wt_int.hpp:215-255)
+__global__ void wtsa_prefix_keys_kernel(const uint32_t* __restrict__ vals, uint64_t n, uint32_t shift, uint32_t* __restrict__ keys)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) keys[i] = vals[i] >> shift;
+}
+
+// data words of one level from its arrangement: one thread per 32-bit word; pops[b] += the word's popcount (the counts come from a scan)
+__global__ void wtsa_emit_kernel(const uint32_t* __restrict__ vals, uint64_t n, uint32_t bit, Block* __restrict__ blocks, uint64_t nb,
+                                 uint32_t* __restrict__ pops)
+{
+    const uint64_t total = nb * 7;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t blk = g / 7;
+        const uint32_t w = (uint32_t)(g % 7);
+        const uint64_t first = blk * kBlockBits + 32ull * w;
+        uint32_t word = 0;
+        if (first < n) {
+            const uint32_t m = n - first < 32 ? (uint32_t)(n - first) : 32u;
+            for (uint32_t j = 0; j < m; ++j) word |= ((vals[first + j] >> bit) & 1u) << j;
+        }
+        blocks[blk].w[w] = word;
+        if (word) atomicAdd(&pops[blk], (uint32_t)__popc(word));
+    }
+}
+__global__ void wtsa_counts_kernel(Block* __restrict__ blocks, const uint32_t* __restrict__ before, uint64_t nb)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) blocks[b].cnt = before[b];
+}
+
+// ---- the two walks ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t level_rank(const WtsaView& w, uint32_t base, uint64_t i) { return (uint32_t)node_rank1(w.blocks, base, i); }
+
+// kQuantile false: number of values < xq among SA[l, l + len); true: the xq-th smallest of them (0-based, xq < len)
+template <bool kQuantile>
+__device__ __forceinline__ uint64_t wtsa_walk(const WtsaView& w, uint64_t l, uint64_t len, uint64_t xq)
+{
+    if (!kQuantile && (w.levels < 64 ? (xq >> w.levels) != 0 : false)) return len;    // beyond every value
+    uint64_t b = 0, sz = w.n_vals, i = l, j = l + len, acc = 0;
+    for (uint32_t lvl = 0; lvl < w.levels; ++lvl) {
+        const uint32_t base = (uint32_t)(lvl * w.nb);
+        const uint32_t rb = level_rank(w, base, b), ri = level_rank(w, base, b + i), rj = level_rank(w, base, b + j),
+                       rn = level_rank(w, base, b + sz);
+        const uint64_t ones_i = ri - rb, ones_j = rj - rb, ones_n = rn - rb;
+        const uint64_t zi = i - ones_i, zj = j - ones_j, zeros_n = sz - ones_n;
+        bool right;
+        if (kQuantile) {
+            const uint64_t z = zj - zi;
+            right = xq >= z;
+            if (right) { xq -= z; acc |= 1ull << (w.levels - 1 - lvl); }
+        } else {
+            right = (xq >> (w.levels - 1 - lvl)) & 1;
+            if (right) acc += zj - zi;
+        }
+        if (right) { i = ones_i; j = ones_j; b += zeros_n; sz = ones_n; }
+        else { i = zi; j = zj; sz = zeros_n; }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ int64_t wtsa_symbol(const WtsaView& w, uint64_t p)
+{
+    if (p >= w.n_text) return -1;                                   // the sentinel is smaller than every symbol
+    return w.sym_bytes == 1 ? (int64_t)reinterpret_cast<const uint8_t*>(w.text)[p] : (int64_t)reinterpret_cast<const uint32_t*>(w.text)[p];
+}
+
+__global__ void __launch_bounds__(256) wtsa_sa_kernel(WtsaView w, const uint64_t* __restrict__ idx, uint64_t* __restrict__ out, uint64_t count)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (uint64_t)gridDim.x * blockDim.x)
+        out[t] = idx[t] < w.n_vals ? wtsa_walk<true>(w, idx[t], 1, 0) : ~0ull;
+}
+
+// forward_search (suffix_array_algorithm.hpp:48-112): binary search on the suffix array, every probe one access + one comparison
+// of the pattern with the text.  One lane per sub-pattern.
+__global__ void __launch_bounds__(256) wtsa_ranges_kernel(WtsaView w, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off,
+                                                          uint64_t n_pat, uint64_t* __restrict__ sp, uint64_t* __restrict__ len)
+{
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pat; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t m = (off[p + 1] - off[p]) / w.sym_bytes;
+        const uint8_t* pat = blob + off[p];
+        auto cmp = [&](uint64_t s) -> int {                         // suffix s against the pattern: -1 smaller, 0 has it as a prefix, +1 greater
+            for (uint64_t t = 0; t < m; ++t) {
+                const int64_t c = wtsa_symbol(w, s + t);
+                const int64_t x = w.sym_bytes == 1 ? (int64_t)pat[t] : (int64_t)reinterpret_cast<const uint32_t*>(pat)[t];
+                if (c != x) return c < x ? -1 : 1;
+            }
+            return 0;
+        };
+        uint64_t lo = 0, hi = w.n_vals;
+        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (cmp(wtsa_walk<true>(w, mid, 1, 0)) < 0) lo = mid + 1; else hi = mid; }
+        const uint64_t first = lo;
+        hi = w.n_vals;
+        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (cmp(wtsa_walk<true>(w, mid, 1, 0)) <= 0) lo = mid + 1; else hi = mid; }
+        sp[p] = first;
+        len[p] = lo - first;
+    }
+}
+
+// ---- the lazy search ----------------------------------------------------------------------------------------------------------------
+// Semantics: SURVEY.md Appendix C (what vlg_iterator yields, include/sdsl/vlg_index.hpp:227-291) -- the left-most, lazy,
+// non-overlapping tuples.  A wave owns a query.  64 consecutive elements of the first list (by rank: quantile) are the candidates
+// of a round, one per lane; each lane looks for the least chain through the other lists by depth-first search (the pointers of
+// the reference only ever move forward, so the first chain found from a candidate is the tuple the reference reports for it);
+// a list that runs out ends the query for this and every later candidate, as in the reference ("stop entirely").  The
+// non-overlap rule is then applied to the round's 64 outcomes in order.
+struct WQuery { uint32_t k, sub0; uint64_t end_len, out_first, out_tuple; };
+
+template <bool kEmit>
+__global__ void __launch_bounds__(64) wtsa_search_kernel(WtsaView w, const uint64_t* __restrict__ sp, const uint64_t* __restrict__ len,
+                                                         const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi,
+                                                         const WQuery* __restrict__ qs, uint32_t nq, uint64_t max_matches,
+                                                         unsigned long long* __restrict__ counts, uint64_t* __restrict__ out_first,
+                                                         uint64_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
+{
+    extern __shared__ uint32_t s_dyn[];                            // [2][k][64]: rank and value of the chain element at every level, per lane
+    const uint32_t qi = blockIdx.x, lane = threadIdx.x;
+    if (qi >= nq) return;
+    const WQuery Q = qs[qi];
+    const uint32_t k = Q.k;
+    if (k == 0) { if (!kEmit && lane == 0) counts[qi] = 0; return; }
+    uint32_t* s_rank = s_dyn;
+    uint32_t* s_val = s_dyn + (size_t)k * 64;
+    bool empty = false;
+    for (uint32_t i = 0; i < k; ++i) empty |= len[Q.sub0 + i] == 0;          // vlg_index.hpp:315-316: an empty range ends it at once
+    const uint64_t l0 = sp[Q.sub0], n0 = empty ? 0 : len[Q.sub0];
+    uint64_t p0 = 0, cur_end = 0, emitted = 0;
+    unsigned long long sum = 0;
+    bool stop = false;
+    while (p0 < n0 && !stop) {
+        const uint64_t cand = p0 + lane;
+        const bool valid = cand < n0;
+        const uint64_t x0 = valid ? wtsa_walk<true>(w, l0, n0, cand) : 0;
+        s_val[lane] = (uint32_t)x0;
+        // ---- depth-first search of the least chain from x0 -------------------------------------------------------------------------
+        uint32_t level = 1;
+        bool done = !valid || k == 1, feasible = valid && k == 1, hard = false, fresh = true;
+        uint64_t prev = x0;
+        while (__any(!done)) {
+            if (!done) {
+                const uint32_t s = Q.sub0 + level;
+                const uint64_t li = sp[s], ni = len[s];
+                uint64_t c;
+                if (fresh) {
+                    const uint64_t from = prev + lo[s] < prev ? ~0ull : prev + lo[s];
+                    c = wtsa_walk<false>(w, li, ni, from);                  // rank of the first element at or after prev + lo
+                } else c = (uint64_t)s_rank[level * 64 + lane] + 1;
+                if (c >= ni) { hard = true; done = true; }                  // the list has run out: nothing more for this query
+                else {
+                    const uint64_t v = wtsa_walk<true>(w, li, ni, c);
+                    const uint64_t limit = prev + hi[s] < prev ? ~0ull : prev + hi[s];
+                    if (v > limit) {                                        // beyond the window: the element one level up leads nowhere
+                        --level;
+                        if (level == 0) done = true;
+                        else { fresh = false; prev = level == 1 ? x0 : (uint64_t)s_val[(level - 1) * 64 + lane]; }
+                    } else {
+                        s_rank[level * 64 + lane] = (uint32_t)c;
+                        s_val[level * 64 + lane] = (uint32_t)v;
+                        if (level + 1 == k) { feasible = true; done = true; }
+                        else { ++level; prev = v; fresh = true; }
+                    }
+                }
+            }
+        }
+        // ---- non-overlap over the round's outcomes, in candidate order ----------------------------------------------------------------
+        const uint64_t last = k == 1 ? x0 : (uint64_t)s_val[(k - 1) * 64 + lane];
+        const uint64_t my_end = last + Q.end_len;
+        const unsigned long long hard_mask = __ballot(hard);
+        const unsigned long long before_hard = hard_mask ? ((1ull << (__ffsll((long long)hard_mask) - 1)) - 1ull) : ~0ull;
+        unsigned long long todo = __ballot(feasible) & before_hard, taken = 0;
+        while (todo && (max_matches == 0 || emitted + (uint64_t)__popcll(taken) < max_matches)) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint64_t xj = __shfl(x0, j);
+            if (xj >= cur_end) { taken |= 1ull << j; cur_end = __shfl(my_end, j); }
+        }
+        if ((taken >> lane) & 1) {
+            const uint64_t at = emitted + (uint64_t)__popcll(taken & ((1ull << lane) - 1ull));
+            sum += x0;
+            if (kEmit) {
+                out_first[Q.out_first + at] = x0;
+                if (out_tuples) {
+                    uint64_t* tp = out_tuples + Q.out_tuple + at * k;
+                    tp[0] = x0;
+                    for (uint32_t i = 1; i < k; ++i) tp[i] = s_val[i * 64 + lane];
+                }
+            }
+        }
+        emitted += (uint64_t)__popcll(taken);
+        if (hard_mask || (max_matches && emitted >= max_matches)) stop = true;
+        // the next round starts behind these candidates, or at the first element that does not overlap the last match
+        p0 += 64;
+        const uint64_t x_last = __shfl(x0, 63);
+        if (!stop && p0 < n0 && cur_end > x_last) {
+            const uint64_t c = wtsa_walk<false>(w, l0, n0, cur_end);
+            p0 = c > p0 ? c : p0;
+        }
+    }
+    if (!kEmit && lane == 0) counts[qi] = emitted;
+    if (kEmit && checksum) {
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+        if (lane == 0 && sum) atomicAdd(checksum, sum);
+    }
+}
+
+WtsaView wtsa_view(const vlg_wtsa* x) { return WtsaView{x->d_blocks, x->d_text, x->nb, x->n_vals, x->n_text, x->levels, x->sym_bytes}; }
+
+}  // namespace
+
+extern "C" void vlg_wtsa_destroy(vlg_wtsa* x)
+{
+    if (!x) return;
+    if (x->d_blocks) (void)hipFree(x->d_blocks);
+    if (x->d_text) (void)hipFree(x->d_text);
+    delete x;
+}
+
+extern "C" vlg_status vlg_wtsa_build(const void* h_text, uint64_t n_symbols, uint32_t symbol_bytes, vlg_wtsa** out)
+{
+    if (!out || (n_symbols && !h_text)) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    if (symbol_bytes != 1 && symbol_bytes != 4) return fail(VLG_E_INVALID, "symbol_bytes must be 1 or 4");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VLG_E_NO_DEVICE, "no HIP device available (the VLG library has no CPU fallback)");
+    const uint64_t byte_len = n_symbols * (symbol_bytes == 1 ? 1 : 5);
+    if (byte_len >= 0xFFFFFFF0ull) return fail(VLG_E_UNSUPPORTED, "text too long for the 32-bit suffix array of this index");
+    release_cached_device_memory();
+    vlg_wtsa* x = new vlg_wtsa();
+    x->n_text = n_symbols; x->n_vals = n_symbols + 1; x->sym_bytes = symbol_bytes;
+    x->levels = std::max(1u, bit_width64(n_symbols));               // values 0..n_symbols
+    x->nb = x->n_vals / kBlockBits + 1;
+    uint8_t* d_bytes = nullptr;
+    uint32_t *d_sa = nullptr, *d_a = nullptr, *d_b = nullptr, *d_ka = nullptr, *d_kb = nullptr, *d_pops = nullptr;
+    void* d_tmp = nullptr;
+    auto grid = [](uint64_t n) { return dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 16384))); };
+    auto run = [&]() -> vlg_status {
+        VLG_HIP_TRY(hipMalloc(&x->d_text, std::max<uint64_t>(n_symbols * symbol_bytes, 16)));
+        if (n_symbols) VLG_HIP_TRY(hipMemcpy(x->d_text, h_text, n_symbols * symbol_bytes, hipMemcpyHostToDevice));
+        // ---- suffix array of text + sentinel (the sorter of the FM-index builder) -----------------------------------------------------
+        VLG_HIP_TRY(hipMalloc((void**)&d_sa, (byte_len + 1) * 4));
+        if (symbol_bytes == 1) {
+            if (vlg_status st = vlg_suffix_array_device((const uint8_t*)x->d_text, n_symbols, d_sa, nullptr)) return st;
+        } else {
+            VLG_HIP_TRY(hipMalloc((void**)&d_bytes, std::max<uint64_t>(byte_len, 16)));
+            hipLaunchKernelGGL(wtsa_expand_kernel, grid(n_symbols), dim3(256), 0, nullptr, (const uint32_t*)x->d_text, n_symbols, d_bytes);
+            VLG_HIP_TRY(hipGetLastError());
+            if (vlg_status st = vlg_suffix_array_device(d_bytes, byte_len, d_sa, nullptr)) return st;
+            (void)hipFree(d_bytes); d_bytes = nullptr;
+            // the suffixes that start on a symbol, in order
+            uint32_t *d_flag = nullptr, *d_pos = nullptr, *d_out = nullptr;
+            const uint64_t nb5 = byte_len + 1;
+            VLG_HIP_TRY(hipMalloc((void**)&d_flag, nb5 * 4));
+            VLG_HIP_TRY(hipMalloc((void**)&d_pos, nb5 * 4));
+            VLG_HIP_TRY(hipMalloc((void**)&d_out, x->n_vals * 4));
+            hipLaunchKernelGGL(wtsa_aligned_flags_kernel, grid(nb5), dim3(256), 0, nullptr, d_sa, nb5, d_flag);
+            size_t tb = 0;
+            VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_flag, d_pos, 0u, nb5, rocprim::plus<uint32_t>(), nullptr));
+            void* t2 = nullptr;
+            VLG_HIP_TRY(hipMalloc(&t2, tb + 16));
+            hipError_t e = rocprim::exclusive_scan(t2, tb, d_flag, d_pos, 0u, nb5, rocprim::plus<uint32_t>(), nullptr);
+            if (e == hipSuccess) hipLaunchKernelGGL(wtsa_aligned_compact_kernel, grid(nb5), dim3(256), 0, nullptr, d_sa, d_pos, nb5, d_out);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            (void)hipFree(t2); (void)hipFree(d_flag); (void)hipFree(d_pos); (void)hipFree(d_sa);
+            d_sa = d_out;
+            VLG_HIP_TRY(e);
+        }
+        // ---- the tree, one level at a time: emit the bits of the current arrangement, then sort stably by one more bit of prefix ---------
+        const uint64_t n = x->n_vals;
+        VLG_HIP_TRY(hipMalloc((void**)&x->d_blocks, (uint64_t)x->levels * x->nb * sizeof(Block)));
+        VLG_HIP_TRY(hipMalloc((void**)&d_a, n * 4));
+        VLG_HIP_TRY(hipMalloc((void**)&d_b, n * 4));
+        VLG_HIP_TRY(hipMalloc((void**)&d_ka, n * 4));
+        VLG_HIP_TRY(hipMalloc((void**)&d_kb, n * 4));
+        VLG_HIP_TRY(hipMalloc((void**)&d_pops, (x->nb + 1) * 4));
+        size_t sort_tb = 0, scan_tb = 0;
+        VLG_HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_tb, d_ka, d_kb, d_a, d_b, n, 0, 32, nullptr));
+        VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tb, d_pops, d_pops, 0u, x->nb, rocprim::plus<uint32_t>(), nullptr));
+        VLG_HIP_TRY(hipMalloc(&d_tmp, std::max(sort_tb, scan_tb) + 16));
+        VLG_HIP_TRY(hipMemcpy(d_a, d_sa, n * 4, hipMemcpyDeviceToDevice));
+        uint32_t* cur = d_a;
+        uint32_t* other = d_b;
+        for (uint32_t lvl = 0; lvl < x->levels; ++lvl) {
+            Block* lb = x->d_blocks + (uint64_t)lvl * x->nb;
+            VLG_HIP_TRY(hipMemsetAsync(d_pops, 0, (x->nb + 1) * 4, nullptr));
+            hipLaunchKernelGGL(wtsa_emit_kernel, grid(x->nb * 7), dim3(256), 0, nullptr, cur, n, x->levels - 1 - lvl, lb, x->nb, d_pops);
+            size_t tb = scan_tb;
+            VLG_HIP_TRY(rocprim::exclusive_scan(d_tmp, tb, d_pops, d_pops, 0u, x->nb, rocprim::plus<uint32_t>(), nullptr));
+            hipLaunchKernelGGL(wtsa_counts_kernel, grid(x->nb), dim3(256), 0, nullptr, lb, d_pops, x->nb);
+            VLG_HIP_TRY(hipGetLastError());
+            if (lvl + 1 < x->levels) {                              // arrangement of the next level: stable by the top lvl + 1 bits
+                hipLaunchKernelGGL(wtsa_prefix_keys_kernel, grid(n), dim3(256), 0, nullptr, cur, n, x->levels - 1 - lvl, d_ka);
+                tb = sort_tb;
+                VLG_HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tb, d_ka, d_kb, cur, other, n, 0, lvl + 1, nullptr));
+                std::swap(cur, other);
+            }
+        }
+        VLG_HIP_TRY(hipDeviceSynchronize());
+        return VLG_OK;
+    };
+    vlg_status st = run();
+    for (void* p : {(void*)d_bytes, (void*)d_sa, (void*)d_a, (void*)d_b, (void*)d_ka, (void*)d_kb, (void*)d_pops, d_tmp}) if (p) (void)hipFree(p);
+    if (st) { vlg_wtsa_destroy(x); return st; }
+    *out = x;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_wtsa_get_info(const vlg_wtsa* x, vlg_wtsa_info* info)
+{
+    if (!x || !info) return fail(VLG_E_INVALID, "null argument");
+    info->n = x->n_vals; info->symbol_bytes = x->sym_bytes; info->levels = x->levels; info->blocks_per_level = x->nb;
+    info->hbm_bytes = x->n_text * x->sym_bytes + (uint64_t)x->levels * x->nb * sizeof(Block);
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_wtsa_sa_batch(const vlg_wtsa* x, const uint64_t* d_i, uint64_t* d_out, uint64_t count, void* stream)
+{
+    if (!x || (count && (!d_i || !d_out))) return fail(VLG_E_INVALID, "null argument");
+    if (!count) return VLG_OK;
+    hipLaunchKernelGGL(wtsa_sa_kernel, dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream, wtsa_view(x), d_i, d_out, count);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+
+namespace {
+vlg_status wtsa_ranges_device(const vlg_wtsa* x, const vlg_queries* q, uint64_t* d_sp, uint64_t* d_len, hipStream_t st)
+{
+    if (q->sym_bytes != x->sym_bytes) return fail(VLG_E_INVALID, "the query batch and the index have different alphabets");
+    if (!q->nsub) return VLG_OK;
+    hipLaunchKernelGGL(wtsa_ranges_kernel, dim3(grid_for(q->nsub, 4096)), dim3(256), 0, st, wtsa_view(x), q->d_blob, q->d_suboff, q->nsub, d_sp, d_len);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+}  // namespace
+
+extern "C" vlg_status vlg_wtsa_ranges(const vlg_wtsa* x, const vlg_queries* q, uint64_t* h_sp, uint64_t* h_ep, void* stream)
+{
+    if (!x || !q || (q->nsub && (!h_sp || !h_ep))) return fail(VLG_E_INVALID, "null argument");
+    if (!q->nsub) return VLG_OK;
+    uint64_t* d = nullptr;
+    VLG_HIP_TRY(hipMalloc((void**)&d, 2 * q->nsub * 8));
+    std::vector<uint64_t> h(2 * q->nsub);
+    vlg_status s = wtsa_ranges_device(x, q, d, d + q->nsub, (hipStream_t)stream);
+    hipError_t e = hipSuccess;
+    if (!s) e = hipMemcpyAsync(h.data(), d, 2 * q->nsub * 8, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (!s && e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d);
+    if (s) return s;
+    VLG_HIP_TRY(e);
+    for (uint64_t i = 0; i < q->nsub; ++i) { h_sp[i] = h[i]; h_ep[i] = h[i] + h[q->nsub + i] - 1; }    // sp = ep + 1 when there is no occurrence
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_wtsa_search_batch(const vlg_wtsa* x, const vlg_queries* q, uint64_t max_matches, vlg_workspace* ws, vlg_result** out)
+{
+    if (!x || !q || !ws || !out) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    hipStream_t st = ws->stream;
+    const uint64_t nq = q->nq, nsub = q->nsub;
+    if (nq > 0xFFFFFFF0ull) return fail(VLG_E_UNSUPPORTED, "too many queries in one batch");
+    vlg_result* res = new vlg_result();
+    memset(&res->sum, 0, sizeof res->sum);
+    res->sum.n_queries = nq;
+    res->counts.assign(nq, 0);
+    res->k.resize(nq);
+    for (uint64_t i = 0; i < nq; ++i) res->k[i] = (uint32_t)(q->qsub[i + 1] - q->qsub[i]);
+    uint8_t* d_mem = nullptr;
+    ResultPiece piece;
+    piece.q0 = 0; piece.q1 = nq;
+    auto run = [&]() -> vlg_status {
+        if (!nq) { res->pieces.push_back(piece); return VLG_OK; }
+        // device scratch: ranges, gap bounds, query table, counts, checksum
+        const uint64_t bytes = (4 * (nsub + 1) + nq + 2) * 8 + (nq + 1) * sizeof(WQuery) + 1024;
+        VLG_HIP_TRY(hipMalloc((void**)&d_mem, bytes));
+        uint64_t* d_sp = (uint64_t*)d_mem;
+        uint64_t* d_len = d_sp + nsub + 1;
+        uint64_t* d_lo = d_len + nsub + 1;
+        uint64_t* d_hi = d_lo + nsub + 1;
+        unsigned long long* d_counts = (unsigned long long*)(d_hi + nsub + 1);
+        unsigned long long* d_chk = d_counts + nq;
+        WQuery* d_q = (WQuery*)(d_chk + 2);
+        svec<WQuery> hq(nq);
+        for (uint64_t i = 0; i < nq; ++i) hq[i] = WQuery{res->k[i], (uint32_t)q->qsub[i], q->end_len[i], 0, 0};
+        svec<uint64_t> hlo(q->lo.begin(), q->lo.end()), hhi(q->hi.begin(), q->hi.end());
+        if (nsub) {
+            VLG_HIP_TRY(hipMemcpyAsync(d_lo, hlo.data(), nsub * 8, hipMemcpyHostToDevice, st));
+            VLG_HIP_TRY(hipMemcpyAsync(d_hi, hhi.data(), nsub * 8, hipMemcpyHostToDevice, st));
+        }
+        VLG_HIP_TRY(hipMemcpyAsync(d_q, hq.data(), nq * sizeof(WQuery), hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemsetAsync(d_chk, 0, 16, st));
+        {
+            Timed t(ws, KS_BSEARCH, 0);
+            if (vlg_status s = wtsa_ranges_device(x, q, d_sp, d_len, st)) return s;
+        }
+        const size_t lds = (size_t)2 * std::max<uint32_t>(q->kmax, 1) * 64 * 4;
+        const WtsaView w = wtsa_view(x);
+        {
+            Timed t(ws, KS_JOIN_CHAIN, 0);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<false>), dim3((uint32_t)nq), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
+                               (uint32_t)nq, max_matches, d_counts, nullptr, nullptr, nullptr);
+        }
+        VLG_HIP_TRY(hipGetLastError());
+        svec<unsigned long long> counts(nq);
+        VLG_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, nq * 8, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipStreamSynchronize(st));
+        uint64_t M = 0, TV = 0;
+        for (uint64_t i = 0; i < nq; ++i) {
+            hq[i].out_first = M; hq[i].out_tuple = TV;
+            M += counts[i]; TV += ws->tuples ? counts[i] * hq[i].k : 0;
+            res->counts[i] = counts[i];
+        }
+        piece.matches = M; piece.tuple_vals = TV;
+        if (M) {
+            VLG_HIP_TRY(result_alloc(&piece.d_first, M * 8, &piece.first_bytes));
+            if (TV) VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * 8, &piece.tuple_bytes));
+            VLG_HIP_TRY(hipMemcpyAsync(d_q, hq.data(), nq * sizeof(WQuery), hipMemcpyHostToDevice, st));
+            Timed t(ws, KS_GATHER, 8ull * (M + TV));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<true>), dim3((uint32_t)nq), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
+                               (uint32_t)nq, max_matches, d_counts, piece.d_first, piece.d_tuples, d_chk);
+            VLG_HIP_TRY(hipGetLastError());
+        }
+        unsigned long long chk = 0;
+        VLG_HIP_TRY(hipMemcpyAsync(&chk, d_chk, 8, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipStreamSynchronize(st));
+        res->pieces.push_back(piece);
+        res->sum.n_matches = M;
+        res->sum.n_tuple_values = TV;
+        res->sum.checksum = chk;
+        res->sum.n_chunks = 1;
+        return VLG_OK;
+    };
+    vlg_status stt;
+    {
+        HostPoolScope staging(&ws->host);
+        try { stt = run(); }
+        catch (const std::bad_alloc&) { stt = fail(VLG_E_OOM, "out of host memory (pinned staging)"); }
+    }
+    if (d_mem) (void)hipFree(d_mem);
+    if (stt) { if (piece.d_first && res->pieces.empty()) result_cache().give(piece.d_first, piece.first_bytes);
+               if (piece.d_tuples && res->pieces.empty()) result_cache().give(piece.d_tuples, piece.tuple_bytes);
+               vlg_result_destroy(res); return stt; }
+    *out = res;
+    return VLG_OK;
+}

@@ -346,6 +346,73 @@ class VlgIndex:
         return SearchResult(h, q.ks)
 
 
+class WtsaIndex:
+    """sdsl::vlg_index<alphabet_tag, wt_int<>> in HBM: the text + a wavelet tree over its suffix array, searched lazily
+    (include/sdsl/vlg_index.hpp:109-373).  `text`: bytes / uint8 array (byte alphabet) or a uint32 array (integer alphabet)."""
+
+    def __init__(self, text):
+        if isinstance(text, np.ndarray) and text.dtype != np.uint8:
+            t = np.ascontiguousarray(text, dtype=np.uint32)
+            self.symbol_bytes = 4
+        else:
+            t = _u8(text)
+            self.symbol_bytes = 1
+        h = C.c_void_p()
+        check(lib().vlg_wtsa_build(t.ctypes.data if len(t) else None, len(t), self.symbol_bytes, C.byref(h)))
+        self._h = h
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vlg_wtsa_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def info(self):
+        i = capi.WtsaInfo()
+        check(lib().vlg_wtsa_get_info(self._h, C.byref(i)))
+        return {k: int(getattr(i, k)) for k, _ in capi.WtsaInfo._fields_}
+
+    def queries(self, regexps):
+        """a parsed batch for this index's alphabet (integer alphabet: sub-patterns are whitespace-separated decimals)"""
+        if isinstance(regexps, Queries):
+            return regexps
+        if self.symbol_bytes == 1:
+            return Queries(regexps)
+        raws = [r.encode("latin-1") if isinstance(r, str) else bytes(r) for r in regexps]
+        off = np.zeros(len(raws) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in raws])
+        q = Queries.__new__(Queries)
+        h = C.c_void_p()
+        check(lib().vlg_queries_parse_int(b"".join(raws), off.ctypes.data, len(raws), None, C.byref(h)))
+        q._h, q.n, q.status = h, len(raws), np.zeros(len(raws), dtype=np.int32)
+        return q
+
+    def sa_device(self, d_idx_ptr, d_out_ptr, count, stream=None):
+        check(lib().vlg_wtsa_sa_batch(self._h, d_idx_ptr, d_out_ptr, count, stream))
+
+    def ranges(self, queries):
+        """forward_search of every sub-pattern -> (sp[], ep[]) suffix-array ranges (sp = ep + 1: no occurrence)"""
+        q = self.queries(queries)
+        nsub = int(lib().vlg_queries_subpatterns(q._h))
+        sp, ep = np.zeros(max(nsub, 1), np.uint64), np.zeros(max(nsub, 1), np.uint64)
+        check(lib().vlg_wtsa_ranges(self._h, q._h, sp.ctypes.data, ep.ctypes.data, None))
+        return sp[:nsub], ep[:nsub]
+
+    def search(self, queries, max_matches=0, workspace=None):
+        """sdsl::locate(idx, query) for a batch, lazily: at most max_matches matches per query (0 = all)."""
+        q = self.queries(queries)
+        if workspace is None:
+            if self._ws is None:
+                self._ws = Workspace()
+            workspace = self._ws
+        h = C.c_void_p()
+        check(lib().vlg_wtsa_search_batch(self._h, q._h, int(max_matches), workspace._h, C.byref(h)))
+        return SearchResult(h, q.ks)
+
+
 def join_batch(d_lists_ptr, list_off, join_list, lo, hi, end_len, workspace, ks=None):
     """vlg_join_batch: the gap-bounded merge join (index_sasearch.hpp:85-116) over caller-provided sorted u64 lists in HBM.
     list_off[n_lists+1], join_list[n_joins+1], lo/hi[n_lists], end_len[n_joins] are host arrays.  -> SearchResult"""
