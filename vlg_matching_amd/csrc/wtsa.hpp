@@ -13,8 +13,8 @@
 //   quantile(l, len, q)     the q-th smallest of SA[l, l + len)
 // so that "the first occurrence of sub-pattern i at or after position p" = quantile(count_less(p)): the sorted occurrence list of a
 // sub-pattern is read by rank without ever being located or sorted.  The reference walks the same tree node by node with a cache of
-// expanded nodes per sub-pattern (wt_range_walker); on the GPU 64 candidates of the first sub-pattern are followed at once, one per
-// lane, each by its own walks.
+// expanded nodes per sub-pattern (wt_range_walker); on the GPU a lane owns a query, and a batch of 10^5 queries keeps 10^5
+// independent walks in flight.
 #pragma once
 #include "device_rank.hpp"
 
@@ -163,104 +163,94 @@ __global__ void __launch_bounds__(256) wtsa_ranges_kernel(WtsaView w, const uint
 
 // ---- the lazy search ----------------------------------------------------------------------------------------------------------------
 // Semantics: SURVEY.md Appendix C (what vlg_iterator yields, include/sdsl/vlg_index.hpp:227-291) -- the left-most, lazy,
-// non-overlapping tuples.  A wave owns a query.  64 consecutive elements of the first list (by rank: quantile) are the candidates
-// of a round, one per lane; each lane looks for the least chain through the other lists by depth-first search (the pointers of
-// the reference only ever move forward, so the first chain found from a candidate is the tuple the reference reports for it);
-// a list that runs out ends the query for this and every later candidate, as in the reference ("stop entirely").  The
-// non-overlap rule is then applied to the round's 64 outcomes in order.
+// non-overlapping tuples.  One lane owns a query and keeps the reference's k monotone pointers, as RANKS into the sorted
+// occurrence lists that exist only implicitly in the tree: `count_less` moves a pointer to the first element at or after a
+// position, `quantile` reads the element under it.  Where the reference steps a pointer one element at a time (relax: next_right,
+// vlg_index.hpp:233-249), the lane leaps: when the element of list i under the pointer lies beyond the window of the element of
+// list i-1, every element of list i-1 before  v_i - hi_i  fails the same way, so pointer i-1 goes straight to the first element at
+// or after that position.  A pointer that runs off its list ends the query ("stop entirely").  The work of a query is a few
+// walks per match or failed alignment, whatever the lengths of its lists -- and it stops after max_matches matches.
 struct WQuery { uint32_t k, sub0; uint64_t end_len, out_first, out_tuple; };
 
 template <bool kEmit>
 __global__ void __launch_bounds__(64) wtsa_search_kernel(WtsaView w, const uint64_t* __restrict__ sp, const uint64_t* __restrict__ len,
                                                          const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi,
-                                                         const WQuery* __restrict__ qs, uint32_t nq, uint64_t max_matches,
+                                                         const WQuery* __restrict__ qs, uint32_t nq, uint32_t kmax, uint64_t max_matches,
                                                          unsigned long long* __restrict__ counts, uint64_t* __restrict__ out_first,
                                                          uint64_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
 {
-    extern __shared__ uint32_t s_dyn[];                            // [2][k][64]: rank and value of the chain element at every level, per lane
-    const uint32_t qi = blockIdx.x, lane = threadIdx.x;
-    if (qi >= nq) return;
-    const WQuery Q = qs[qi];
-    const uint32_t k = Q.k;
-    if (k == 0) { if (!kEmit && lane == 0) counts[qi] = 0; return; }
+    extern __shared__ uint32_t s_dyn[];                            // [2][kmax][64]: rank and value under every pointer, per lane
+    const uint32_t lane = threadIdx.x;
+    const uint64_t qi = (uint64_t)blockIdx.x * 64 + lane;
     uint32_t* s_rank = s_dyn;
-    uint32_t* s_val = s_dyn + (size_t)k * 64;
-    bool empty = false;
-    for (uint32_t i = 0; i < k; ++i) empty |= len[Q.sub0 + i] == 0;          // vlg_index.hpp:315-316: an empty range ends it at once
-    const uint64_t l0 = sp[Q.sub0], n0 = empty ? 0 : len[Q.sub0];
-    uint64_t p0 = 0, cur_end = 0, emitted = 0;
+    uint32_t* s_val = s_dyn + (size_t)kmax * 64;
+    WQuery Q{0, 0, 0, 0, 0};
+    if (qi < nq) Q = qs[qi];
+    const uint32_t k = Q.k;
+    bool fin = qi >= nq || k == 0;
+    for (uint32_t i = 0; i < k && !fin; ++i) fin = len[Q.sub0 + i] == 0;     // vlg_index.hpp:315-316: an empty range ends it at once
+    uint64_t emitted = 0;
     unsigned long long sum = 0;
-    bool stop = false;
-    while (p0 < n0 && !stop) {
-        const uint64_t cand = p0 + lane;
-        const bool valid = cand < n0;
-        const uint64_t x0 = valid ? wtsa_walk<true>(w, l0, n0, cand) : 0;
-        s_val[lane] = (uint32_t)x0;
-        // ---- depth-first search of the least chain from x0 -------------------------------------------------------------------------
-        uint32_t level = 1;
-        bool done = !valid || k == 1, feasible = valid && k == 1, hard = false, fresh = true;
-        uint64_t prev = x0;
-        while (__any(!done)) {
-            if (!done) {
-                const uint32_t s = Q.sub0 + level;
-                const uint64_t li = sp[s], ni = len[s];
-                uint64_t c;
-                if (fresh) {
-                    const uint64_t from = prev + lo[s] < prev ? ~0ull : prev + lo[s];
-                    c = wtsa_walk<false>(w, li, ni, from);                  // rank of the first element at or after prev + lo
-                } else c = (uint64_t)s_rank[level * 64 + lane] + 1;
-                if (c >= ni) { hard = true; done = true; }                  // the list has run out: nothing more for this query
-                else {
-                    const uint64_t v = wtsa_walk<true>(w, li, ni, c);
-                    const uint64_t limit = prev + hi[s] < prev ? ~0ull : prev + hi[s];
-                    if (v > limit) {                                        // beyond the window: the element one level up leads nowhere
-                        --level;
-                        if (level == 0) done = true;
-                        else { fresh = false; prev = level == 1 ? x0 : (uint64_t)s_val[(level - 1) * 64 + lane]; }
-                    } else {
-                        s_rank[level * 64 + lane] = (uint32_t)c;
-                        s_val[level * 64 + lane] = (uint32_t)v;
-                        if (level + 1 == k) { feasible = true; done = true; }
-                        else { ++level; prev = v; fresh = true; }
+    // pending walk: level `lv`; op 0 = count_less(key) -> rank, then always the quantile of that rank
+    uint32_t lv = 0;
+    bool need_count = false;                                       // false: the rank at lv is set, read its value
+    uint64_t key = 0;
+    uint32_t have = 0;                                             // levels (< 32 tracked; beyond: always recomputed) whose pointer holds a value
+    if (!fin) s_rank[lane] = 0;
+    while (__any(!fin)) {
+        if (!fin) {
+            const uint32_t s = Q.sub0 + lv;
+            const uint64_t li = sp[s], ni = len[s];
+            uint64_t r = s_rank[lv * 64 + lane];
+            if (need_count) r = wtsa_walk<false>(w, li, ni, key);         // (every key lies beyond the element under the pointer: it only moves forward)
+            if (r >= ni) fin = true;                                        // the list has run out: nothing more for this query
+            else {
+                const uint64_t v = wtsa_walk<true>(w, li, ni, r);
+                s_rank[lv * 64 + lane] = (uint32_t)r;
+                s_val[lv * 64 + lane] = (uint32_t)v;
+                if (lv < 32) have |= 1u << lv;
+                // ---- decide the next walk: no memory is touched in here except the lane's own pointers ------------------------------
+                for (;;) {
+                    const uint64_t cur = s_val[lv * 64 + lane];
+                    if (lv > 0) {
+                        const uint64_t prev = s_val[(lv - 1) * 64 + lane];
+                        const uint64_t h = hi[Q.sub0 + lv];
+                        if (cur > (prev + h < prev ? ~0ull : prev + h)) {
+                            // beyond the window of the element one list up: that pointer leaps to the first element that can reach cur
+                            const uint64_t reach = cur - h;                 // (cur > prev + h >= h)
+                            key = reach > prev + 1 ? reach : prev + 1;
+                            --lv; need_count = true;
+                            break;
+                        }
                     }
+                    if (lv + 1 == k) {                                      // a match: report it, then pull the first pointer behind it
+                        const uint64_t first = s_val[lane];
+                        sum += first;
+                        if (kEmit) {
+                            out_first[Q.out_first + emitted] = first;
+                            if (out_tuples) {
+                                uint64_t* tp = out_tuples + Q.out_tuple + emitted * k;
+                                for (uint32_t i = 0; i < k; ++i) tp[i] = s_val[i * 64 + lane];
+                            }
+                        }
+                        ++emitted;
+                        if (max_matches && emitted >= max_matches) { fin = true; break; }
+                        key = cur + Q.end_len;                              // vlg_index.hpp:254-266 (pull_forward)
+                        lv = 0; need_count = true;
+                        break;
+                    }
+                    // one list down: its pointer stays if it already stands at or behind the window's start
+                    ++lv;
+                    const uint64_t l = lo[Q.sub0 + lv];
+                    const uint64_t from = cur + l < cur ? ~0ull : cur + l;
+                    if (lv < 32 && ((have >> lv) & 1) && (uint64_t)s_val[lv * 64 + lane] >= from) continue;
+                    key = from; need_count = true;
+                    break;
                 }
             }
-        }
-        // ---- non-overlap over the round's outcomes, in candidate order ----------------------------------------------------------------
-        const uint64_t last = k == 1 ? x0 : (uint64_t)s_val[(k - 1) * 64 + lane];
-        const uint64_t my_end = last + Q.end_len;
-        const unsigned long long hard_mask = __ballot(hard);
-        const unsigned long long before_hard = hard_mask ? ((1ull << (__ffsll((long long)hard_mask) - 1)) - 1ull) : ~0ull;
-        unsigned long long todo = __ballot(feasible) & before_hard, taken = 0;
-        while (todo && (max_matches == 0 || emitted + (uint64_t)__popcll(taken) < max_matches)) {
-            const int j = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const uint64_t xj = __shfl(x0, j);
-            if (xj >= cur_end) { taken |= 1ull << j; cur_end = __shfl(my_end, j); }
-        }
-        if ((taken >> lane) & 1) {
-            const uint64_t at = emitted + (uint64_t)__popcll(taken & ((1ull << lane) - 1ull));
-            sum += x0;
-            if (kEmit) {
-                out_first[Q.out_first + at] = x0;
-                if (out_tuples) {
-                    uint64_t* tp = out_tuples + Q.out_tuple + at * k;
-                    tp[0] = x0;
-                    for (uint32_t i = 1; i < k; ++i) tp[i] = s_val[i * 64 + lane];
-                }
-            }
-        }
-        emitted += (uint64_t)__popcll(taken);
-        if (hard_mask || (max_matches && emitted >= max_matches)) stop = true;
-        // the next round starts behind these candidates, or at the first element that does not overlap the last match
-        p0 += 64;
-        const uint64_t x_last = __shfl(x0, 63);
-        if (!stop && p0 < n0 && cur_end > x_last) {
-            const uint64_t c = wtsa_walk<false>(w, l0, n0, cur_end);
-            p0 = c > p0 ? c : p0;
         }
     }
-    if (!kEmit && lane == 0) counts[qi] = emitted;
+    if (!kEmit && qi < nq) counts[qi] = emitted;
     if (kEmit && checksum) {
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
         if (lane == 0 && sum) atomicAdd(checksum, sum);
@@ -455,12 +445,14 @@ extern "C" vlg_status vlg_wtsa_search_batch(const vlg_wtsa* x, const vlg_queries
             Timed t(ws, KS_BSEARCH, 0);
             if (vlg_status s = wtsa_ranges_device(x, q, d_sp, d_len, st)) return s;
         }
-        const size_t lds = (size_t)2 * std::max<uint32_t>(q->kmax, 1) * 64 * 4;
+        const uint32_t kmax = std::max<uint32_t>(q->kmax, 1);
+        const size_t lds = (size_t)2 * kmax * 64 * 4;
+        const uint32_t wgs = (uint32_t)((nq + 63) / 64);
         const WtsaView w = wtsa_view(x);
         {
             Timed t(ws, KS_JOIN_CHAIN, 0);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<false>), dim3((uint32_t)nq), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
-                               (uint32_t)nq, max_matches, d_counts, nullptr, nullptr, nullptr);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<false>), dim3(wgs), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
+                               (uint32_t)nq, kmax, max_matches, d_counts, nullptr, nullptr, nullptr);
         }
         VLG_HIP_TRY(hipGetLastError());
         svec<unsigned long long> counts(nq);
@@ -478,8 +470,8 @@ extern "C" vlg_status vlg_wtsa_search_batch(const vlg_wtsa* x, const vlg_queries
             if (TV) VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * 8, &piece.tuple_bytes));
             VLG_HIP_TRY(hipMemcpyAsync(d_q, hq.data(), nq * sizeof(WQuery), hipMemcpyHostToDevice, st));
             Timed t(ws, KS_GATHER, 8ull * (M + TV));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<true>), dim3((uint32_t)nq), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
-                               (uint32_t)nq, max_matches, d_counts, piece.d_first, piece.d_tuples, d_chk);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<true>), dim3(wgs), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
+                               (uint32_t)nq, kmax, max_matches, d_counts, piece.d_first, piece.d_tuples, d_chk);
             VLG_HIP_TRY(hipGetLastError());
         }
         unsigned long long chk = 0;
