@@ -334,8 +334,38 @@ locate(a.{0,10}?a.{0,10}?a)=
 
 count(foo.{0,10}?bar)=0
 locate(foo.{0,10}?bar)=
+
+count(97 99 .{2,5}? 97 .{4,8}? 98)=1
+locate(97 99 .{2,5}? 97 .{4,8}? 98)=
+  1. occ starting at position 3
+     Subpattern positions: 3 10 18
+
+count(97 .{0,10}? 97 .{0,10}? 97)=2
+locate(97 .{0,10}? 97 .{0,10}? 97)=
+  1. occ starting at position 0
+     Subpattern positions: 0 3 5
+  2. occ starting at position 7
+     Subpattern positions: 7 10 15
+
+count(1337 .{0,10}? 42)=0
+locate(1337 .{0,10}? 42)=
 """
     assert out == want
+
+
+def test_cpp_example_lazy_iterator_on_a_file(V, oracle, tmp_path):
+    """vlg_matching_example <file> <query>: more matches than the iterator's first request (16), so it asks again (x4) on the way;
+    the printed tuples equal the oracle's."""
+    import subprocess
+    text = dna_text(4000, 77).tobytes()
+    (tmp_path / "t.txt").write_bytes(text)
+    q = "AC.{0,9}?G"
+    out = subprocess.run([_bin("vlg_matching_example"), str(tmp_path / "t.txt"), q], capture_output=True, text=True, check=True).stdout
+    want = oracle.Index.from_text(text).search(q).tolist()
+    assert len(want) > 100
+    assert ("count(%s)=%d" % (q, len(want))) in out
+    got = [[int(x) for x in l.split(":")[1].split()] for l in out.splitlines() if "Subpattern positions" in l]
+    assert got == want
 
 
 def test_cpp_driver_pipeline_matches_oracle(V, oracle, tmp_path):
