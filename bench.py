@@ -73,13 +73,16 @@ CLASSES = {
     "backward_search": ("backward_search_kernel", ["backward_search_kernel"], "32 B per wavelet-tree level of every rank (SURVEY 8d K2)"),
     "expand": ("expand_kernel", [], ""),
     "locate": ("sweep_step_kernel", ["sweep_step_kernel", "sweep_tail_kernel"], "32 B per tree level actually walked + one SA sample per occurrence (SURVEY 8d K3)"),
-    "locate_partition": ("sweep_partition_kernel", ["sweep_hist_kernel", "sweep_scatter_kernel", "sweep_partition_kernel"],
+    "locate_partition": ("rocprim radix_sort_pairs (u16 symbol key, u64 element): one 5-bit pass per round",
+                         ["rocprim:radix_sort_onesweep<unsigned_short,unsigned_long>"],
                          "per element of the round: key + value read once, written once (2 x 10 B)"),
     "locate_resolve": ("trail_resolve_kernel", ["trail_resolve_kernel", "trail_resolve_round_kernel"], "8 B record read + 4..8 B position written per occurrence"),
-    "sort": ("radix sort of (list, position) keys", ["sort_compose_kernel", "sort_narrow_kernel"], "one read + one write of every position (2 x 4 B); the radix passes in between are overhead"),
+    "sort": ("rocprim radix_sort_keys on (list, position) keys + compose / narrow",
+             ["sort_compose_kernel", "sort_narrow_kernel", "rocprim:radix_sort_onesweep<unsigned_long,empty_type>"],
+             "one read + one write of every position (2 x 4 B); the radix passes in between are overhead"),
     "filter_pivot": ("filter_pivot_kernel", ["filter_pivot_kernel"], "16 B per (pivot element, level): two lower bounds"),
     "filter_pass": ("filter_pass_kernel", ["filter_pass_kernel"], "4 B per list element streamed"),
-    "filter_compact": ("filter_compact_kernel", ["filter_compact_kernel", "filter_count_runs_kernel", "filter_gather_counts_kernel"],
+    "filter_compact": ("filter_compact_kernel", ["filter_compact_kernel", "filter_count_runs_kernel", "filter_gather_counts_kernel", "rocprim:scan<unsigned_int>"],
                        "activity bits read + every survivor read and written (2 x 4 B)"),
     "join_init": ("join_init_kernel", ["join_init_kernel"], ""),
     "join_link": ("join_link_kernel", ["join_link_kernel"], "8 B per join slot (SURVEY 8d K5: list element read + link state written)"),
@@ -91,7 +94,7 @@ CLASSES = {
 }
 
 
-def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=1200000, budget_s=45.0, min_queries=100):
+def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=1600000, budget_s=45.0, min_queries=100):
     """The CPU oracle (restatement of the reference path, reference data layout) timed on this host, ONE thread (the
     reference is single-threaded, gm_search.cpp:91), on a bounded seeded sample of the same query batch; then the same
     code on nproc threads over disjoint query shards, for disclosure."""
@@ -113,7 +116,7 @@ def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=1200000, budget_s=
     # each capped so that no single heavy query eats the budget (a 10^6-occurrence query costs 40 s on one core)
     stats = np.zeros(4, dtype=np.uint64)
     done, dt, remaining = 0, 0.0, budget_occ
-    per_query_cap = budget_occ // min_queries * 4
+    per_query_cap = budget_occ // min_queries * 2
     for qi in order:
         need = need_of(int(qi))
         if need > remaining or need > per_query_cap:
@@ -222,6 +225,7 @@ def main():
     ap.add_argument("--bv", choices=["plain", "rrr"], default=None, help="wavelet-tree bit-vectors (default: rrr for C5, else plain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling region")
+    ap.add_argument("--strong-sharding", choices=["affinity", "work"], default="affinity")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (parse + H2D + search + D2H) region")
     ap.add_argument("--tuples", action="store_true", help="also materialise every sub-pattern position of every match (sdsl::locate output)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -404,11 +408,15 @@ def main():
     strong = None
     if world > 1 and not args.no_strong:
         if rank == 0:
-            w = idx.query_weights(queries)                     # sum of SA-interval sizes per query: one backward-search pass
-            cuts = vdist.shard_by_work(w, world)
-            slices = [queries[b:e] for b, e in cuts]
+            if args.strong_sharding == "affinity":             # queries that share their longest list stay together
+                l_, r_, q_all = idx.intervals(queries)
+                sets = vdist.shard_by_affinity(l_, r_, q_all.subpattern_range(), world)
+                slices = [[queries[i] for i in st_] for st_ in sets]
+            else:
+                w = idx.query_weights(queries)                 # sum of SA-interval sizes per query: one backward-search pass
+                slices = [queries[b:e] for b, e in vdist.shard_by_work(w, world)]
         else:
-            cuts, slices = None, None
+            slices = None
         mine = [None]
         dist.scatter_object_list(mine, slices, src=0)
         qs = Queries(mine[0])
@@ -421,9 +429,11 @@ def main():
         strong = {"scaling": "strong", "value": tq * args.steps / dt_s, "unit": "queries/s", "ms_per_step": dt_s / args.steps * 1e3,
                   "queries": tq, "matches": tm, "checksum": chk, "located_occ_per_step_all_ranks": tocc, "logical_occ_per_step": tlog,
                   "per_rank": [{"ms_per_step": p[0], "queries": int(p[1]), "located_occ": int(p[2]), "logical_occ": int(p[3])} for p in pr],
-                  "note": "the 1-GPU batch sharded by sum of SA-interval sizes; each rank locates the distinct intervals of its own "
-                          "slice, so occurrences shared between slices are located once per rank that needs them (located_occ summed "
-                          "over ranks > the 1-GPU figure): strong scaling of this batch is sub-linear by construction"}
+                  "sharding": args.strong_sharding,
+                  "note": "the 1-GPU batch sharded; each rank locates the distinct intervals of its own queries, so a list that queries "
+                          "on several ranks share is located once per such rank (located_occ summed over ranks >= the 1-GPU figure). "
+                          "'affinity' keeps the queries that share their longest list on one rank (vlg_matching_amd.dist.shard_by_affinity); "
+                          "'work' cuts contiguous slices of equal sum of SA-interval sizes"}
         if rank == 0:
             # same batch as the weak region of rank 0: totals must agree
             assert tq == s["n_queries"] and tm == s["n_matches"] and chk == s["checksum"], (tq, tm, chk, s)

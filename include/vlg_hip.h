@@ -242,6 +242,10 @@ vlg_status vlg_queries_create(const uint8_t* h_blob, const uint64_t* h_suboff, c
  * backward-search pass, h_occ[s] = r + 1 - l (vlg_queries_subpatterns(q) entries, in batch order).  What SURVEY.md 8(e) shards
  * a batch by: the sum over a query's sub-patterns estimates its locate + join work. */
 vlg_status vlg_queries_occurrences(const vlg_index* idx, const vlg_queries* q, uint64_t* h_occ, void* stream);
+/* The same pass, returning the SA interval [l, r] of every sub-pattern as backward_search leaves it (r + 1 - l occurrences;
+ * suffix_array_algorithm.hpp:305-326).  Equal intervals are the same occurrence list: a host that shards a batch can keep the
+ * queries that share their longest list on one GPU, so that the list is located once (vlg_matching_amd.dist.shard_by_affinity). */
+vlg_status vlg_queries_intervals(const vlg_index* idx, const vlg_queries* q, uint64_t* h_l, uint64_t* h_r, void* stream);
 uint64_t vlg_queries_count(const vlg_queries* q);
 uint64_t vlg_queries_subpatterns(const vlg_queries* q);
 /* h_k[q] = number of sub-patterns of query q (0 for a query that failed to parse). */

@@ -107,3 +107,31 @@ def test_checksum_reduction_is_modulo_2_64():
     assert vdist.reduce_checksum(big) == big                                  # single rank: unchanged, no 2^63 folding
     r = vdist.run_sharded(lambda qs: ([1] * len(qs), big, 7), ["a", "b", "c"])
     assert r["checksum"] == big and r["num_results"] == 3 and r["located"] == 7
+
+
+def test_shard_by_affinity_keeps_sharers_together_and_covers_all():
+    from vlg_matching_amd import dist as vdist
+    rng = np.random.default_rng(3)
+    # 400 queries x 3 sub-patterns drawn from 40 lists of very different lengths (interval start = list identity)
+    starts = np.cumsum(rng.integers(1, 10 ** 6, 40)).astype(np.uint64)
+    lens = (10 ** rng.uniform(0, 6, 40)).astype(np.uint64) + 1
+    pick = rng.integers(0, 40, (400, 3))
+    l = starts[pick].ravel()
+    r = (starts[pick] + lens[pick] - 1).ravel()
+    qsub = np.arange(0, 1201, 3)
+    for world in (1, 2, 4, 8):
+        parts = vdist.shard_by_affinity(l, r, qsub, world)
+        allq = np.sort(np.concatenate(parts))
+        assert len(parts) == world and (allq == np.arange(400)).all()              # every query exactly once
+        heavy = np.array([pick[i][np.argmax(lens[pick[i]])] for i in range(400)])
+        rank_of = np.zeros(400, dtype=int)
+        for t, p in enumerate(parts):
+            rank_of[p] = t
+        spread = [len(set(rank_of[heavy == h])) for h in range(40) if (heavy == h).sum() and (heavy == h).sum() * world <= 400]
+        assert all(x == 1 for x in spread)                                           # one rank per heavy list (unless it is too popular to fit one)
+        # distinct lists per rank, summed, against contiguous slices: fewer located occurrences
+        def located(sets):
+            return sum(int(lens[np.unique(pick[list(s)].ravel())].sum()) for s in sets if len(s))
+        if world > 1:
+            contiguous = [np.arange(b, e) for b, e in (vdist.shard_bounds(400, t, world) for t in range(world))]
+            assert located(parts) <= located(contiguous)

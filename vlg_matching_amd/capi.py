@@ -98,6 +98,7 @@ SYMBOLS = [
     ("vlg_queries_parse", _I, [C.c_char_p, _P, _U64, _I, _P, C.POINTER(_P)]),
     ("vlg_queries_create", _I, [_P, _P, _P, _P, _P, _P, _U64, C.POINTER(_P)]),
     ("vlg_queries_occurrences", _I, [_P, _P, _P, _P]),
+    ("vlg_queries_intervals", _I, [_P, _P, _P, _P, _P]),
     ("vlg_queries_count", _U64, [_P]),
     ("vlg_queries_subpatterns", _U64, [_P]),
     ("vlg_queries_k", _I, [_P, _P]),

@@ -683,7 +683,9 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
     if (!ptasks.empty()) {
         VLG_HIP_TRY(hipMemcpyAsync(d_ptasks, ptasks.data(), ptasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st));
         VLG_HIP_TRY(hipMemcpyAsync(d_prun0, prun0.data(), prun0.size() * 8, hipMemcpyHostToDevice, st));
-        Timed t(ws, KS_FILTER_PIVOT, 0);
+        uint64_t probes = 0;                                      // (pivot element, level) pairs: two lower bounds of 8 bytes each
+        for (const PTask& pt : ptasks) probes += (uint64_t)(segs[pt.seg0 + pt.p].pend - segs[pt.seg0 + pt.p].pbegin) * (pt.k >= 2 ? pt.k - 2 + (pt.p + 1 == pt.k ? 1 : 0) : 0);
+        Timed t(ws, KS_FILTER_PIVOT, 16 * probes);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t>), dim3((uint32_t)((prun0.back() + 3) / 4)), dim3(256), 0, st, P, fg.d_segs,
                            d_ptasks, d_prun0, (uint32_t)ptasks.size(), fg.d_abits);
         VLG_HIP_TRY(hipGetLastError());

@@ -871,7 +871,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
             size_t tb = temp_bytes;
-            if (timer) timer->begin(1);
+            if (timer) timer->begin(1, 20ull * alive);           // key + element read once and written once
             rocprim::double_buffer<uint16_t> dk(key_a, key_b);
             rocprim::double_buffer<uint64_t> dv(val_a, val_b);
             hipError_t se = rocprim::radix_sort_pairs(temp, tb, dk, dv, alive, 0, bits, stream);
@@ -902,7 +902,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
         // every element has a record now; jump pointers until all of them are positions
         for (uint32_t round = 0;; ++round) {
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
-            if (timer) timer->begin(2);
+            if (timer) timer->begin(2, round == 0 ? total * (8ull + sizeof(pos_t)) : 0);     // every record read, every position written
             hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_kernel<pos_t>), dim3(grid_for(total, 16384)), dim3(256), 0, stream, rec, total, d_out,
                                d_counter, round);
             if (timer) timer->end(2);

@@ -15,7 +15,7 @@ vlg_status launch_locate(const IndexView& iv, pos_t* d_io, uint64_t total, unsig
 // Optional per-launch timing hooks (HIP events on the stream), implemented by the workspace.
 struct LaunchTimer {
     virtual ~LaunchTimer() {}
-    virtual void begin(int which) = 0;     // which: 0 = LF step kernel, 1 = stable partition by symbol, 2 = trail record resolution
+    virtual void begin(int which, uint64_t algorithmic_bytes = 0) = 0;     // which: 0 = LF step kernel, 1 = stable partition by symbol, 2 = trail record resolution
     virtual void end(int which) = 0;
 };
 

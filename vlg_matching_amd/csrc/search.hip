@@ -113,10 +113,11 @@ struct Timed {      // RAII: HIP events around one launch (or one library call) 
 struct SweepTimer : LaunchTimer {      // one event pair per launch of the sweep, accounted per kernel class
     vlg_workspace* ws; hipEvent_t a = nullptr, b = nullptr;
     explicit SweepTimer(vlg_workspace* w) : ws(w) {}
-    void begin(int which) override
+    void begin(int which, uint64_t algorithmic_bytes) override
     {
         int k = which == 0 ? KS_LOCATE : (which == 1 ? KS_LOCATE_PART : KS_LOCATE_RESOLVE);
         ws->stats[k].launches++;
+        ws->stats[k].algorithmic_bytes += algorithmic_bytes;
         a = b = nullptr;
         if (ws->profile) { a = ws_event(ws); b = ws_event(ws); if (a) (void)hipEventRecord(a, ws->stream); }
     }
@@ -1158,24 +1159,32 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
 // =============================================================================================
 // sdsl::count for every sub-pattern of a batch (what a multi-GPU host shards the batch by)
 // =============================================================================================
-extern "C" vlg_status vlg_queries_occurrences(const vlg_index* idx, const vlg_queries* q, uint64_t* h_occ, void* stream)
+extern "C" vlg_status vlg_queries_intervals(const vlg_index* idx, const vlg_queries* q, uint64_t* h_l, uint64_t* h_r, void* stream)
 {
-    if (!idx || !q || (q->nsub && !h_occ)) return fail(VLG_E_INVALID, "null argument");
+    if (!idx || !q || (q->nsub && (!h_l || !h_r))) return fail(VLG_E_INVALID, "null argument");
     if (q->sym_bytes != 1) return fail(VLG_E_INVALID, "integer-alphabet query batch: only the vlg_wtsa_* entry points take it");
     const uint64_t nsub = q->nsub;
     if (!nsub) return VLG_OK;
     hipStream_t st = (hipStream_t)stream;
     uint64_t* d_lr = nullptr;
     VLG_HIP_TRY(hipMalloc((void**)&d_lr, 2 * nsub * 8));
-    std::vector<uint64_t> lr(2 * nsub);
     vlg_status s = launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_lr, d_lr + nsub, nullptr, st);
     hipError_t e = hipSuccess;
-    if (!s) e = hipMemcpyAsync(lr.data(), d_lr, 2 * nsub * 8, hipMemcpyDeviceToHost, st);
+    if (!s) e = hipMemcpyAsync(h_l, d_lr, nsub * 8, hipMemcpyDeviceToHost, st);
+    if (!s && e == hipSuccess) e = hipMemcpyAsync(h_r, d_lr + nsub, nsub * 8, hipMemcpyDeviceToHost, st);
     if (!s && e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d_lr);
     if (s) return s;
     VLG_HIP_TRY(e);
-    for (uint64_t i = 0; i < nsub; ++i) h_occ[i] = lr[nsub + i] + 1 - lr[i];      // r + 1 - l (suffix_array_algorithm.hpp:325)
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_queries_occurrences(const vlg_index* idx, const vlg_queries* q, uint64_t* h_occ, void* stream)
+{
+    if (!idx || !q || (q->nsub && !h_occ)) return fail(VLG_E_INVALID, "null argument");
+    std::vector<uint64_t> r(q->nsub + 1);
+    if (vlg_status s = vlg_queries_intervals(idx, q, h_occ, r.data(), stream)) return s;
+    for (uint64_t i = 0; i < q->nsub; ++i) h_occ[i] = r[i] + 1 - h_occ[i];        // r + 1 - l (suffix_array_algorithm.hpp:325)
     return VLG_OK;
 }
 

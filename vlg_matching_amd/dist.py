@@ -30,6 +30,45 @@ def shard_by_work(weights, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def shard_by_affinity(l, r, qsub, world):
+    """Query sets (index arrays, one per rank) for a batch whose queries share occurrence lists: a list that several queries use
+    is located and sorted once per GPU that holds one of them, so contiguous slices repeat that work on every rank.  Queries
+    are grouped by their LONGEST list (identified by its SA interval [l, r]; equal intervals are the same list), a group costs
+    that list once plus the lists its queries join, and the groups go to the least loaded rank, heaviest first.
+    l, r: per sub-pattern (vlg_queries_intervals); qsub[nq+1]: query i owns the sub-patterns [qsub[i], qsub[i+1])."""
+    l = np.asarray(l, dtype=np.uint64)
+    occ = (np.asarray(r, dtype=np.uint64) + np.uint64(1) - l).astype(np.float64)
+    nq = len(qsub) - 1
+    key = np.zeros(nq, dtype=np.uint64)
+    big = np.zeros(nq)
+    w = np.ones(nq)
+    for i in range(nq):
+        a, b = int(qsub[i]), int(qsub[i + 1])
+        if b > a and occ[a:b].min() > 0:
+            j = a + int(np.argmax(occ[a:b]))
+            key[i], big[i], w[i] = l[j], occ[j], 1.0 + occ[a:b].sum()
+        else:
+            key[i] = np.uint64(0xFFFFFFFFFFFFFFFF)                 # nothing to locate: any rank
+    order = np.argsort(key, kind="stable")
+    cuts = np.flatnonzero(np.concatenate([[True], key[order][1:] != key[order][:-1]]))
+    groups = [order[a:b] for a, b in zip(cuts, list(cuts[1:]) + [nq])]
+    cost = [big[g[0]] + w[g].sum() for g in groups]
+    load = np.zeros(world)
+    out = [[] for _ in range(world)]
+    for gi in np.argsort(cost)[::-1]:
+        g = groups[gi]
+        if key[g[0]] == np.uint64(0xFFFFFFFFFFFFFFFF) or len(g) * world > nq:        # free queries, or a group too big for one rank: spread them
+            for part in np.array_split(g, world):
+                t = int(np.argmin(load))
+                out[t].append(part)
+                load[t] += (big[g[0]] if len(part) else 0.0) + w[part].sum()
+            continue
+        t = int(np.argmin(load))
+        out[t].append(g)
+        load[t] += cost[gi]
+    return [np.sort(np.concatenate(o)) if o else np.zeros(0, dtype=np.int64) for o in out]
+
+
 def replicate_index(idx, dist, device, src=0):
     """Broadcast the index image from rank `src` to every rank's HBM and attach to it.  `idx` is None elsewhere."""
     import torch

@@ -317,6 +317,14 @@ class VlgIndex:
         check(lib().vlg_queries_occurrences(self._h, q._h, occ.ctypes.data, None))
         return occ[:nsub], q
 
+    def intervals(self, queries, dialect=capi.DIALECT_LIBRARY):
+        """SA interval [l, r] of every sub-pattern of the batch (one backward-search pass) -> (l[], r[], Queries)"""
+        q = queries if isinstance(queries, Queries) else Queries(queries, dialect)
+        nsub = int(lib().vlg_queries_subpatterns(q._h))
+        l, r = np.zeros(max(nsub, 1), dtype=np.uint64), np.zeros(max(nsub, 1), dtype=np.uint64)
+        check(lib().vlg_queries_intervals(self._h, q._h, l.ctypes.data, r.ctypes.data, None))
+        return l[:nsub], r[:nsub], q
+
     def query_weights(self, queries, dialect=capi.DIALECT_LIBRARY):
         """Estimated work per query = sum of the SA-interval sizes of its sub-patterns (0 when one of them does not occur: such a
         query locates nothing) -- what vlg_matching_amd.dist.shard_by_work balances."""
