@@ -245,7 +245,7 @@ def test_c5_one_gib_dna_rrr_full_size(oracle):
     for k in ("lf_steps", "wt_levels_locate", "located_occurrences", "wt_levels_bsearch"):
         assert pl.summary[k] == s[k], k                                      # same walks, only the rank primitive differs
     del pl
-    for opts in ({"sweep": 0}, {"trail": 0, "filter": 0}, {"dedup": 0}):
+    for opts in ({"sweep": 0}, {"trail": 0, "filter": 0}):
         w2 = Workspace(100 << 30)
         for k_, v_ in opts.items():
             w2.set_option(k_, v_)
