@@ -362,8 +362,9 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
  * "trail" (default 1, needs "dedup"): inside a sorted sweep an occurrence that steps onto an SA index another occurrence
  * has visited stops there and takes that occurrence's position plus the distance (csa[i] = csa[LF(i)] + 1 shared between
  * lanes), so a batch walks every LF trail once; 0 = every occurrence walks to its own sample like csa_wt::operator[].
- * "global_sort_min" (default 2^20): from this many occurrences on all lists are sorted by one radix sort of
- * (list, position) keys instead of one segmented sort.
+ * "list_sort" (default 1): with 32-bit positions every occurrence list is sorted inside itself by LSD radix passes on the
+ * position bits alone (short lists in LDS); 0, or 64-bit positions: "global_sort_min" (default 2^20): from this many
+ * occurrences on all lists are sorted by one radix sort of (list, position) keys instead of one segmented sort.
  * "filter" (default 1): before the join drop the list elements whose gap windows hold no element of the neighbouring
  * lists (they are in no match); "filter_min" (default 2^12) = join slots below which a query is joined as it is
  * ("filter_stream_min", default 2^16, for the queries filtered by streaming sweeps);

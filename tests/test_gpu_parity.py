@@ -488,7 +488,8 @@ def test_window_filter_equals_unfiltered_join_and_oracle(V, oracle, name, seed, 
     ws_f.set_option("filter_min", 0)
     ws_f.set_option("filter_stream_min", 0)
     ws_f.set_option("filter_pivot", pivot)
-    ws_f.set_option("global_sort_min", 1 if pivot else 1 << 40)      # all lists sorted at once / one sort per list
+    ws_f.set_option("global_sort_min", 1 if pivot else 1 << 40)      # all lists sorted at once / one sort per list ...
+    ws_f.set_option("list_sort", seed % 2)                           # ... when the sort inside every list is off
     if seed in (62, 65):
         ws_f.set_option("filter_group_bytes", 1 << 16)                # many small filter groups inside one batch
     a, b = idx.search(qs, workspace=ws_n), idx.search(qs, workspace=ws_f)

@@ -1,0 +1,252 @@
+// K4: every occurrence list sorted ascending (std::sort, benchmark/gapped-matching/include/index_sasearch.hpp:80), all lists of a
+// batch at once, for 32-bit positions.
+// Internal to search.hip's translation unit; included exactly once from there.
+//
+// The lists come out of locate grouped (list l = P[off[l], off[l+1])) but in suffix-array order inside.  Sorting 64-bit
+// (list, position) keys with one device-wide radix sort moves 16 bytes per element and pass and spends its upper passes on list
+// bits that are in order already (C3: 30 + 18 bits = 6 passes of 8 bits).  Here only the position bits are sorted, as 32-bit keys,
+// INSIDE every list:
+//   lists of up to kSortTile elements  one workgroup sorts the list in LDS (rocPRIM block_radix_sort), one read + one write;
+//   longer lists                       LSD radix passes of <= 8 bits over tiles of kSortTile elements that never straddle two
+//                                      lists: per tile a digit histogram, per list an exclusive scan of the histograms (by chunks
+//                                      of kSortChunk tiles, so that a list of 2000 tiles is not one serial loop), then every tile
+//                                      sorts its keys by the digit in LDS and writes them as runs behind its prefix.
+// An even number of passes (2 or 4) brings the long lists back to the buffer they started in, where the short ones were sorted in
+// place.  rocPRIM's block-level sort / load / store are the plumbing; the tiling, the per-list scans and the scatter are this file.
+#pragma once
+namespace {
+
+constexpr uint32_t kSortTile = 4096;          // elements per tile: 256 threads x 16
+constexpr uint32_t kSortChunk = 32;           // tiles per chunk of the histogram scan
+
+// ---- short lists: whole list in one workgroup ------------------------------------------------------------------------------------
+template <uint32_t kThreads, uint32_t kItems>
+__global__ void __launch_bounds__(kThreads) list_sort_small_kernel(uint32_t* __restrict__ P, const uint64_t* __restrict__ off,
+                                                                   const uint32_t* __restrict__ lists, uint32_t n_lists, uint32_t bits)
+{
+    using Load = rocprim::block_load<uint32_t, kThreads, kItems, rocprim::block_load_method::block_load_transpose>;
+    using Store = rocprim::block_store<uint32_t, kThreads, kItems, rocprim::block_store_method::block_store_transpose>;
+    using Sort = rocprim::block_radix_sort<uint32_t, kThreads, kItems>;
+    __shared__ union { typename Load::storage_type load; typename Store::storage_type store; typename Sort::storage_type sort; } s;
+    if (blockIdx.x >= n_lists) return;
+    const uint32_t l = lists[blockIdx.x];
+    const uint64_t begin = off[l];
+    const uint32_t len = (uint32_t)(off[l + 1] - begin);
+    uint32_t keys[kItems];
+    Load().load(P + begin, keys, len, 0xFFFFFFFFu, s.load);       // positions are < 2^32 - 1: the padding sorts last
+    __syncthreads();
+    Sort().sort(keys, s.sort, 0, bits);
+    __syncthreads();
+    Store().store(P + begin, keys, len, s.store);
+}
+
+// ---- long lists ----------------------------------------------------------------------------------------------------------------------
+struct SortList { uint64_t begin; uint32_t len, tile0, chunk0, pad; };      // a long list: elements, first tile, first chunk
+
+// digit histogram of every tile: hist[tile][256]
+__global__ void __launch_bounds__(256) list_sort_hist_kernel(const uint32_t* __restrict__ in, const SortList* __restrict__ lists,
+                                                             const uint32_t* __restrict__ tile_list, uint32_t n_tiles, uint32_t shift,
+                                                             uint32_t mask, uint16_t* __restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const SortList L = lists[tile_list[t]];
+    const uint32_t first = (t - L.tile0) * kSortTile;
+    const uint32_t cnt = L.len - first < kSortTile ? L.len - first : kSortTile;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t* src = in + L.begin + first;
+#pragma unroll
+    for (uint32_t i = 0; i < kSortTile / 256; ++i) {
+        const uint32_t e = i * 256 + threadIdx.x;
+        if (e < cnt) atomicAdd(&h[(src[e] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    hist[(uint64_t)t * 256 + threadIdx.x] = (uint16_t)h[threadIdx.x];      // <= kSortTile = 2^12
+}
+
+// totals of every chunk of kSortChunk tiles: tot[chunk][256]
+__global__ void __launch_bounds__(256) list_sort_chunk_kernel(const uint16_t* __restrict__ hist, const SortList* __restrict__ lists,
+                                                              const uint32_t* __restrict__ chunk_list, uint32_t n_chunks,
+                                                              uint32_t* __restrict__ tot)
+{
+    const uint32_t c = blockIdx.x;
+    if (c >= n_chunks) return;
+    const SortList L = lists[chunk_list[c]];
+    const uint32_t tiles = (L.len + kSortTile - 1) / kSortTile;
+    const uint32_t t0 = (c - L.chunk0) * kSortChunk, t1 = t0 + kSortChunk < tiles ? t0 + kSortChunk : tiles;
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; ++t) sum += hist[(uint64_t)(L.tile0 + t) * 256 + threadIdx.x];
+    tot[(uint64_t)c * 256 + threadIdx.x] = sum;
+}
+
+// per list: tot[chunk][d] becomes the number of keys of the list that go before the chunk's keys with digit d (smaller digits of the
+// whole list + digit d of the chunks before it)
+__global__ void __launch_bounds__(256) list_sort_scan_kernel(const SortList* __restrict__ lists, uint32_t n_long, uint32_t* __restrict__ tot)
+{
+    __shared__ uint32_t s[256];
+    const uint32_t m = blockIdx.x;
+    if (m >= n_long) return;
+    const SortList L = lists[m];
+    const uint32_t tiles = (L.len + kSortTile - 1) / kSortTile, chunks = (tiles + kSortChunk - 1) / kSortChunk;
+    uint32_t run = 0;
+    for (uint32_t c = 0; c < chunks; ++c) {
+        uint32_t* p = tot + (uint64_t)(L.chunk0 + c) * 256 + threadIdx.x;
+        const uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    // exclusive scan of the digit totals over the 256 threads
+    s[threadIdx.x] = run;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint32_t v = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+        __syncthreads();
+        s[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const uint32_t base = s[threadIdx.x] - run;
+    for (uint32_t c = 0; c < chunks; ++c) tot[(uint64_t)(L.chunk0 + c) * 256 + threadIdx.x] += base;
+}
+
+// per chunk: pref[tile][d] = where the tile's keys with digit d start inside the list
+__global__ void __launch_bounds__(256) list_sort_prefix_kernel(const uint16_t* __restrict__ hist, const SortList* __restrict__ lists,
+                                                               const uint32_t* __restrict__ chunk_list, uint32_t n_chunks,
+                                                               const uint32_t* __restrict__ tot, uint32_t* __restrict__ pref)
+{
+    const uint32_t c = blockIdx.x;
+    if (c >= n_chunks) return;
+    const SortList L = lists[chunk_list[c]];
+    const uint32_t tiles = (L.len + kSortTile - 1) / kSortTile;
+    const uint32_t t0 = (c - L.chunk0) * kSortChunk, t1 = t0 + kSortChunk < tiles ? t0 + kSortChunk : tiles;
+    uint32_t run = tot[(uint64_t)c * 256 + threadIdx.x];
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint64_t at = (uint64_t)(L.tile0 + t) * 256 + threadIdx.x;
+        pref[at] = run;
+        run += hist[at];
+    }
+}
+
+// every tile: keys sorted by the digit in LDS (stable), then written as runs behind the tile's prefixes
+__global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                const SortList* __restrict__ lists, const uint32_t* __restrict__ tile_list,
+                                                                uint32_t n_tiles, uint32_t shift, uint32_t dbits,
+                                                                const uint32_t* __restrict__ pref)
+{
+    constexpr uint32_t kItems = kSortTile / 256;
+    using Load = rocprim::block_load<uint32_t, 256, kItems, rocprim::block_load_method::block_load_transpose>;
+    using Sort = rocprim::block_radix_sort<uint32_t, 256, kItems>;
+    __shared__ union { typename Load::storage_type load; typename Sort::storage_type sort; uint32_t keys[kSortTile]; } s;
+    __shared__ uint32_t first[256];
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const SortList L = lists[tile_list[t]];
+    const uint32_t begin = (t - L.tile0) * kSortTile;
+    const uint32_t cnt = L.len - begin < kSortTile ? L.len - begin : kSortTile;
+    const uint32_t mask = (1u << dbits) - 1u;
+    uint32_t keys[kItems];
+    Load().load(in + L.begin + begin, keys, cnt, 0xFFFFFFFFu, s.load);       // the padding has the largest digit and stands last: it stays last
+    __syncthreads();
+    Sort().sort(keys, s.sort, shift, shift + dbits);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kItems; ++i) s.keys[threadIdx.x * kItems + i] = keys[i];
+    __syncthreads();
+    // first[d] = position of the first key with digit d among the tile's sorted keys
+#pragma unroll
+    for (uint32_t i = 0; i < kItems; ++i) {
+        const uint32_t p = i * 256 + threadIdx.x;
+        const uint32_t d = (s.keys[p] >> shift) & mask;
+        if (p == 0 || ((s.keys[p - 1] >> shift) & mask) != d) first[d] = p;
+    }
+    __syncthreads();
+    const uint32_t* pf = pref + (uint64_t)t * 256;
+    uint32_t* dst = out + L.begin;
+#pragma unroll
+    for (uint32_t i = 0; i < kItems; ++i) {
+        const uint32_t p = i * 256 + threadIdx.x;                            // neighbouring lanes write neighbouring keys of a run
+        if (p < cnt) {
+            const uint32_t k = s.keys[p], d = (k >> shift) & mask;
+            dst[pf[d] + (p - first[d])] = k;
+        }
+    }
+}
+
+inline uint64_t list_sort_scratch_bytes(uint64_t n_long, uint64_t n_tiles, uint64_t n_chunks)
+{
+    return n_long * sizeof(SortList) + (n_tiles + n_chunks) * 4 + n_tiles * 256 * 6 + n_chunks * 256 * 4 + 8 * 256;
+}
+
+// P: the lists (in suffix-array order inside), `other`: a second buffer of the same size; the sorted lists end up in P.
+// A (arena) provides the histogram scratch; everything is enqueued on `st`, nothing is waited for.
+inline vlg_status list_sort_u32(uint32_t* P, uint32_t* other, const svec<uint64_t>& off64, const uint64_t* d_off64, uint32_t nd, unsigned bits,
+                                Arena& A, hipStream_t st)
+{
+    // size classes
+    svec<uint32_t> small[3];                                       // <= 256, <= 1024, <= kSortTile elements
+    svec<SortList> longs;
+    svec<uint32_t> tile_list, chunk_list;
+    for (uint32_t l = 0; l < nd; ++l) {
+        const uint64_t len = off64[l + 1] - off64[l];
+        if (len <= 1) continue;
+        if (len <= 256) small[0].push_back(l);
+        else if (len <= 1024) small[1].push_back(l);
+        else if (len <= kSortTile) small[2].push_back(l);
+        else {
+            if (len > 0xFFFFFFFFull) return fail(VLG_E_INTERNAL, "list sort: list too long");
+            const uint32_t tiles = (uint32_t)((len + kSortTile - 1) / kSortTile), chunks = (tiles + kSortChunk - 1) / kSortChunk;
+            const uint32_t m = (uint32_t)longs.size();
+            longs.push_back(SortList{off64[l], (uint32_t)len, (uint32_t)tile_list.size(), (uint32_t)chunk_list.size(), 0});
+            tile_list.insert(tile_list.end(), tiles, m);
+            chunk_list.insert(chunk_list.end(), chunks, m);
+        }
+    }
+    {   // room for everything, or nothing is launched (the caller then takes the device-wide sort)
+        uint64_t need = 4096;
+        for (int c = 0; c < 3; ++c) need += align_up(small[c].size() * 4, 256);
+        if (!longs.empty()) need += list_sort_scratch_bytes(longs.size(), tile_list.size(), chunk_list.size());
+        if (A.failed || A.size - A.used < need) return fail(VLG_E_WORKSPACE, "list sort: no room for its tables");
+    }
+    for (int c = 0; c < 3; ++c) {
+        if (small[c].empty()) continue;
+        uint32_t* d_lists = A.take<uint32_t>(small[c].size());
+        if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (list sort)");
+        VLG_HIP_TRY(hipMemcpyAsync(d_lists, small[c].data(), small[c].size() * 4, hipMemcpyHostToDevice, st));
+        const uint32_t n = (uint32_t)small[c].size();
+        if (c == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<64, 4>), dim3(n), dim3(64), 0, st, P, d_off64, d_lists, n, bits);
+        else if (c == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<256, 4>), dim3(n), dim3(256), 0, st, P, d_off64, d_lists, n, bits);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<256, 16>), dim3(n), dim3(256), 0, st, P, d_off64, d_lists, n, bits);
+        VLG_HIP_TRY(hipGetLastError());
+    }
+    if (longs.empty()) return VLG_OK;
+    const uint32_t n_long = (uint32_t)longs.size(), n_tiles = (uint32_t)tile_list.size(), n_chunks = (uint32_t)chunk_list.size();
+    if (A.size - A.used < list_sort_scratch_bytes(n_long, n_tiles, n_chunks)) return fail(VLG_E_WORKSPACE, "list sort: no room for the histograms");
+    SortList* d_longs = A.take<SortList>(n_long);
+    uint32_t* d_tile_list = A.take<uint32_t>(n_tiles);
+    uint32_t* d_chunk_list = A.take<uint32_t>(n_chunks);
+    uint16_t* d_hist = A.take<uint16_t>((uint64_t)n_tiles * 256);
+    uint32_t* d_tot = A.take<uint32_t>((uint64_t)n_chunks * 256);
+    uint32_t* d_pref = A.take<uint32_t>((uint64_t)n_tiles * 256);
+    if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (list sort)");
+    VLG_HIP_TRY(hipMemcpyAsync(d_longs, longs.data(), n_long * sizeof(SortList), hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_tile_list, tile_list.data(), n_tiles * 4, hipMemcpyHostToDevice, st));
+    VLG_HIP_TRY(hipMemcpyAsync(d_chunk_list, chunk_list.data(), n_chunks * 4, hipMemcpyHostToDevice, st));
+    const unsigned passes = bits <= 16 ? 2 : 4;                    // even: the lists come back to P
+    const unsigned dbits = (bits + passes - 1) / passes;          // <= 8
+    uint32_t* src = P;
+    uint32_t* dst = other;
+    for (unsigned p = 0; p < passes; ++p) {
+        const uint32_t shift = p * dbits, mask = (1u << dbits) - 1u;
+        hipLaunchKernelGGL(list_sort_hist_kernel, dim3(n_tiles), dim3(256), 0, st, src, d_longs, d_tile_list, n_tiles, shift, mask, d_hist);
+        hipLaunchKernelGGL(list_sort_chunk_kernel, dim3(n_chunks), dim3(256), 0, st, d_hist, d_longs, d_chunk_list, n_chunks, d_tot);
+        hipLaunchKernelGGL(list_sort_scan_kernel, dim3(n_long), dim3(256), 0, st, d_longs, n_long, d_tot);
+        hipLaunchKernelGGL(list_sort_prefix_kernel, dim3(n_chunks), dim3(256), 0, st, d_hist, d_longs, d_chunk_list, n_chunks, d_tot, d_pref);
+        hipLaunchKernelGGL(list_sort_scatter_kernel, dim3(n_tiles), dim3(256), 0, st, src, dst, d_longs, d_tile_list, n_tiles, shift, dbits, d_pref);
+        VLG_HIP_TRY(hipGetLastError());
+        std::swap(src, dst);
+    }
+    return VLG_OK;
+}
+
+}  // namespace

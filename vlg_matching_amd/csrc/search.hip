@@ -61,6 +61,7 @@ struct vlg_workspace {
     uint64_t filter_group_bytes = 0;    // cap of the filter state of one group of queries (0: a third of the join budget)
     uint64_t filter_pivot_ratio = 6;    // ... i.e. when all lists together are at least this many times longer (C3, ms per batch: 24 -> 262,
                                         // 12 -> 251, 6 -> 246.6, 4 -> 246.4, <= 3 -> 248: the probes win wherever a list is clearly the shortest)
+    bool list_sort = true;      // 32-bit positions: every list sorted inside itself (list_sort.hpp); off: the two rocPRIM paths below
     uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
     uint64_t sweep_tail = 1ull << 20;   // stragglers of a sweep are finished one lane each
@@ -209,6 +210,7 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "sweep")) { ws->sweep = value != 0; return VLG_OK; }
     if (!strcmp(name, "sweep_min")) { ws->sweep_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "global_sort_min")) { ws->global_sort_min = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "list_sort")) { ws->list_sort = value != 0; return VLG_OK; }
     if (!strcmp(name, "trail")) { ws->trail = value != 0; return VLG_OK; }
     if (!strcmp(name, "tuples")) { ws->tuples = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter")) { ws->filter = value != 0; return VLG_OK; }
@@ -419,6 +421,8 @@ __global__ void sort_narrow_kernel(const uint64_t* __restrict__ keys, uint64_t t
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) P[t] = (pos_t)(keys[t] & mask);
 }
 
+#include "list_sort.hpp"
+
 // ---- physical pass: locate + sort every distinct interval used by queries [Q0,Q1) -------------------
 template <typename pos_t>
 vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* res, const std::vector<uint32_t>& dlist /* distinct ids */,
@@ -484,8 +488,22 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     // sort every occurrence list ascending (std::sort, index_sasearch.hpp:80)
     const unsigned list_bits = bit_width64(nd);
     const bool global_sort = acc >= ws->global_sort_min && bits + list_bits <= 64;
-    uint64_t dead_bytes;                                  // free bytes behind the sorted lists (the survivors of the window filter go there)
-    if (global_sort) {
+    uint64_t dead_bytes = 0;                              // free bytes behind the sorted lists (the survivors of the window filter go there)
+    bool sorted = false;
+    if (sizeof(pos_t) == 4 && ws->list_sort) {
+        // 32-bit positions: sorted inside every list (list_sort.hpp) -- 4 passes of 8 B per element instead of 6 of 16 B
+        const uint64_t mark = A.used;
+        Timed t(ws, KS_SORT, 2ull * acc * sizeof(pos_t));
+        const vlg_status ls = list_sort_u32(reinterpret_cast<uint32_t*>(Pa), reinterpret_cast<uint32_t*>(scratch), off64, d_off64, nd, bits, A, st);
+        A.used = mark;                                    // its tables are dead once its kernels have run (stream order)
+        if (ls == VLG_OK) {
+            sorted = true;
+            P_out = Pa;
+            dead_bytes = (uint64_t)(scratch - reinterpret_cast<uint8_t*>(Pa)) + acc * kPhysScratchPerElem<pos_t>() - acc * sizeof(pos_t);
+        } else if (ls != VLG_E_WORKSPACE) return ls;      // no room for its tables: the device-wide sort below
+    }
+    if (sorted) {
+    } else if (global_sort) {
         // one radix sort of (list, position) keys: the passes stream the whole batch whatever the list sizes are
         uint64_t* ka = reinterpret_cast<uint64_t*>(scratch);
         uint64_t* kb = ka + acc;
