@@ -7,6 +7,7 @@
 namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kChecksumSlots = 64;     // partial checksums of the gather kernel (added up by the host)
 
 // Occurrence lists are PHYSICAL: one sorted list per distinct SA interval of the batch, shared by every
 // query that uses the sub-pattern.  Join state (link / end / feasibility ...) is LOGICAL: one slot per
@@ -797,8 +798,15 @@ __global__ void __launch_bounds__(256) join_gather_kernel(const pos_t* __restric
         }
         s_w = __shfl(s, 0);
     }
+    // one atomic per workgroup, spread over kChecksumSlots words (a single word takes ~90 atomics per microsecond; there are
+    // 10^5..10^6 waves here); the host adds the slots up
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
-    if (lane == 0 && local) atomicAdd(checksum, local);
+    if (lane == 0 && local) atomicAdd(&s_sum, local);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) atomicAdd(checksum + (blockIdx.x % kChecksumSlots), s_sum);
 }
 
 

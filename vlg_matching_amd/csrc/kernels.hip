@@ -410,6 +410,24 @@ __global__ void __launch_bounds__(256) backward_search_kernel(IndexView iv, cons
     }
 }
 
+// Statistics counters: a wave-level sum, then ONE atomic per workgroup and counter -- a single word takes ~90 atomics per
+// microsecond, so one per wave (16 k waves a launch) would cost every launch of the sweep a fifth of a millisecond.
+template <int N>
+__device__ __forceinline__ void block_add(unsigned long long (&v)[N], unsigned long long* const (&dst)[N])
+{
+    __shared__ unsigned long long s_acc[N];
+    if (threadIdx.x < N) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        unsigned long long x = v[k];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&s_acc[k], x);
+    }
+    __syncthreads();
+    if (threadIdx.x < N && s_acc[threadIdx.x] && dst[threadIdx.x]) atomicAdd(dst[threadIdx.x], s_acc[threadIdx.x]);
+}
+
 // =============================================================================================
 // K3: csa[i] = LF iteration to the next sampled SA index (include/sdsl/csa_wt.hpp:335-348,
 //     LF = C[c] + inverse_select(i): suffix_array_helper.hpp:336-349, wt_pc.hpp:385-402).
@@ -488,9 +506,9 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
         }
     }
     if (stats) {
-        unsigned long long a = n_lf, b = n_lv;
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
-        if (lane == 0) { if (a) atomicAdd(&stats[0], a); if (b) atomicAdd(&stats[1], b); }
+        unsigned long long v[2] = {n_lf, n_lv};
+        unsigned long long* const dst[2] = {&stats[0], &stats[1]};
+        block_add<2>(v, dst);
     }
 }
 
@@ -627,13 +645,9 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
             key[e] = (uint16_t)c;
         }
     }
-    unsigned long long a = n_lf, b = n_lv, d = n_fin;
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); d += __shfl_down(d, o); }
-    if ((threadIdx.x & 63) == 0) {
-        if (a) atomicAdd(&stats[0], a);
-        if (b) atomicAdd(&stats[1], b);
-        if (d) atomicAdd(n_done, d);
-    }
+    unsigned long long v[3] = {n_lf, n_lv, n_fin};
+    unsigned long long* const dst[3] = {&stats[0], &stats[1], n_done};
+    block_add<3>(v, dst);
 }
 
 // stragglers: finish the few elements still alive after the sweep, one lane each
@@ -674,9 +688,9 @@ __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uin
         if (rec) rec[slot0 + (v64 >> kShift)] = r;
         else out[v64 >> kShift] = (pos_t)r;
     }
-    unsigned long long a = n_lf, b = n_lv;
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
-    if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&stats[0], a); if (b) atomicAdd(&stats[1], b); }
+    unsigned long long v[2] = {n_lf, n_lv};
+    unsigned long long* const dst[2] = {&stats[0], &stats[1]};
+    block_add<2>(v, dst);
 }
 
 // Records of a trail-sharing sweep -> positions: every element follows its chain of records (element it follows, steps apart) to
@@ -707,8 +721,9 @@ __global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict
             out[e] = (pos_t)r;                                                    // elements that never followed anyone
         }
     }
-    for (int o = 32; o > 0; o >>= 1) open += __shfl_down(open, o);
-    if ((threadIdx.x & 63) == 0 && open) atomicAdd(n_open, (unsigned long long)open);
+    unsigned long long v[1] = {open};
+    unsigned long long* const dst[1] = {n_open};
+    block_add<1>(v, dst);
 }
 
 // ISA samples (csa_sampling_strategy.hpp:626-642: isa_sample[SA[i] / d'] = i for every i with SA[i] % d' == 0), computed from the

@@ -128,16 +128,18 @@ __global__ void __launch_bounds__(256) list_sort_prefix_kernel(const uint16_t* _
     }
 }
 
-// every tile: keys sorted by the digit in LDS (stable), then written as runs behind the tile's prefixes
+// every tile: the stable rank of every key by its digit (rocPRIM's warp-match ranking: keys in warp-striped order, i.e. loaded
+// coalesced as they lie), keys placed by rank in LDS, then written as runs behind the tile's prefixes
 __global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                                 const SortList* __restrict__ lists, const uint32_t* __restrict__ tile_list,
                                                                 uint32_t n_tiles, uint32_t shift, uint32_t dbits,
                                                                 const uint32_t* __restrict__ pref)
 {
     constexpr uint32_t kItems = kSortTile / 256;
-    using Load = rocprim::block_load<uint32_t, 256, kItems, rocprim::block_load_method::block_load_transpose>;
-    using Sort = rocprim::block_radix_sort<uint32_t, 256, kItems>;
-    __shared__ union { typename Load::storage_type load; typename Sort::storage_type sort; uint32_t keys[kSortTile]; } s;
+    using Rank = rocprim::block_radix_rank<256, 8, rocprim::block_radix_rank_algorithm::match>;
+    static_assert(Rank::digits_per_thread == 1, "thread d holds digit d");
+    __shared__ typename Rank::storage_type s_rank;
+    __shared__ uint32_t s_keys[kSortTile];
     __shared__ uint32_t first[256];
     const uint32_t t = blockIdx.x;
     if (t >= n_tiles) return;
@@ -145,21 +147,20 @@ __global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* 
     const uint32_t begin = (t - L.tile0) * kSortTile;
     const uint32_t cnt = L.len - begin < kSortTile ? L.len - begin : kSortTile;
     const uint32_t mask = (1u << dbits) - 1u;
+    const uint32_t* src = in + L.begin + begin;
+    const uint32_t wbase = (threadIdx.x >> 6) * (64 * kItems) + (threadIdx.x & 63);
     uint32_t keys[kItems];
-    Load().load(in + L.begin + begin, keys, cnt, 0xFFFFFFFFu, s.load);       // the padding has the largest digit and stands last: it stays last
-    __syncthreads();
-    Sort().sort(keys, s.sort, shift, shift + dbits);
-    __syncthreads();
-#pragma unroll
-    for (uint32_t i = 0; i < kItems; ++i) s.keys[threadIdx.x * kItems + i] = keys[i];
-    __syncthreads();
-    // first[d] = position of the first key with digit d among the tile's sorted keys
+    unsigned int ranks[kItems];
 #pragma unroll
     for (uint32_t i = 0; i < kItems; ++i) {
-        const uint32_t p = i * 256 + threadIdx.x;
-        const uint32_t d = (s.keys[p] >> shift) & mask;
-        if (p == 0 || ((s.keys[p - 1] >> shift) & mask) != d) first[d] = p;
+        const uint32_t e = wbase + 64 * i;                                   // warp-striped: the order of the elements themselves
+        keys[i] = e < cnt ? src[e] : 0xFFFFFFFFu;                            // the padding has the largest digit and stands last: it stays last
     }
+    unsigned int prefix[1], counts[1];
+    Rank().rank_keys(keys, ranks, s_rank, [shift, mask](const uint32_t& k) { return (k >> shift) & mask; }, prefix, counts);
+    first[threadIdx.x] = prefix[0];                                          // where the tile's keys with digit threadIdx.x start
+#pragma unroll
+    for (uint32_t i = 0; i < kItems; ++i) s_keys[ranks[i]] = keys[i];
     __syncthreads();
     const uint32_t* pf = pref + (uint64_t)t * 256;
     uint32_t* dst = out + L.begin;
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* 
     for (uint32_t i = 0; i < kItems; ++i) {
         const uint32_t p = i * 256 + threadIdx.x;                            // neighbouring lanes write neighbouring keys of a run
         if (p < cnt) {
-            const uint32_t k = s.keys[p], d = (k >> shift) & mask;
+            const uint32_t k = s_keys[p], d = (k >> shift) & mask;
             dst[pf[d] + (p - first[d])] = k;
         }
     }

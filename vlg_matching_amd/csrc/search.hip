@@ -358,6 +358,10 @@ extern "C" vlg_status vlg_result_fetch(const vlg_result* r, uint64_t* h_counts, 
 
 #include "join_device.hpp"
 
+// device counters of a batch: [0] LF steps, [1] tree levels of locate, [3] tree levels of the backward searches, [4..5] flags of
+// vlg_join_batch's input check, [kStatsChecksum ..) partial checksums
+constexpr uint32_t kStatsChecksum = 8, kStatsWords = kStatsChecksum + kChecksumSlots;
+
 namespace {
 
 inline uint32_t runs_grid(uint64_t slots) { return (uint32_t)((((slots + kRun - 1) / kRun) + 3) / 4); }   // 4 waves per workgroup
@@ -805,7 +809,7 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
         VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
         Timed t(ws, KS_GATHER, 8ull * (M + TV));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(runs_grid(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, d_segb, nlive,
-                           d_sm, d_qm, lvl0_begin, lvl0_end, link, mlist, d_counts, piece.d_first, piece.d_tuples, d_stats + 2);
+                           d_sm, d_qm, lvl0_begin, lvl0_end, link, mlist, d_counts, piece.d_first, piece.d_tuples, d_stats + kStatsChecksum);
         VLG_HIP_TRY(hipGetLastError());
     } else {
         res->pieces.push_back(piece);
@@ -1087,8 +1091,8 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         const uint64_t nsub = q->nsub;
         VLG_HIP_TRY(hipMalloc((void**)&d_l, (nsub + 1) * 8));
         VLG_HIP_TRY(hipMalloc((void**)&d_r, (nsub + 1) * 8));
-        VLG_HIP_TRY(hipMalloc((void**)&d_stats, 4 * 8));
-        VLG_HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * 8, st));
+        VLG_HIP_TRY(hipMalloc((void**)&d_stats, kStatsWords * 8));
+        VLG_HIP_TRY(hipMemsetAsync(d_stats, 0, kStatsWords * 8, st));
         // ---- K2: every sub-pattern's SA interval ------------------------------------------------------
         {
             Timed t(ws, KS_BSEARCH, 0);
@@ -1145,12 +1149,13 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         const uint64_t pos_bytes = idx->hdr.sample_bytes;
         vlg_status s = (pos_bytes == 4) ? run_batch<uint32_t>(idx, q, ws, res, pl, d_stats) : run_batch<uint64_t>(idx, q, ws, res, pl, d_stats);
         if (s) return s;
-        unsigned long long hs[4];
+        unsigned long long hs[kStatsWords];
         VLG_HIP_TRY(hipMemcpyAsync(hs, d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
         VLG_HIP_TRY(hipStreamSynchronize(st));
         res->sum.lf_steps = hs[0];
         res->sum.wt_levels_locate = hs[1];
-        res->sum.checksum = hs[2];
+        res->sum.checksum = 0;
+        for (uint32_t i = 0; i < kChecksumSlots; ++i) res->sum.checksum += hs[kStatsChecksum + i];      // modulo 2^64, like gm_search.cpp:110-114
         res->sum.wt_levels_bsearch = hs[3];
         // algorithmic bytes: 32 B per super-block read (+ one sample per occurrence)
         ws->stats[KS_LOCATE].algorithmic_bytes += 32ull * hs[1] + pos_bytes * res->sum.located_occurrences;
@@ -1300,8 +1305,8 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
     for (uint64_t s = 0; s < qq.nsub; ++s) res->sum.logical_occurrences += pl.occ[s];
     unsigned long long* d_stats = nullptr;
     auto run = [&]() -> vlg_status {
-        VLG_HIP_TRY(hipMalloc((void**)&d_stats, 6 * 8));
-        VLG_HIP_TRY(hipMemsetAsync(d_stats, 0, 6 * 8, st));
+        VLG_HIP_TRY(hipMalloc((void**)&d_stats, kStatsWords * 8));
+        VLG_HIP_TRY(hipMemsetAsync(d_stats, 0, kStatsWords * 8, st));
         PhaseTrace tr(st);
         const uint64_t fixed = 8ull << 20;
         if (ws->cap_bytes <= 2 * fixed) return fail(VLG_E_WORKSPACE, "workspace cap too small");
@@ -1339,10 +1344,11 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
         tr.mark("join lists copied + checked");
         if (vlg_status s = run_joins<uint64_t>(n_positions, &qq, ws, res, pl, poff, P, A, pc_cap ? P + pc_first : nullptr, pc_cap, 0, n_joins, jp,
                                                d_stats, tr)) return s;
-        unsigned long long hs[4];
+        unsigned long long hs[kStatsWords];
         VLG_HIP_TRY(hipMemcpyAsync(hs, d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
         VLG_HIP_TRY(hipStreamSynchronize(st));
-        res->sum.checksum = hs[2];
+        res->sum.checksum = 0;
+        for (uint32_t i = 0; i < kChecksumSlots; ++i) res->sum.checksum += hs[kStatsChecksum + i];
         return VLG_OK;
     };
     vlg_status stt;
