@@ -628,7 +628,8 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
             if (i + 1 < k) { r.nlo = q->lo[s0 + i + 1]; r.nhi = q->hi[s0 + i + 1]; }
             r.fq = by_pivot ? kNone : nfq; r.level = i; r.dist = k - 1 - i;
             r.abit = ~0ull;
-            if (i + 1 < k) {
+            // the pivot list keeps every element: the join reads it where it lies (no activity bits, no private copy)
+            if (i + 1 < k && !(by_pivot && i == pivot)) {
                 r.abit = abit;                                   // on a run boundary
                 abit += (pl.occ[s0 + i] + kRun - 1) / kRun * kRun;
                 fg.cidx[s0 + i - fg.sub0] = (uint32_t)cseg.size();
@@ -748,10 +749,12 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
     // a query that lost a whole list has no match; one whose survivors do not fit a chunk is joined on its full lists
     for (uint64_t qi = fg.g0; qi < fg.g1; ++qi) {
         const uint64_t s0 = q->qsub[qi] - fg.sub0, k = q->qsub[qi + 1] - q->qsub[qi];
-        if (!k || fg.cidx[s0] == kNone) continue;
+        bool was_filtered = false;
+        for (uint64_t i = 0; i < k; ++i) was_filtered |= fg.cidx[s0 + i] != kNone;
+        if (!was_filtered) continue;
         bool dead = false;
         uint64_t sum = 0;
-        for (uint64_t i = 0; i + 1 < k; ++i) { dead |= fg.eff[s0 + i] == 0; sum += fg.eff[s0 + i]; }
+        for (uint64_t i = 0; i + 1 < k; ++i) { dead |= fg.eff[s0 + i] == 0; if (fg.cidx[s0 + i] != kNone) sum += fg.eff[s0 + i]; }
         if (dead) for (uint64_t i = 0; i < k; ++i) fg.eff[s0 + i] = 0;
         else if (sum > fg.pc_cap) for (uint64_t i = 0; i < k; ++i) { fg.eff[s0 + i] = pl.occ[fg.sub0 + s0 + i]; fg.cidx[s0 + i] = kNone; }
     }
