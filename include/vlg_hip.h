@@ -357,7 +357,7 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
 /* Options: "dedup" (default 1): share one located+sorted list between all sub-patterns of a batch that
  * have the same SA interval; 0 = locate every sub-pattern of every query separately like the reference.
  * "sweep" (default 1): locate by the synchronous sorted LF sweep (coalesced super-block reads) when the batch has
- * at least "sweep_min" occurrences (default 2^22); the last "sweep_tail" (default 2^20) stragglers and smaller
+ * at least "sweep_min" occurrences (default 2^22); the last "sweep_tail" (default 2^22) stragglers and smaller
  * batches use the one-lane-per-occurrence random-access kernel.
  * "trail" (default 1, needs "dedup"): inside a sorted sweep an occurrence that steps onto an SA index another occurrence
  * has visited stops there and takes that occurrence's position plus the distance (csa[i] = csa[LF(i)] + 1 shared between

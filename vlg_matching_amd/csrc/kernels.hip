@@ -650,11 +650,14 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
     block_add<3>(v, dst);
 }
 
-// stragglers: finish the few elements still alive after the sweep, one lane each
+// stragglers: finish the few elements still alive after the sweep, one lane each.  With shared trails a straggler still stops on
+// the first index another element stood on during the sweep (it writes no marks itself any more: whoever it could meet from now
+// on is a straggler too and walks at the same pace).
 template <class BV, typename pos_t>
 __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uint64_t* __restrict__ val, uint64_t count, uint32_t step,
                                                          pos_t* __restrict__ out, unsigned long long* __restrict__ stats,
-                                                         uint64_t* __restrict__ rec, uint64_t slot0)
+                                                         uint64_t* __restrict__ rec, uint64_t slot0, const uint64_t* __restrict__ trail,
+                                                         uint64_t gen)
 {
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
@@ -667,7 +670,22 @@ __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uin
         uint64_t v64 = val[e];
         uint64_t i = v64 & kPosMask;
         uint64_t off = step;
+        bool followed = false;
         while (i % dens) {
+            if (trail) {
+                const uint64_t m = trail[i];
+                if ((m >> 48 << 48) == gen && (m & 0xFFFFu) < off) {             // someone stood here earlier in this sweep: take its trail
+                    const uint64_t owner = ((m >> 16) & 0xFFFFFFFFull) - 1, delta = off - (m & 0xFFFFu);
+                    const uint64_t ro = rec[owner];
+                    uint64_t r;
+                    if (ro == ~0ull) r = (delta << kShift) | owner;               // still walking: follow it
+                    else if ((ro >> kShift) == 0) r = ro + delta;                  // its position is known
+                    else r = ro + (delta << kShift);                               // it follows someone itself: follow that one
+                    rec[slot0 + (v64 >> kShift)] = r;
+                    followed = true;
+                    break;
+                }
+            }
             uint32_t v = 0;
             uint64_t pos = i;
             for (;;) {
@@ -683,6 +701,7 @@ __global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uin
             }
             ++off; ++n_lf;
         }
+        if (followed) continue;
         uint64_t r = (uint64_t)samples[i / dens] + off;
         if (r >= iv.n) r -= iv.n;
         if (rec) rec[slot0 + (v64 >> kShift)] = r;
@@ -905,10 +924,10 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             if (timer) timer->begin(0);
             if (iv.bv_kind == kBvRrr63)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<RrrBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, alive,
-                                   step, out, d_stats, trail ? rec : nullptr, t0);
+                                   step, out, d_stats, trail ? rec : nullptr, t0, trail, gen);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<PlainBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a,
-                                   alive, step, out, d_stats, trail ? rec : nullptr, t0);
+                                   alive, step, out, d_stats, trail ? rec : nullptr, t0, trail, gen);
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
         }

@@ -64,7 +64,7 @@ struct vlg_workspace {
     bool list_sort = true;      // 32-bit positions: every list sorted inside itself (list_sort.hpp); off: the two rocPRIM paths below
     uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
-    uint64_t sweep_tail = 1ull << 20;   // stragglers of a sweep are finished one lane each
+    uint64_t sweep_tail = 1ull << 22;   // stragglers of a sweep are finished one lane each (C3, ms per batch: 2^20 214.0, 2^22 213.4, 2^24 213.7, 2^26 213.8)
     // trail table of the sorted sweep: it lives at the head of the arena and carries generation stamps, so it is cleared once, not per batch
     uint32_t trail_gen = 0;             // generation of the last sweep that wrote it; 0 = content unknown
     uint64_t trail_n = 0;               // text length it was last used for
