@@ -991,6 +991,14 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             ++Q1;
         }
         ++epoch;
+        // distinct lists in ascending id order: SA order when the plan came from the device (ids are ranks of the intervals), which is
+        // the order the sorted sweep wants to start in
+        if (dlist.size() > 1) {
+            if (dlist.size() * 8 >= pl.dl.size()) {               // most ids are used: walk the stamps instead of sorting
+                size_t w = 0;
+                for (uint32_t d = 0; d < (uint32_t)pl.dl.size(); ++d) if (stamp[d] == epoch - 1) dlist[w++] = d;
+            } else std::sort(dlist.begin(), dlist.end());
+        }
         // ---- arena: physical lists first, filter state and join scratch behind them ---------------------
         size_t sort_tmp = 0;
         if (phys) {
@@ -1067,6 +1075,111 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
 
 }  // namespace
 
+namespace {
+
+// ---- distinct SA intervals of a batch, found on the device ----------------------------------------------------------------------
+// key of a sub-pattern: l << 32 | (occurrences - 1) (n <= 2^32), ~0 for the sub-patterns of a query that has an empty list
+__global__ void interval_keys_kernel(const uint64_t* __restrict__ l, const uint64_t* __restrict__ r, const uint64_t* __restrict__ qsub,
+                                     uint64_t nq, uint64_t* __restrict__ keys, uint32_t* __restrict__ sub)
+{
+    for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < nq; qi += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = qsub[qi], b = qsub[qi + 1];
+        bool live = b > a;
+        for (uint64_t s = a; s < b && live; ++s) live = r[s] + 1 - l[s] > 0;
+        for (uint64_t s = a; s < b; ++s) {
+            keys[s] = live ? (l[s] << 32) | (r[s] - l[s]) : ~0ull;
+            sub[s] = (uint32_t)s;
+        }
+    }
+}
+__global__ void interval_heads_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ head)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
+        head[j] = (keys[j] != ~0ull && (j == 0 || keys[j] != keys[j - 1])) ? 1u : 0u;
+}
+// gid = inclusive scan of the heads: the (gid-1)-th distinct interval, in ascending SA order
+__global__ void interval_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ sub, const uint32_t* __restrict__ gid,
+                                        uint64_t n, uint32_t* __restrict__ did, uint64_t* __restrict__ dl, uint64_t* __restrict__ docc)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = keys[j];
+        if (k == ~0ull) { did[sub[j]] = 0xFFFFFFFFu; continue; }
+        const uint32_t g = gid[j] - 1;
+        did[sub[j]] = g;
+        if (j == 0 || keys[j - 1] != k) { dl[g] = k >> 32; docc[g] = (k & 0xFFFFFFFFull) + 1; }
+    }
+}
+
+// Plan of a batch (which sub-patterns are live, which distinct interval each one is) from the intervals in d_l / d_r.
+// Identical SA intervals are the same occurrence list: each distinct one is located + sorted once per super-chunk and shared.
+// The distinct intervals are numbered in ascending SA order, so the sweep that locates them starts globally sorted.
+vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_t* d_l, const uint64_t* d_r, Plan& pl, uint64_t& logical)
+{
+    hipStream_t st = ws->stream;
+    const uint64_t nsub = q->nsub, nq = q->nq;
+    pl.occ.assign(nsub, 0);
+    pl.did.assign(nsub, 0);
+    if (!nsub) return VLG_OK;
+    uint8_t* mem = nullptr;
+    size_t sort_tb = 0, scan_tb = 0;
+    {
+        rocprim::double_buffer<uint64_t> nk(nullptr, nullptr);
+        rocprim::double_buffer<uint32_t> nv(nullptr, nullptr);
+        VLG_HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_tb, nk, nv, nsub, 0, 64, st));
+        uint32_t* nu = nullptr;
+        VLG_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_tb, nu, nu, nsub, rocprim::plus<uint32_t>(), st));
+    }
+    const uint64_t n8 = align_up(nsub * 8, 256), n4 = align_up(nsub * 4, 256);
+    const uint64_t bytes = 4 * n8 + 5 * n4 + align_up((nq + 1) * 8, 256) + align_up(std::max(sort_tb, scan_tb), 256) + 1024;
+    VLG_HIP_TRY(hipMalloc((void**)&mem, bytes));
+    uint64_t* keys_a = (uint64_t*)mem;
+    uint64_t* keys_b = (uint64_t*)(mem + n8);
+    uint64_t* d_dl = (uint64_t*)(mem + 2 * n8);
+    uint64_t* d_docc = (uint64_t*)(mem + 3 * n8);
+    uint32_t* sub_a = (uint32_t*)(mem + 4 * n8);
+    uint32_t* sub_b = (uint32_t*)(mem + 4 * n8 + n4);
+    uint32_t* d_head = (uint32_t*)(mem + 4 * n8 + 2 * n4);
+    uint32_t* d_gid = (uint32_t*)(mem + 4 * n8 + 3 * n4);
+    uint32_t* d_did = (uint32_t*)(mem + 4 * n8 + 4 * n4);
+    uint64_t* d_qsub = (uint64_t*)(mem + 4 * n8 + 5 * n4);
+    void* d_tmp = mem + 4 * n8 + 5 * n4 + align_up((nq + 1) * 8, 256);
+    auto run = [&]() -> vlg_status {
+        svec<uint64_t> h_qsub(q->qsub.begin(), q->qsub.end());
+        VLG_HIP_TRY(hipMemcpyAsync(d_qsub, h_qsub.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(interval_keys_kernel, dim3(grid_for(nq, 2048)), dim3(256), 0, st, d_l, d_r, d_qsub, nq, keys_a, sub_a);
+        rocprim::double_buffer<uint64_t> dk(keys_a, keys_b);
+        rocprim::double_buffer<uint32_t> dv(sub_a, sub_b);
+        size_t tb = sort_tb;
+        VLG_HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tb, dk, dv, nsub, 0, 64, st));
+        hipLaunchKernelGGL(interval_heads_kernel, dim3(grid_for(nsub, 2048)), dim3(256), 0, st, dk.current(), nsub, d_head);
+        tb = scan_tb;
+        VLG_HIP_TRY(rocprim::inclusive_scan(d_tmp, tb, d_head, d_gid, nsub, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(interval_scatter_kernel, dim3(grid_for(nsub, 2048)), dim3(256), 0, st, dk.current(), dv.current(), d_gid, nsub, d_did,
+                           d_dl, d_docc);
+        VLG_HIP_TRY(hipGetLastError());
+        uint32_t nd = 0;
+        svec<uint32_t> h_did(nsub);
+        VLG_HIP_TRY(hipMemcpyAsync(&nd, d_gid + (nsub - 1), 4, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipMemcpyAsync(h_did.data(), d_did, nsub * 4, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipStreamSynchronize(st));
+        pl.dl.resize(nd);
+        pl.docc.resize(nd);
+        if (nd) {
+            VLG_HIP_TRY(hipMemcpyAsync(pl.dl.data(), d_dl, (uint64_t)nd * 8, hipMemcpyDeviceToHost, st));
+            VLG_HIP_TRY(hipMemcpyAsync(pl.docc.data(), d_docc, (uint64_t)nd * 8, hipMemcpyDeviceToHost, st));
+            VLG_HIP_TRY(hipStreamSynchronize(st));
+        }
+        for (uint64_t s = 0; s < nsub; ++s)
+            if (h_did[s] != 0xFFFFFFFFu) { pl.did[s] = h_did[s]; pl.occ[s] = pl.docc[h_did[s]]; logical += pl.occ[s]; }
+        return VLG_OK;
+    };
+    const vlg_status stt = run();
+    (void)hipFree(mem);
+    return stt;
+}
+
+}  // namespace
+
 extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result** out)
 {
     if (!idx || !q || !ws || !out) return fail(VLG_E_INVALID, "null argument");
@@ -1099,6 +1212,11 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
             if (vlg_status s = launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_l, d_r, d_stats + 3, st)) return s;
         }
         tr.mark("backward search");
+        Plan pl;
+        const bool device_plan = ws->dedup && idx->hdr.n <= (1ull << 32) && nsub > 0 && nsub < 0xFFFFFFF0ull;
+        if (device_plan) {
+            if (vlg_status s = plan_on_device(q, ws, d_l, d_r, pl, res->sum.logical_occurrences)) return s;
+        } else {
         svec<uint64_t> l(nsub), r(nsub);
         if (nsub) {
             VLG_HIP_TRY(hipMemcpyAsync(l.data(), d_l, nsub * 8, hipMemcpyDeviceToHost, st));
@@ -1107,7 +1225,6 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         VLG_HIP_TRY(hipStreamSynchronize(st));
         // a query with an empty occurrence list has no match: none of its lists is materialised
         // (vlg_index.hpp:315-316 returns at the first empty range)
-        Plan pl;
         pl.occ.assign(nsub, 0);
         pl.did.assign(nsub, 0);
         for (uint64_t qi = 0; qi < q->nq; ++qi) {
@@ -1144,6 +1261,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
             } else {
                 for (uint64_t s : order) { pl.did[s] = (uint32_t)pl.dl.size(); pl.dl.push_back(l[s]); pl.docc.push_back(pl.occ[s]); }
             }
+        }
         }
         tr.mark("intervals to host + plan");
         const uint64_t pos_bytes = idx->hdr.sample_bytes;
