@@ -591,6 +591,7 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
                         Arena& A /* advanced past the state the join chunks still need */, FilterGroup& fg)
 {
     hipStream_t st = ws->stream;
+    PhaseTrace ft(st);
     const uint32_t g = filter_block_shift(n_positions);
     const uint64_t nblocks = (n_positions >> g) + 1, nbw = (nblocks + 63) / 64;
     const uint64_t nsub = q->qsub[fg.g1] - q->qsub[fg.g0];
@@ -744,7 +745,9 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
     VLG_HIP_TRY(hipGetLastError());
     svec<unsigned long long> segcnt(cseg.size());
     VLG_HIP_TRY(hipMemcpyAsync(segcnt.data(), d_segcnt, cseg.size() * 8, hipMemcpyDeviceToHost, st));
+    ft.mark("  filter: launched");
     VLG_HIP_TRY(hipStreamSynchronize(st));
+    ft.mark("  filter: counts back");
     for (uint32_t c = 0; c < cseg.size(); ++c) fg.eff[seg_sub[cseg[c]]] = segcnt[c];
     // a query that lost a whole list has no match; one whose survivors do not fit a chunk is joined on its full lists
     for (uint64_t qi = fg.g0; qi < fg.g1; ++qi) {

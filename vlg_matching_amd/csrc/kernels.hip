@@ -862,8 +862,10 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
                                pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
                                hipStream_t stream, LaunchTimer* timer, uint64_t* trail /* n words, or null */, uint64_t* rec /* total words */,
-                               uint32_t* trail_gen /* generation of the last sweep that used this table; 0 = unknown content */)
+                               uint32_t* trail_gen /* generation of the last sweep that used this table; 0 = unknown content */,
+                               const std::function<vlg_status()>* while_first_step /* host work to do while the first step runs, or null */)
 {
+    bool hook_due = while_first_step != nullptr;
     constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
     if (iv.n > (1ull << kShift)) return fail(VLG_E_UNSUPPORTED, "sorted sweep: text too long for the packed position");
     const unsigned bits = bit_width64(iv.sigma);            // keys 0..sigma (sigma = finished, sorts last)
@@ -913,6 +915,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             VLG_HIP_TRY(se);
             unsigned long long done = 0;
             VLG_HIP_TRY(hipMemcpyAsync(&done, d_counter, 8, hipMemcpyDeviceToHost, stream));
+            if (hook_due) { hook_due = false; if (vlg_status hs = (*while_first_step)()) return hs; }
             VLG_HIP_TRY(hipStreamSynchronize(stream));
             key_a = dk.current(); key_b = dk.alternate();
             val_a = dv.current(); val_b = dv.alternate();
@@ -932,6 +935,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             VLG_HIP_TRY(hipGetLastError());
         }
     }
+    if (hook_due) { hook_due = false; if (vlg_status hs = (*while_first_step)()) return hs; }
     if (trail) {
         // every element has a record now; jump pointers until all of them are positions
         for (uint32_t round = 0;; ++round) {
@@ -952,10 +956,10 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
 }
 template vlg_status launch_locate_sweep<uint32_t>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint32_t*, uint64_t*,
                                                   uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, uint64_t,
-                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*, uint32_t*);
+                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*, uint32_t*, const std::function<vlg_status()>*);
 template vlg_status launch_locate_sweep<uint64_t>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint64_t*, uint64_t*,
                                                   uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, uint64_t,
-                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*, uint32_t*);
+                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*, uint32_t*, const std::function<vlg_status()>*);
 
 }  // namespace vlg
 

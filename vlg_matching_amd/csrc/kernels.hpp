@@ -1,5 +1,6 @@
 // Internal launch interface between kernels.hip and search.hip.
 #pragma once
+#include <functional>
 #include "common.hpp"
 
 namespace vlg {
@@ -26,6 +27,7 @@ template <typename pos_t>
 vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
                                pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
-                               hipStream_t stream, LaunchTimer* timer, uint64_t* trail, uint64_t* rec, uint32_t* trail_gen);
+                               hipStream_t stream, LaunchTimer* timer, uint64_t* trail, uint64_t* rec, uint32_t* trail_gen,
+                               const std::function<vlg_status()>* while_first_step = nullptr);
 
 }  // namespace vlg

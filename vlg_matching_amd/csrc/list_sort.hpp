@@ -179,12 +179,21 @@ inline uint64_t list_sort_scratch_bytes(uint64_t n_long, uint64_t n_tiles, uint6
     return n_long * sizeof(SortList) + (n_tiles + n_chunks) * 4 + n_tiles * 256 * 6 + n_chunks * 256 * 4 + 8 * 256;
 }
 
-// P: the lists (in suffix-array order inside), `other`: a second buffer of the same size; the sorted lists end up in P.
-// A (arena) provides the histogram scratch; everything is enqueued on `st`, nothing is waited for.
-inline vlg_status list_sort_u32(uint32_t* P, uint32_t* other, const svec<uint64_t>& off64, const uint64_t* d_off64, uint32_t nd, unsigned bits,
-                                Arena& A, hipStream_t st)
+// The host side comes in two halves so that the tables are built and uploaded BEFORE the lists exist (while locate still runs):
+// list_sort_prepare sizes and uploads everything (status VLG_E_WORKSPACE: no room in the arena -- nothing was carved or launched,
+// the caller takes the device-wide sort), list_sort_enqueue launches the kernels.
+struct ListSortPlan {
+    bool ready = false;
+    uint32_t n_small[3] = {0, 0, 0};
+    uint32_t* d_small[3] = {nullptr, nullptr, nullptr};
+    uint32_t n_long = 0, n_tiles = 0, n_chunks = 0;
+    SortList* d_longs = nullptr;
+    uint32_t *d_tile_list = nullptr, *d_chunk_list = nullptr, *d_tot = nullptr, *d_pref = nullptr;
+    uint16_t* d_hist = nullptr;
+};
+
+inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Arena& A, hipStream_t st, ListSortPlan& lp)
 {
-    // size classes
     svec<uint32_t> small[3];                                       // <= 256, <= 1024, <= kSortTile elements
     svec<SortList> longs;
     svec<uint32_t> tile_list, chunk_list;
@@ -203,47 +212,55 @@ inline vlg_status list_sort_u32(uint32_t* P, uint32_t* other, const svec<uint64_
             chunk_list.insert(chunk_list.end(), chunks, m);
         }
     }
-    {   // room for everything, or nothing is launched (the caller then takes the device-wide sort)
+    {   // room for everything, or nothing is carved
         uint64_t need = 4096;
         for (int c = 0; c < 3; ++c) need += align_up(small[c].size() * 4, 256);
         if (!longs.empty()) need += list_sort_scratch_bytes(longs.size(), tile_list.size(), chunk_list.size());
         if (A.failed || A.size - A.used < need) return fail(VLG_E_WORKSPACE, "list sort: no room for its tables");
     }
     for (int c = 0; c < 3; ++c) {
+        lp.n_small[c] = (uint32_t)small[c].size();
         if (small[c].empty()) continue;
-        uint32_t* d_lists = A.take<uint32_t>(small[c].size());
-        if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (list sort)");
-        VLG_HIP_TRY(hipMemcpyAsync(d_lists, small[c].data(), small[c].size() * 4, hipMemcpyHostToDevice, st));
-        const uint32_t n = (uint32_t)small[c].size();
-        if (c == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<64, 4>), dim3(n), dim3(64), 0, st, P, d_off64, d_lists, n, bits);
-        else if (c == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<256, 4>), dim3(n), dim3(256), 0, st, P, d_off64, d_lists, n, bits);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<256, 16>), dim3(n), dim3(256), 0, st, P, d_off64, d_lists, n, bits);
-        VLG_HIP_TRY(hipGetLastError());
+        lp.d_small[c] = A.take<uint32_t>(small[c].size());
+        VLG_HIP_TRY(hipMemcpyAsync(lp.d_small[c], small[c].data(), small[c].size() * 4, hipMemcpyHostToDevice, st));
     }
-    if (longs.empty()) return VLG_OK;
-    const uint32_t n_long = (uint32_t)longs.size(), n_tiles = (uint32_t)tile_list.size(), n_chunks = (uint32_t)chunk_list.size();
-    if (A.size - A.used < list_sort_scratch_bytes(n_long, n_tiles, n_chunks)) return fail(VLG_E_WORKSPACE, "list sort: no room for the histograms");
-    SortList* d_longs = A.take<SortList>(n_long);
-    uint32_t* d_tile_list = A.take<uint32_t>(n_tiles);
-    uint32_t* d_chunk_list = A.take<uint32_t>(n_chunks);
-    uint16_t* d_hist = A.take<uint16_t>((uint64_t)n_tiles * 256);
-    uint32_t* d_tot = A.take<uint32_t>((uint64_t)n_chunks * 256);
-    uint32_t* d_pref = A.take<uint32_t>((uint64_t)n_tiles * 256);
+    lp.n_long = (uint32_t)longs.size(); lp.n_tiles = (uint32_t)tile_list.size(); lp.n_chunks = (uint32_t)chunk_list.size();
+    if (lp.n_long) {
+        lp.d_longs = A.take<SortList>(lp.n_long);
+        lp.d_tile_list = A.take<uint32_t>(lp.n_tiles);
+        lp.d_chunk_list = A.take<uint32_t>(lp.n_chunks);
+        lp.d_hist = A.take<uint16_t>((uint64_t)lp.n_tiles * 256);
+        lp.d_tot = A.take<uint32_t>((uint64_t)lp.n_chunks * 256);
+        lp.d_pref = A.take<uint32_t>((uint64_t)lp.n_tiles * 256);
+        if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (list sort)");
+        VLG_HIP_TRY(hipMemcpyAsync(lp.d_longs, longs.data(), lp.n_long * sizeof(SortList), hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemcpyAsync(lp.d_tile_list, tile_list.data(), lp.n_tiles * 4, hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemcpyAsync(lp.d_chunk_list, chunk_list.data(), lp.n_chunks * 4, hipMemcpyHostToDevice, st));
+    }
     if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (list sort)");
-    VLG_HIP_TRY(hipMemcpyAsync(d_longs, longs.data(), n_long * sizeof(SortList), hipMemcpyHostToDevice, st));
-    VLG_HIP_TRY(hipMemcpyAsync(d_tile_list, tile_list.data(), n_tiles * 4, hipMemcpyHostToDevice, st));
-    VLG_HIP_TRY(hipMemcpyAsync(d_chunk_list, chunk_list.data(), n_chunks * 4, hipMemcpyHostToDevice, st));
+    lp.ready = true;
+    return VLG_OK;
+}
+
+// P: the lists (in suffix-array order inside), `other`: a second buffer of the same size; the sorted lists end up in P.
+inline vlg_status list_sort_enqueue(const ListSortPlan& lp, uint32_t* P, uint32_t* other, const uint64_t* d_off64, unsigned bits, hipStream_t st)
+{
+    if (lp.n_small[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<64, 4>), dim3(lp.n_small[0]), dim3(64), 0, st, P, d_off64, lp.d_small[0], lp.n_small[0], bits);
+    if (lp.n_small[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<256, 4>), dim3(lp.n_small[1]), dim3(256), 0, st, P, d_off64, lp.d_small[1], lp.n_small[1], bits);
+    if (lp.n_small[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<256, 16>), dim3(lp.n_small[2]), dim3(256), 0, st, P, d_off64, lp.d_small[2], lp.n_small[2], bits);
+    VLG_HIP_TRY(hipGetLastError());
+    if (!lp.n_long) return VLG_OK;
     const unsigned passes = bits <= 16 ? 2 : 4;                    // even: the lists come back to P
     const unsigned dbits = (bits + passes - 1) / passes;          // <= 8
     uint32_t* src = P;
     uint32_t* dst = other;
     for (unsigned p = 0; p < passes; ++p) {
         const uint32_t shift = p * dbits, mask = (1u << dbits) - 1u;
-        hipLaunchKernelGGL(list_sort_hist_kernel, dim3(n_tiles), dim3(256), 0, st, src, d_longs, d_tile_list, n_tiles, shift, mask, d_hist);
-        hipLaunchKernelGGL(list_sort_chunk_kernel, dim3(n_chunks), dim3(256), 0, st, d_hist, d_longs, d_chunk_list, n_chunks, d_tot);
-        hipLaunchKernelGGL(list_sort_scan_kernel, dim3(n_long), dim3(256), 0, st, d_longs, n_long, d_tot);
-        hipLaunchKernelGGL(list_sort_prefix_kernel, dim3(n_chunks), dim3(256), 0, st, d_hist, d_longs, d_chunk_list, n_chunks, d_tot, d_pref);
-        hipLaunchKernelGGL(list_sort_scatter_kernel, dim3(n_tiles), dim3(256), 0, st, src, dst, d_longs, d_tile_list, n_tiles, shift, dbits, d_pref);
+        hipLaunchKernelGGL(list_sort_hist_kernel, dim3(lp.n_tiles), dim3(256), 0, st, src, lp.d_longs, lp.d_tile_list, lp.n_tiles, shift, mask, lp.d_hist);
+        hipLaunchKernelGGL(list_sort_chunk_kernel, dim3(lp.n_chunks), dim3(256), 0, st, lp.d_hist, lp.d_longs, lp.d_chunk_list, lp.n_chunks, lp.d_tot);
+        hipLaunchKernelGGL(list_sort_scan_kernel, dim3(lp.n_long), dim3(256), 0, st, lp.d_longs, lp.n_long, lp.d_tot);
+        hipLaunchKernelGGL(list_sort_prefix_kernel, dim3(lp.n_chunks), dim3(256), 0, st, lp.d_hist, lp.d_longs, lp.d_chunk_list, lp.n_chunks, lp.d_tot, lp.d_pref);
+        hipLaunchKernelGGL(list_sort_scatter_kernel, dim3(lp.n_tiles), dim3(256), 0, st, src, dst, lp.d_longs, lp.d_tile_list, lp.n_tiles, shift, dbits, lp.d_pref);
         VLG_HIP_TRY(hipGetLastError());
         std::swap(src, dst);
     }

@@ -78,14 +78,14 @@ namespace {
 // VLG_TRACE=1: wall time of the host phases of a batch on stderr (the stream is drained at every mark, so the figures
 // include the kernels launched in the phase)
 struct PhaseTrace {
-    bool on;
+    bool on, sync;          // VLG_TRACE=host: host time between the marks only (no wait for the stream: the batch runs as it does untraced)
     hipStream_t st;
     std::chrono::steady_clock::time_point t0;
-    explicit PhaseTrace(hipStream_t s) : on(getenv("VLG_TRACE") != nullptr), st(s), t0(std::chrono::steady_clock::now()) {}
+    explicit PhaseTrace(hipStream_t s) : on(getenv("VLG_TRACE") != nullptr), sync(!on || strcmp(getenv("VLG_TRACE"), "host") != 0), st(s), t0(std::chrono::steady_clock::now()) {}
     void mark(const char* what)
     {
         if (!on) return;
-        (void)hipStreamSynchronize(st);
+        if (sync) (void)hipStreamSynchronize(st);
         const auto t1 = std::chrono::steady_clock::now();
         fprintf(stderr, "[vlg trace] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
@@ -435,6 +435,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
                           uint64_t* trail /* n words at the head of the arena when trails are shared, else null */)
 {
     hipStream_t st = ws->stream;
+    PhaseTrace bt(st);
     const uint32_t nd = (uint32_t)dlist.size();
     svec<uint64_t> off64(nd + 1), lh(nd);
     svec<uint32_t> off32(nd + 1);
@@ -450,7 +451,6 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     Pc_out = nullptr;
     pc_cap = 0;
     if (!acc) return VLG_OK;
-    const unsigned bits = std::max(1u, bit_width64(idx->hdr.n >= 2 ? idx->hdr.n - 2 : 0));   // the largest position is n - 2 (n - 1 is the sentinel)
     const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (sizeof(pos_t) == 4 ? 32 : 33));
     pos_t* Pa = A.take<pos_t>(acc);
     // scratch of the sweep (20 B per element); the sorted lists Pb reuse it once locate is done
@@ -465,21 +465,35 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     VLG_HIP_TRY(hipMemcpyAsync(d_off64, off64.data(), (nd + 1) * 8, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_off32, off32.data(), (nd + 1) * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_lh, lh.data(), nd * 8, hipMemcpyHostToDevice, st));
+    uint64_t* rec = nullptr;
+    if (use_sweep && trail) {                                                     // (trails are shared inside one sweep)
+        rec = A.take<uint64_t>(acc);
+        if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (trail records)");
+    }
+    // the sort's tables only depend on the list lengths: they are built and uploaded while the first step of locate runs
+    const uint64_t sort_mark = A.used;
+    ListSortPlan lsp;
+    const unsigned bits = std::max(1u, bit_width64(idx->hdr.n >= 2 ? idx->hdr.n - 2 : 0));   // the largest position is n - 2 (n - 1 is the sentinel)
+    const std::function<vlg_status()> plan_sort = [&]() -> vlg_status {
+        if (sizeof(pos_t) != 4 || !ws->list_sort) return VLG_OK;
+        const vlg_status ls = list_sort_prepare(off64, nd, A, st, lsp);
+        if (ls != VLG_OK && ls != VLG_E_WORKSPACE) return ls;      // no room for its tables: the device-wide sort below
+        if (ls != VLG_OK) A.used = sort_mark;
+        return VLG_OK;
+    };
     if (use_sweep) {
         const uint64_t cap = std::min<uint64_t>(acc, sweep_batch_max<pos_t>());
-        uint64_t* rec = nullptr;
-        if (trail) {                                                              // (trails are shared inside one sweep)
-            rec = A.take<uint64_t>(acc);
-            if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (trail records)");
-        }
         uint64_t* val_a = reinterpret_cast<uint64_t*>(scratch);
         uint64_t* val_b = val_a + cap;
         uint16_t* key_a = reinterpret_cast<uint16_t*>(val_b + cap);
         uint16_t* key_b = key_a + cap;
         SweepTimer timer(ws);
+        bt.mark("  physical: tables + sort plan");
         if (vlg_status s = launch_locate_sweep<pos_t>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b,
-                                               d_tmp, sort_tmp, d_counter, d_stats, ws->sweep_tail, st, &timer, trail, rec, &ws->trail_gen)) return s;
+                                               d_tmp, sort_tmp, d_counter, d_stats, ws->sweep_tail, st, &timer, trail, rec, &ws->trail_gen, &plan_sort)) return s;
+        bt.mark("  physical: sweep");
     } else {
+        if (vlg_status s = plan_sort()) return s;
         {
             Timed t(ws, KS_EXPAND, 0);
             if (vlg_status s = launch_expand<pos_t>(d_lh, d_off64, nd, acc, Pa, nullptr, st)) return s;
@@ -494,17 +508,14 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     const bool global_sort = acc >= ws->global_sort_min && bits + list_bits <= 64;
     uint64_t dead_bytes = 0;                              // free bytes behind the sorted lists (the survivors of the window filter go there)
     bool sorted = false;
-    if (sizeof(pos_t) == 4 && ws->list_sort) {
+    if (lsp.ready) {
         // 32-bit positions: sorted inside every list (list_sort.hpp) -- 4 passes of 8 B per element instead of 6 of 16 B
-        const uint64_t mark = A.used;
         Timed t(ws, KS_SORT, 2ull * acc * sizeof(pos_t));
-        const vlg_status ls = list_sort_u32(reinterpret_cast<uint32_t*>(Pa), reinterpret_cast<uint32_t*>(scratch), off64, d_off64, nd, bits, A, st);
-        A.used = mark;                                    // its tables are dead once its kernels have run (stream order)
-        if (ls == VLG_OK) {
-            sorted = true;
-            P_out = Pa;
-            dead_bytes = (uint64_t)(scratch - reinterpret_cast<uint8_t*>(Pa)) + acc * kPhysScratchPerElem<pos_t>() - acc * sizeof(pos_t);
-        } else if (ls != VLG_E_WORKSPACE) return ls;      // no room for its tables: the device-wide sort below
+        if (vlg_status ls = list_sort_enqueue(lsp, reinterpret_cast<uint32_t*>(Pa), reinterpret_cast<uint32_t*>(scratch), d_off64, bits, st)) return ls;
+        A.used = sort_mark;                               // its tables are dead once its kernels have run (stream order)
+        sorted = true;
+        P_out = Pa;
+        dead_bytes = (uint64_t)(scratch - reinterpret_cast<uint8_t*>(Pa)) + acc * kPhysScratchPerElem<pos_t>() - acc * sizeof(pos_t);
     }
     if (sorted) {
     } else if (global_sort) {
@@ -563,37 +574,34 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
     ResultPiece piece;
     piece.q0 = q0; piece.q1 = q1;
     // ---- host-side metadata of the chunk: segments in class-major order (dist descending) -------------
+    // The filtered sub-patterns of the chunk are collected on the same walk (in Pc order): their compaction is launched first so
+    // that it runs while the rest of the metadata is built.
     svec<QueryMeta> qm(nq);
     uint32_t kmax = 0;
-    for (uint64_t qi = q0; qi < q1; ++qi) {
-        uint32_t k = (uint32_t)(q->qsub[qi + 1] - q->qsub[qi]);
-        QueryMeta& Q = qm[qi - q0];
-        Q.k = k; Q.end_len = q->end_len[qi]; Q.out_first = Q.out_tuple = 0; Q.seg0 = kNone;
-        bool live = k > 0 && eo(q->qsub[qi]) > 0;
-        if (live) kmax = std::max(kmax, k);
-    }
-    // filtered sub-patterns of the chunk (group relative), in Pc order; their compaction is launched first so that it runs while
-    // the rest of the metadata is built
-    std::vector<uint32_t> pc_tasks;
+    svec<uint32_t> t_seg, t_cidx;
+    svec<uint64_t> t_run0;
+    if (fg) { t_seg.reserve(nseg); t_cidx.reserve(nseg); t_run0.reserve(nseg + 1); }
+    t_run0.push_back(0);
     uint64_t pc_total = 0;
     for (uint64_t qi = q0; qi < q1; ++qi) {
-        const uint32_t k = qm[qi - q0].k;
-        if (!(k > 0 && eo(q->qsub[qi]) > 0)) continue;
-        for (uint32_t i = 0; i < k; ++i) {
-            const uint64_t s = q->qsub[qi] + i;
-            if (filtered(s)) { pc_tasks.push_back((uint32_t)(s - fg->sub0)); pc_total += eo(s); }
-        }
+        const uint64_t a = q->qsub[qi];
+        uint32_t k = (uint32_t)(q->qsub[qi + 1] - a);
+        QueryMeta& Q = qm[qi - q0];
+        Q.k = k; Q.end_len = q->end_len[qi]; Q.out_first = Q.out_tuple = 0; Q.seg0 = kNone;
+        if (!(k > 0 && eo(a) > 0)) continue;
+        kmax = std::max(kmax, k);
+        if (fg)
+            for (uint32_t i = 0; i < k; ++i) {
+                const uint32_t c = fg->cidx[a + i - fg->sub0];
+                if (c == kNone) continue;
+                t_cidx.push_back(c);
+                t_seg.push_back(fg->cseg[c]);
+                t_run0.push_back(t_run0.back() + (fg->crun0[c + 1] - fg->crun0[c]));
+                pc_total += fg->eff[a + i - fg->sub0];
+            }
     }
     // ---- private lists: compact the survivors of the chunk's filtered lists behind P ------------------------
-    if (!pc_tasks.empty()) {
-        svec<uint32_t> t_seg(pc_tasks.size()), t_cidx(pc_tasks.size());
-        svec<uint64_t> t_run0(pc_tasks.size() + 1, 0);
-        for (size_t i = 0; i < pc_tasks.size(); ++i) {
-            const uint32_t c = fg->cidx[pc_tasks[i]];
-            t_cidx[i] = c;
-            t_seg[i] = fg->cseg[c];
-            t_run0[i + 1] = t_run0[i] + (fg->crun0[c + 1] - fg->crun0[c]);
-        }
+    if (!t_seg.empty()) {
         const uint64_t runs = t_run0.back();
         uint32_t* d_tseg = A.take<uint32_t>(t_seg.size());
         uint32_t* d_tcidx = A.take<uint32_t>(t_cidx.size());
@@ -617,6 +625,7 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
         }
         VLG_HIP_TRY(hipGetLastError());
     }
+    jt.mark("  chunk: compaction launched");
     std::vector<uint32_t> cls_count(kmax + 1, 0), cls_first(kmax + 2, 0);   // segments per dist class
     for (uint64_t qi = q0; qi < q1; ++qi) {
         uint32_t k = qm[qi - q0].k;
@@ -649,7 +658,7 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
             m.level = i; m.dist = k - 1 - i;
             m.lo = q->lo[s]; m.hi = q->hi[s];
             if (filtered(s)) {                                   // private list of the query: the survivors, compacted behind P
-                m.pbegin = (uint32_t)((Pc - P) + pc_used);                 // the order of pc_tasks
+                m.pbegin = (uint32_t)((Pc - P) + pc_used);                 // the order of the compaction tasks
                 pc_used += eo(s);
             } else {
                 m.pbegin = poff[s];
@@ -926,17 +935,28 @@ vlg_status run_joins(uint64_t n_positions, const vlg_queries* q, vlg_workspace* 
             if (fg.any) fgp = &fg;
             tr.mark("filter group");
         }
-        auto eff = [&](uint64_t s) -> uint64_t { return fgp ? fgp->eff[s - fgp->sub0] : pl.occ[s]; };
-        auto pc_of = [&](uint64_t qi) -> uint64_t {                      // survivors the query puts into Pc
-            uint64_t t = 0;
-            if (fgp) for (uint64_t s = q->qsub[qi]; s < q->qsub[qi + 1]; ++s) if (fgp->cidx[s - fgp->sub0] != kNone) t += fgp->eff[s - fgp->sub0];
-            return t;
+        // one walk over the lists of a query: its join scratch (join_bytes_of), its slots (join_slots_of), the survivors it puts into Pc
+        const bool uniform_k = q->kmin == q->kmax;
+        auto cost_of = [&](uint64_t qi, uint64_t& bytes, uint64_t& slots, uint64_t& pc) {
+            const uint64_t a = q->qsub[qi];
+            const uint32_t k = (uint32_t)(q->qsub[qi + 1] - a);
+            uint64_t t = 0, first = 0;
+            pc = 0;
+            for (uint32_t i = 0; i < k; ++i) {
+                const uint64_t e = fgp ? fgp->eff[a + i - fgp->sub0] : pl.occ[a + i];
+                if (i == 0) first = e;
+                if (i + 1 < k || k == 1) t += e;
+                if (fgp && fgp->cidx[a + i - fgp->sub0] != kNone) pc += e;
+            }
+            bytes = t * kJoinBytesPerSlot + (k ? (uniform_k ? first : t) : 0) * kJoinBytesPerSlot0;
+            slots = t + 64ull * k;
         };
         uint64_t q0 = g0;
         while (q0 < g1) {
             uint64_t T = 0, S = 0, C = 0, q1 = q0;
             while (q1 < g1) {
-                uint64_t t = join_bytes_of(q, q1, eff), sl = join_slots_of(q, q1, eff), pc = pc_of(q1);
+                uint64_t t, sl, pc;
+                cost_of(q1, t, sl, pc);
                 if (sl > max_chunk_slots) return fail(VLG_E_WORKSPACE, "a query has more than 2^32 join slots");
                 if (((T + t > jp.want_bytes || S + sl > max_chunk_slots || C + pc > pc_cap) && q1 > q0) || (q1 - q0) >= (1u << 22)) break;
                 T += t; S += sl; C += pc;
