@@ -52,7 +52,9 @@ def test_c2_properties_and_mode_equivalence(c2):
     assert checked == s["n_matches"]
     assert int(first.astype(np.uint64).sum()) % (1 << 64) == s["checksum"]
     # --- identical results whatever the execution strategy ------------------------------------------------
-    for opts in ({"dedup": 0}, {"sweep": 0}, {"filter_min": 0, "filter_stream_min": 0}, {"sweep_min": 1, "sweep_tail": 1000}):
+    # (sweep_tail: how many elements are left to the stragglers' walk -- none of the sort, a third of it, all of it)
+    for opts in ({"dedup": 0}, {"sweep": 0}, {"filter_min": 0, "filter_stream_min": 0}, {"sweep_min": 1, "sweep_tail": 1000},
+                 {"sweep_min": 1, "sweep_tail": 1 << 25}, {"sweep_min": 1, "sweep_tail": 1 << 40, "trail": 0}):
         ws = Workspace()
         for k_, v_ in opts.items():
             ws.set_option(k_, v_)
@@ -130,6 +132,15 @@ def test_c3_headline_config_modes_and_oracle_sample(oracle):
     counts = a.counts
     assert (counts == b.counts).all() and (counts == c.counts).all()
     del b, c
+    ws.set_option("trail", 1)
+    ws.set_option("filter", 1)
+    ws.set_option("sweep_tail", 1 << 26)                         # a tenth of the occurrences finish as stragglers, on shared trails
+    d = idx.search(q, workspace=ws)
+    for k in ("n_matches", "checksum", "n_tuple_values", "located_occurrences"):
+        assert sa[k] == d.summary[k], k
+    assert (counts == d.counts).all()
+    del d
+    ws.set_option("sweep_tail", 1 << 22)
     kst = ws.kernel_stats()
     assert kst["filter_compact"]["launches"] > 0
     # ---- structural properties of EVERY match of the batch (as C2 has them) ----------------------------------------------
@@ -245,7 +256,7 @@ def test_c5_one_gib_dna_rrr_full_size(oracle):
     for k in ("lf_steps", "wt_levels_locate", "located_occurrences", "wt_levels_bsearch"):
         assert pl.summary[k] == s[k], k                                      # same walks, only the rank primitive differs
     del pl
-    for opts in ({"sweep": 0}, {"trail": 0, "filter": 0}):
+    for opts in ({"sweep": 0}, {"trail": 0, "filter": 0}, {"sweep_tail": 1 << 20}):
         w2 = Workspace(100 << 30)
         for k_, v_ in opts.items():
             w2.set_option(k_, v_)

@@ -77,7 +77,7 @@ def main():
         for k_, v_ in (("dedup", 1), ("sweep", 0), ("filter", 0), ("global_sort_min", 1 << 40)):
             base.set_option(k_, v_)
         a = idx.search(qs, workspace=base, strict=False)
-        opts = {"sweep_min": int(rng.choice([1, 1 << 22])), "sweep_tail": int(rng.choice([1, 7, 1000])), "trail": int(rng.integers(0, 2)),
+        opts = {"sweep_min": int(rng.choice([1, 1 << 22])), "sweep_tail": int(rng.choice([1, 7, 1000, 1 << 40])), "trail": int(rng.integers(0, 2)),
                 "global_sort_min": int(rng.choice([1, 1 << 40])), "list_sort": int(rng.integers(0, 2)), "filter_min": int(rng.choice([0, 1 << 12])), "filter_stream_min": int(rng.choice([0, 1 << 16])),
                 "filter_pivot": int(rng.integers(0, 2)), "filter_pivot_ratio": int(rng.choice([1, 4, 12, 64])),
                 "filter_group_bytes": int(rng.choice([0, 1 << 14, 1 << 18])), "dedup": int(rng.choice([1, 1, 0]))}

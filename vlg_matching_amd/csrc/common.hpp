@@ -27,7 +27,7 @@ namespace vlg {
 
 constexpr uint32_t kBlockBits = 224;
 constexpr uint32_t kLeafFlag = 0x80000000u;
-constexpr uint64_t kBlobMagic = 0x31424C4756ULL;  // "VGLB1"
+constexpr uint64_t kBlobMagic = 0x32424C4756ULL;  // "VGLB2" (2: rrr offsets numbered by halves, rrr_code.hpp)
 constexpr uint32_t kMaxNodes = 512;
 
 struct __attribute__((aligned(16))) DNode {
@@ -55,7 +55,7 @@ struct BlobHeader {
     uint32_t sample_bytes;
     uint32_t pad0;
     uint64_t off_blocks, off_nodes, off_C, off_paths, off_c2c, off_samples, off_refnodes;
-    uint64_t bv_kind;             // 0 = plain 256-bit super-blocks, 1 = rrr-63 (K6 layout)
+    uint64_t bv_kind;             // 0 = plain 256-bit super-blocks, 1 = rrr-63 (headers + offset stream as K6, block code of rrr_code.hpp)
     uint64_t off_rrr_hdr, off_rrr_stream, off_binom, n_rrr_sb, rrr_stream_words;
     uint64_t reserved[1];
 };
@@ -79,7 +79,7 @@ struct IndexView {
     uint32_t pad;
     const uint4* rrr_hdr;
     const uint64_t* rrr_stream;
-    const uint64_t* binom;        // [64][64]
+    const struct RrrTables* rrr_tables;   // rrr_code.hpp
 };
 
 constexpr uint32_t kBvPlain = 0, kBvRrr63 = 1;

@@ -3,6 +3,7 @@
 // "- bv_pos_rank(v)" of wt_pc::rank / inverse_select (include/sdsl/wt_pc.hpp:362-368, 389-397).
 #pragma once
 #include "common.hpp"
+#include "rrr_code.hpp"
 
 namespace vlg {
 
@@ -77,31 +78,18 @@ struct PlainBV {
     }
 };
 
-// rrr-63 (K6): 32-byte header {ones before, offset word position, 32 x 6-bit classes} per 32 blocks of 63 bits, offsets in
-// a bit stream (each super-block's offsets start on a word), decoded against the binomial table staged in LDS
-// (rank_support_rrr::rank, include/sdsl/rrr_vector.hpp:444-480; decode include/sdsl/rrr_helper.hpp:411-460).
+// rrr-63: 32-byte header {ones before, offset word position, 32 x 6-bit classes} per 32 blocks of 63 bits, offsets in a bit stream
+// (each super-block's offsets start on a word) -- the sizes of rrr_vector<63> (include/sdsl/rrr_vector.hpp:145-237; rank:
+// :444-480), the offsets numbered by halves so that a rank inside a block is a fixed, short computation (rrr_code.hpp).
 struct RrrBV {
     struct Shared {
-        uint64_t binom[64][64];
-        uint8_t space[64];
+        RrrTables t;
     };
     static __device__ __forceinline__ void stage(Shared& s, const IndexView& iv)
     {
-        for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) (&s.binom[0][0])[i] = iv.binom[i];
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            uint64_t c = s.binom[63][threadIdx.x];
-            s.space[threadIdx.x] = (c == 1) ? 0 : (uint8_t)(64 - __clzll((long long)c));
-        }
-    }
-    static __device__ __forceinline__ uint32_t cls(uint64_t c0, uint64_t c1, uint64_t c2, uint32_t j)
-    {
-        uint32_t b = 6u * j, w = b >> 6, o = b & 63;
-        uint64_t lo = w == 0 ? c0 : (w == 1 ? c1 : c2);
-        uint64_t hi = w == 0 ? c1 : c2;
-        uint64_t v = lo >> o;
-        if (o > 58) v |= hi << (64 - o);
-        return (uint32_t)v & 63u;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(iv.rrr_tables);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&s.t);
+        for (uint32_t i = threadIdx.x; i < sizeof(RrrTables) / 4; i += blockDim.x) dst[i] = src[i];
     }
     // ones in the first `want` bits of the addressed block, plus bit number `want` when asked for
     template <bool kBit>
@@ -111,36 +99,33 @@ struct RrrBV {
         const uint32_t r = (uint32_t)(i - sb * kRrrSuperBits);
         const uint32_t blk = r / kRrrBlockBits, off = r - blk * kRrrBlockBits;
         const uint4 h0 = iv.rrr_hdr[2 * ((uint64_t)base + sb)], h1 = iv.rrr_hdr[2 * ((uint64_t)base + sb) + 1];
-        uint64_t rank = h0.x;
+        uint32_t rank = h0.x;
         uint64_t ptr = (uint64_t)h0.y << 6;
-        const uint64_t c0 = (uint64_t)h0.z | ((uint64_t)h0.w << 32), c1 = (uint64_t)h1.x | ((uint64_t)h1.y << 32),
-                       c2 = (uint64_t)h1.z | ((uint64_t)h1.w << 32);
+        uint64_t c0 = (uint64_t)h0.z | ((uint64_t)h0.w << 32), c1 = (uint64_t)h1.x | ((uint64_t)h1.y << 32),
+                 c2 = (uint64_t)h1.z | ((uint64_t)h1.w << 32);
+        // classes in front of the block (rrr_vector.hpp:463-467): the 192 bits of classes are shifted past one class per step
+        uint32_t bits = 0;
         for (uint32_t j = 0; j < blk; ++j) {
-            uint32_t k = cls(c0, c1, c2, j);
+            const uint32_t k = (uint32_t)c0 & 63u;
             rank += k;
-            ptr += s.space[k];
+            bits += s.t.space[k];
+            c0 = (c0 >> 6) | (c1 << 58);
+            c1 = (c1 >> 6) | (c2 << 58);
+            c2 >>= 6;
         }
+        ptr += bits;
         bit = 0;
         if (kBit || off) {
-            uint32_t k = cls(c0, c1, c2, blk);
-            const uint32_t len = s.space[k];
-            uint64_t nr = 0;
+            const uint32_t k = (uint32_t)c0 & 63u;
+            const uint32_t len = s.t.space[k];
+            uint64_t o = 0;
             if (len) {
-                const uint64_t w = ptr >> 6, o = ptr & 63;
-                nr = iv.rrr_stream[w] >> o;
-                if (o + len > 64) nr |= iv.rrr_stream[w + 1] << (64 - o);
-                nr &= (len == 64) ? ~0ull : ((1ull << len) - 1);
+                const uint64_t w = ptr >> 6, sh = ptr & 63;
+                o = iv.rrr_stream[w] >> sh;
+                if (sh + len > 64) o |= iv.rrr_stream[w + 1] << (64 - sh);
+                o &= (len == 64) ? ~0ull : ((1ull << len) - 1);
             }
-            uint32_t ones = 0, nn = kRrrBlockBits;
-            if (k == kRrrBlockBits) { ones = off; bit = 1; }
-            else if (k) {
-                for (uint32_t b = 0; b < off && k; ++b, --nn) {
-                    const uint64_t c = s.binom[nn - 1][k];
-                    if (nr >= c) { nr -= c; --k; ++ones; }
-                }
-                if (kBit && k) bit = nr >= s.binom[kRrrBlockBits - off - 1][k];     // nn == 63 - off here unless k ran out
-            }
-            rank += ones;
+            rank += rrr_dec63(s.t, k, o, off, bit);
         }
         r1 = rank;
     }

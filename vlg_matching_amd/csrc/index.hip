@@ -5,6 +5,7 @@
 #include <cstring>
 #include <string.h>
 #include "common.hpp"
+#include "rrr_code.hpp"
 #include <rocprim/rocprim.hpp>
 
 using namespace vlg;
@@ -152,7 +153,7 @@ void bind_view(vlg_index* idx)
     idx->view.pad = 0;
     idx->view.rrr_hdr = reinterpret_cast<const uint4*>(b + h.off_rrr_hdr);
     idx->view.rrr_stream = reinterpret_cast<const uint64_t*>(b + h.off_rrr_stream);
-    idx->view.binom = reinterpret_cast<const uint64_t*>(b + h.off_binom);
+    idx->view.rrr_tables = reinterpret_cast<const RrrTables*>(b + h.off_binom);
 }
 
 // Plan the blob from the host tree, allocate it, upload the small tables. Blocks + samples stay to be filled.
@@ -520,24 +521,19 @@ __device__ __forceinline__ uint32_t rrr_find(const RrrTable& t, uint32_t sb)
     return lo;
 }
 
-__device__ __forceinline__ uint32_t rrr_space(const uint64_t* binom_lds, uint32_t k)
-{
-    uint64_t c = binom_lds[63 * 64 + k];
-    return c == 1 ? 0u : (uint32_t)(64 - __clzll((long long)c));
-}
-
 // pass 1: ones and offset words of every super-block;  pass 2 (hdr != nullptr): headers + offsets
 __global__ void __launch_bounds__(256) rrr_encode_kernel(const Block* __restrict__ blocks, const RrrTable* __restrict__ tab, uint64_t n_sb,
-                                                         const uint64_t* __restrict__ binom, uint64_t* __restrict__ ones_out,
+                                                         const RrrTables* __restrict__ code, uint64_t* __restrict__ ones_out,
                                                          uint64_t* __restrict__ words_out, const uint64_t* __restrict__ ones_scan,
                                                          const uint64_t* __restrict__ words_scan, uint4* __restrict__ hdr,
                                                          uint64_t* __restrict__ stream)
 {
     __shared__ RrrTable t;
-    __shared__ uint64_t bn[64 * 64];
+    __shared__ RrrTables ct;
     for (uint32_t i = threadIdx.x; i < sizeof(RrrTable) / 4; i += blockDim.x)
         reinterpret_cast<uint32_t*>(&t)[i] = reinterpret_cast<const uint32_t*>(tab)[i];
-    for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) bn[i] = binom[i];
+    for (uint32_t i = threadIdx.x; i < sizeof(RrrTables) / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&ct)[i] = reinterpret_cast<const uint32_t*>(code)[i];
     __syncthreads();
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_sb; g += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t k_node = rrr_find(t, (uint32_t)g);
@@ -548,16 +544,15 @@ __global__ void __launch_bounds__(256) rrr_encode_kernel(const Block* __restrict
         for (uint32_t j = 0; j < kRrrBlocksPerSuper; ++j) {
             const uint64_t bin = plain_bits63(blocks, t.pbase[k_node], sb * kRrrSuperBits + (uint64_t)j * kRrrBlockBits, t.size[k_node]);
             const uint32_t k = (uint32_t)__popcll(bin);
-            const uint32_t len = rrr_space(bn, k);
+            const uint32_t len = ct.space[k];
             ones += k;
             if (hdr) {
                 const uint32_t b = 6 * j, w = b >> 6, o = b & 63;
                 cls[w] |= (uint64_t)k << o;
                 if (o > 58) cls[w + 1] |= (uint64_t)k >> (64 - o);
-                if (len) {                                       // bin_to_nr (rrr_helper.hpp:304-320)
-                    uint64_t nr = 0, bb = bin;
-                    uint32_t kk = k, nn = kRrrBlockBits;
-                    while (bb) { if (bb & 1) { nr += bn[(nn - 1) * 64 + kk]; --kk; } bb >>= 1; --nn; }
+                if (len) {
+                    uint32_t kk;
+                    const uint64_t nr = rrr_enc63(ct, bin, kk);  // the block's number inside its class (rrr_code.hpp)
                     const uint64_t p = wpos + bits, w2 = p >> 6, o2 = p & 63;
                     stream[w2] |= nr << o2;                      // the region of a super-block is word-aligned and private
                     if (o2 + len > 64) stream[w2 + 1] |= nr >> (64 - o2);
@@ -602,21 +597,19 @@ extern "C" vlg_status vlg_index_compress(const vlg_index* src, int kind, vlg_ind
     if (n_sb > 0xFFFFFFF0ull) { delete idx; return fail(VLG_E_UNSUPPORTED, "too many rrr super-blocks"); }
     hipStream_t stream = nullptr;
     auto run = [&]() -> vlg_status {
-        std::vector<uint64_t> binom(64 * 64, 0);
-        for (int nn = 0; nn < 64; ++nn) binom[nn * 64] = 1;
-        for (int nn = 1; nn < 64; ++nn)
-            for (int k = 1; k < 64; ++k) binom[nn * 64 + k] = (k == nn) ? 1 : (k > nn ? 0 : binom[(nn - 1) * 64 + k - 1] + binom[(nn - 1) * 64 + k]);
+        std::vector<uint8_t> code(64 * 64 * 8, 0);                // the block code's tables (the blob keeps 32 KiB for them)
+        build_rrr_tables(*reinterpret_cast<RrrTables*>(code.data()));
         uint64_t total_words = 0;
-        DevBuf d_tab, d_binom, d_ones, d_words, d_tmp;
+        DevBuf d_tab, d_code, d_ones, d_words, d_tmp;
         VLG_HIP_TRY(d_tab.alloc(sizeof tab));
-        VLG_HIP_TRY(d_binom.alloc(64 * 64 * 8));
+        VLG_HIP_TRY(d_code.alloc(64 * 64 * 8));
         VLG_HIP_TRY(hipMemcpy(d_tab.p, &tab, sizeof tab, hipMemcpyHostToDevice));
-        VLG_HIP_TRY(hipMemcpy(d_binom.p, binom.data(), 64 * 64 * 8, hipMemcpyHostToDevice));
+        VLG_HIP_TRY(hipMemcpy(d_code.p, code.data(), 64 * 64 * 8, hipMemcpyHostToDevice));
         if (n_sb) {
             VLG_HIP_TRY(d_ones.alloc((n_sb + 1) * 8));
             VLG_HIP_TRY(d_words.alloc((n_sb + 1) * 8));
             const uint32_t grid = (uint32_t)std::min<uint64_t>((n_sb + 255) / 256, 4096);
-            hipLaunchKernelGGL(rrr_encode_kernel, dim3(grid), dim3(256), 0, stream, src->view.blocks, d_tab.as<RrrTable>(), n_sb, d_binom.as<uint64_t>(),
+            hipLaunchKernelGGL(rrr_encode_kernel, dim3(grid), dim3(256), 0, stream, src->view.blocks, d_tab.as<RrrTable>(), n_sb, d_code.as<RrrTables>(),
                                d_ones.as<uint64_t>(), d_words.as<uint64_t>(), nullptr, nullptr, nullptr, nullptr);
             VLG_HIP_TRY(hipGetLastError());
             uint64_t last_words = 0;
@@ -637,12 +630,12 @@ extern "C" vlg_status vlg_index_compress(const vlg_index* src, int kind, vlg_ind
         uint8_t* b = reinterpret_cast<uint8_t*>(idx->d_blob);
         const uint8_t* sb = reinterpret_cast<const uint8_t*>(src->d_blob);
         VLG_HIP_TRY(hipMemcpyAsync(b + h.off_samples, sb + src->hdr.off_samples, h.n_samples * h.sample_bytes, hipMemcpyDeviceToDevice, stream));
-        VLG_HIP_TRY(hipMemcpyAsync(b + h.off_binom, d_binom.p, 64 * 64 * 8, hipMemcpyDeviceToDevice, stream));
+        VLG_HIP_TRY(hipMemcpyAsync(b + h.off_binom, d_code.p, 64 * 64 * 8, hipMemcpyDeviceToDevice, stream));
         VLG_HIP_TRY(hipMemsetAsync(b + h.off_rrr_stream, 0, (total_words + 2) * 8, stream));
         VLG_HIP_TRY(hipMemsetAsync(b + h.off_rrr_hdr, 0, std::max<uint64_t>(n_sb, 1) * 32, stream));
         if (n_sb) {
             const uint32_t grid = (uint32_t)std::min<uint64_t>((n_sb + 255) / 256, 4096);
-            hipLaunchKernelGGL(rrr_encode_kernel, dim3(grid), dim3(256), 0, stream, src->view.blocks, d_tab.as<RrrTable>(), n_sb, d_binom.as<uint64_t>(),
+            hipLaunchKernelGGL(rrr_encode_kernel, dim3(grid), dim3(256), 0, stream, src->view.blocks, d_tab.as<RrrTable>(), n_sb, d_code.as<RrrTables>(),
                                nullptr, nullptr, d_ones.as<uint64_t>(), d_words.as<uint64_t>(), reinterpret_cast<uint4*>(b + h.off_rrr_hdr),
                                reinterpret_cast<uint64_t*>(b + h.off_rrr_stream));
             VLG_HIP_TRY(hipGetLastError());

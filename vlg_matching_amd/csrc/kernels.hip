@@ -438,10 +438,18 @@ __device__ __forceinline__ void block_add(unsigned long long (&v)[N], unsigned l
 // all 64 lanes issue one 32-byte super-block read per iteration whatever the (geometric) number
 // of LF steps and whatever the code lengths.
 // =============================================================================================
-template <typename pos_t, class BV>
+// kTail: the same walk for the stragglers of the sorted sweep (K3s below): the elements are val[] = slot << kShift | SA index, they
+// have walked `step` steps already, positions go to out[slot] -- or to rec[slot0 + slot] when trails are shared, and then a walk
+// also ends on the first index another element stood on during the sweep (sweep_step_kernel explains the records).
+template <typename pos_t, class BV, bool kTail = false>
 __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __restrict__ io, uint64_t total, uint32_t per_wave,
-                                                     unsigned long long* __restrict__ stats /* [2]: lf steps, levels */)
+                                                     unsigned long long* __restrict__ stats /* [2]: lf steps, levels */,
+                                                     const uint64_t* __restrict__ val = nullptr, uint32_t step = 0,
+                                                     uint64_t* __restrict__ rec = nullptr, uint64_t slot0 = 0,
+                                                     const uint64_t* __restrict__ trail = nullptr, uint64_t gen = 0)
 {
+    constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
+    constexpr uint64_t kPosMask = (1ull << kShift) - 1;
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
     const uint32_t lane = threadIdx.x & 63;
@@ -466,7 +474,12 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
             uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
             if (need) {
                 uint64_t cand = next + before;
-                if (cand < slice_end) { t = cand; i = io[cand]; v = 0; off = 0; active = true; }
+                if (cand < slice_end) {
+                    if (kTail) { const uint64_t e = val[cand]; t = e >> kShift; i = e & kPosMask; off = step; }
+                    else { t = cand; i = io[cand]; off = 0; }
+                    v = 0;
+                    active = true;
+                }
                 else active = false;
                 need = false;
             }
@@ -479,7 +492,21 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
                 uint64_t q = pow2 ? (i >> dshift) : (i / dens);
                 uint64_t r = (uint64_t)samples[q] + off;
                 if (r >= iv.n) r -= iv.n;                  // csa_wt.hpp:343-347
-                io[t] = (pos_t)r;
+                if (kTail && rec) rec[slot0 + t] = r;
+                else io[t] = (pos_t)r;
+                need = true;
+                active = false;
+            } else if (kTail && trail && v == 0 && (trail[i] >> 48 << 48) == gen && (uint32_t)(trail[i] & 0xFFFFu) < off) {
+                // someone stood here earlier in this sweep: take its trail (a straggler writes no marks itself any more: whoever it
+                // could meet from now on is a straggler too and walks at the same pace)
+                const uint64_t mk = trail[i];
+                const uint64_t owner = ((mk >> 16) & 0xFFFFFFFFull) - 1, delta = off - (mk & 0xFFFFu);
+                const uint64_t ro = rec[owner];
+                uint64_t r;
+                if (ro == ~0ull) r = (delta << kShift) | owner;               // still walking: follow it
+                else if ((ro >> kShift) == 0) r = ro + delta;                  // its position is known
+                else r = ro + (delta << kShift);                               // it follows someone itself: follow that one
+                rec[slot0 + t] = r;
                 need = true;
                 active = false;
             } else if (iv.sigma == 1) {                    // degenerate: only the sentinel exists
@@ -650,67 +677,10 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
     block_add<3>(v, dst);
 }
 
-// stragglers: finish the few elements still alive after the sweep, one lane each.  With shared trails a straggler still stops on
-// the first index another element stood on during the sweep (it writes no marks itself any more: whoever it could meet from now
-// on is a straggler too and walks at the same pace).
-template <class BV, typename pos_t>
-__global__ void __launch_bounds__(256) sweep_tail_kernel(IndexView iv, const uint64_t* __restrict__ val, uint64_t count, uint32_t step,
-                                                         pos_t* __restrict__ out, unsigned long long* __restrict__ stats,
-                                                         uint64_t* __restrict__ rec, uint64_t slot0, const uint64_t* __restrict__ trail,
-                                                         uint64_t gen)
-{
-    __shared__ WalkLds<BV> s;
-    stage_walk(s, iv);
-    const uint32_t dens = iv.dens;
-    const pos_t* samples = reinterpret_cast<const pos_t*>(iv.samples);
-    constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
-    constexpr uint64_t kPosMask = (1ull << kShift) - 1;
-    uint32_t n_lv = 0, n_lf = 0;
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t v64 = val[e];
-        uint64_t i = v64 & kPosMask;
-        uint64_t off = step;
-        bool followed = false;
-        while (i % dens) {
-            if (trail) {
-                const uint64_t m = trail[i];
-                if ((m >> 48 << 48) == gen && (m & 0xFFFFu) < off) {             // someone stood here earlier in this sweep: take its trail
-                    const uint64_t owner = ((m >> 16) & 0xFFFFFFFFull) - 1, delta = off - (m & 0xFFFFu);
-                    const uint64_t ro = rec[owner];
-                    uint64_t r;
-                    if (ro == ~0ull) r = (delta << kShift) | owner;               // still walking: follow it
-                    else if ((ro >> kShift) == 0) r = ro + delta;                  // its position is known
-                    else r = ro + (delta << kShift);                               // it follows someone itself: follow that one
-                    rec[slot0 + (v64 >> kShift)] = r;
-                    followed = true;
-                    break;
-                }
-            }
-            uint32_t v = 0;
-            uint64_t pos = i;
-            for (;;) {
-                const DNode nd = s.nodes[v];
-                uint32_t bit;
-                uint64_t r1;
-                BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
-                ++n_lv;
-                pos = bit ? r1 : pos - r1;
-                uint32_t ch = nd.child[bit];
-                if (ch & kLeafFlag) { i = s.C[ch & ~kLeafFlag] + pos; break; }
-                v = ch;
-            }
-            ++off; ++n_lf;
-        }
-        if (followed) continue;
-        uint64_t r = (uint64_t)samples[i / dens] + off;
-        if (r >= iv.n) r -= iv.n;
-        if (rec) rec[slot0 + (v64 >> kShift)] = r;
-        else out[v64 >> kShift] = (pos_t)r;
-    }
-    unsigned long long v[2] = {n_lf, n_lv};
-    unsigned long long* const dst[2] = {&stats[0], &stats[1]};
-    block_add<2>(v, dst);
-}
+// stragglers: the elements still alive after the sweep are finished without sorting them any more, by locate_kernel<.., kTail>:
+// how long an element still walks is geometrically distributed (one SA index in `dens` is sampled), so a lane that kept one
+// element to its end would idle most of the time behind the longest walk of its wave; there a lane that has finished takes the
+// next element of its wave's slice.
 
 // Records of a trail-sharing sweep -> positions: every element follows its chain of records (element it follows, steps apart) to
 // the end, at most kResolveHops hops per round, and replaces its record by what it found -- a position, or a shorter pointer for
@@ -924,13 +894,20 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             if (step > 1u << 20) return fail(VLG_E_INTERNAL, "locate sweep did not converge");
         }
         if (alive) {
+            // slices as launch_locate cuts them: enough waves to fill the chip several times over, long enough that a slice's slowest
+            // element is a small part of it
+            const uint64_t target_waves = 256ull * 32 * 4;
+            uint64_t per_wave = (alive + target_waves - 1) / target_waves;
+            per_wave = std::min<uint64_t>(std::max<uint64_t>(per_wave, 64 * 16), 1u << 20);
+            const uint64_t waves = (alive + per_wave - 1) / per_wave;
+            const dim3 grid((uint32_t)((waves + 3) / 4));
             if (timer) timer->begin(0);
             if (iv.bv_kind == kBvRrr63)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<RrrBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a, alive,
-                                   step, out, d_stats, trail ? rec : nullptr, t0, trail, gen);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, RrrBV, true>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave,
+                                   d_stats, val_a, step, trail ? rec : nullptr, t0, trail, gen);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_tail_kernel<PlainBV, pos_t>), dim3(grid_for(alive, 4096)), dim3(256), 0, stream, iv, val_a,
-                                   alive, step, out, d_stats, trail ? rec : nullptr, t0, trail, gen);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, PlainBV, true>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave,
+                                   d_stats, val_a, step, trail ? rec : nullptr, t0, trail, gen);
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
         }
