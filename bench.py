@@ -72,13 +72,15 @@ def load_pmc():
 CLASSES = {
     "backward_search": ("backward_search_kernel", ["backward_search_kernel"], "32 B per wavelet-tree level of every rank (SURVEY 8d K2)"),
     "expand": ("expand_kernel", [], ""),
-    "locate": ("sweep_step_kernel", ["sweep_step_kernel", "sweep_tail_kernel"], "32 B per tree level actually walked + one SA sample per occurrence (SURVEY 8d K3)"),
+    "locate": ("sweep_step_kernel", ["sweep_step_kernel", "locate_kernel"],      # (locate_kernel<.., kTail> finishes the stragglers)
+               "32 B per tree level actually walked + one SA sample per occurrence (SURVEY 8d K3)"),
     "locate_partition": ("rocprim radix_sort_pairs (u16 symbol key, u64 element): one 5-bit pass per round",
                          ["rocprim:radix_sort_onesweep<unsigned_short,unsigned_long>"],
                          "per element of the round: key + value read once, written once (2 x 10 B)"),
     "locate_resolve": ("trail_resolve_kernel", ["trail_resolve_kernel", "trail_resolve_round_kernel"], "8 B record read + 4..8 B position written per occurrence"),
-    "sort": ("rocprim radix_sort_keys on (list, position) keys + compose / narrow",
-             ["sort_compose_kernel", "sort_narrow_kernel", "rocprim:radix_sort_onesweep<unsigned_long,empty_type>"],
+    "sort": ("list_sort_* (LSD radix sort of the 32-bit positions inside every list; short lists in LDS)",
+             ["list_sort_small_kernel", "list_sort_hist_kernel", "list_sort_chunk_kernel", "list_sort_scan_kernel", "list_sort_prefix_kernel",
+              "list_sort_scatter_kernel"],
              "one read + one write of every position (2 x 4 B); the radix passes in between are overhead"),
     "filter_pivot": ("filter_pivot_kernel", ["filter_pivot_kernel"], "16 B per (pivot element, level): two lower bounds"),
     "filter_pass": ("filter_pass_kernel", ["filter_pass_kernel"], "4 B per list element streamed"),

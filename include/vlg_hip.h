@@ -117,8 +117,11 @@ typedef struct {
 } vlg_index_parts_out;
 vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_parts* sizes, vlg_index_parts_out* out);
 /* A second index over the same text whose wavelet-tree bit-vectors are H0-compressed -- csa_wt<wt_huff<rrr_vector<63>>>
- * (BASELINE config 5; include/sdsl/rrr_vector.hpp).  Every search entry point accepts it and returns identical results;
- * ranks decode 63-bit blocks on the fly against a binomial table staged in LDS.  `src` must be a plain index. */
+ * (BASELINE config 5; include/sdsl/rrr_vector.hpp).  Every search entry point accepts it and returns identical results.
+ * Blocks of 63 bits are stored as a 6-bit class and an offset of ceil(log2 C(63,k)) bits -- the sizes of rrr_vector<63>; the
+ * offset numbers the blocks of a class by halves (csrc/rrr_code.hpp) instead of bit by bit, so that a rank decodes in a fixed
+ * short sequence of table lookups.  The image is this library's own (blob magic "VGLB2"); an index that comes from an sdsl file
+ * with rrr bit-vectors is loaded as bits and compressed here.  `src` must be a plain index. */
 #define VLG_BV_PLAIN 0
 #define VLG_BV_RRR63 1
 vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out);
