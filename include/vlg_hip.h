@@ -120,8 +120,8 @@ vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_parts* sizes, 
  * (BASELINE config 5; include/sdsl/rrr_vector.hpp).  Every search entry point accepts it and returns identical results.
  * Blocks of 63 bits are stored as a 6-bit class and an offset of ceil(log2 C(63,k)) bits -- the sizes of rrr_vector<63>; the
  * offset numbers the blocks of a class by halves (csrc/rrr_code.hpp) instead of bit by bit, so that a rank decodes in a fixed
- * short sequence of table lookups.  The image is this library's own (blob magic "VGLB2"); an index that comes from an sdsl file
- * with rrr bit-vectors is loaded as bits and compressed here.  `src` must be a plain index. */
+ * short sequence of table lookups.  The image is this library's own (blob magic "VGLB2"; vlg_index_load_sdsl reads the plain
+ * csa_wt<wt_huff<>> format only): an rrr index is always made here, from a plain one.  `src` must be a plain index. */
 #define VLG_BV_PLAIN 0
 #define VLG_BV_RRR63 1
 vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out);
