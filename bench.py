@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+RANDOM_REQUEST_WALL = 5.0e10   # random 64-byte read requests per second, measured with tools/k1_bench.py (profiles/r01_k1_bitrank_kernel.json)
 
 
 def log(*a):
@@ -471,6 +472,10 @@ def main():
                         "source": "profiles/pmc_traffic.json (%s)" % got[0].get("tag", ""),
                         "note": "FETCH_SIZE is exact for 64-byte random requests and reads half of a wide coalesced streaming read on "
                                 "gfx950 (MI355X_MICROARCH.md, HBM): both readings are given"},
+                    # the other wall of this workload: random 64-byte read requests (K1, profiles/r01_k1_bitrank_kernel.json: 5.0e10 per
+                    # second chip-wide whatever the working set; FETCH_SIZE counts exactly 64 B per such request)
+                    "read_requests_64B_per_s": None if rd is None or class_ms <= 0 else rd / 64.0 / (class_ms * 1e-3),
+                    "frac_of_random_request_wall": None if rd is None or class_ms <= 0 else rd / 64.0 / (class_ms * 1e-3) / RANDOM_REQUEST_WALL,
                     "hbm_frac_counter": None if tr is None or class_ms <= 0 else tr / (class_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "hbm_frac_counter_if_streaming": None if tr is None or class_ms <= 0 else (2 * rd + wr) / (class_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic_over_algorithmic": None if tr is None or not st["algorithmic_bytes"] else tr / (st["algorithmic_bytes"] / args.steps),
