@@ -434,16 +434,29 @@ __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restri
 }
 
 // survivors per run (for the compaction offsets): the activity bits of a filtered list start on a run boundary, so run r of
-// the group owns the words [32 r, 32 r + 32).  Half a wave per run.
+// the group owns the words [32 r, 32 r + 32).  Sixteen lanes per run (16 bytes each), sixteen runs per wave with their four
+// loads per lane in flight together.
+constexpr uint32_t kCountRunsPerWave = 16;
 __global__ void __launch_bounds__(256) filter_count_runs_kernel(const uint64_t* __restrict__ abits, uint64_t total_runs,
                                                                 uint32_t* __restrict__ runcnt)
 {
     static_assert(kRun == 2048, "one run = 32 activity words");
-    const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    uint32_t c = 0;
-    if (r < total_runs) c = (uint32_t)__popcll(abits[r * 32 + (threadIdx.x & 31)]);
-    for (int o = 16; o > 0; o >>= 1) c += __shfl_xor(c, o);                  // both halves of the wave reduce on their own
-    if (r < total_runs && (threadIdx.x & 31) == 0) runcnt[r] = c;
+    const uint32_t lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const uint64_t r0 = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kCountRunsPerWave;
+    const ulonglong2* words = reinterpret_cast<const ulonglong2*>(abits);
+    ulonglong2 w[4];
+#pragma unroll
+    for (uint32_t it = 0; it < 4; ++it) {
+        const uint64_t r = r0 + it * 4 + grp;
+        w[it] = r < total_runs ? words[r * 16 + sub] : make_ulonglong2(0, 0);
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < 4; ++it) {
+        const uint64_t r = r0 + it * 4 + grp;
+        uint32_t c = (uint32_t)(__popcll(w[it].x) + __popcll(w[it].y));
+        for (int o = 8; o > 0; o >>= 1) c += __shfl_xor(c, o);                // the four groups of the wave reduce on their own
+        if (r < total_runs && sub == 0) runcnt[r] = c;
+    }
 }
 
 // survivors per list (for the host's plan): a wave per list
@@ -738,7 +751,7 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
     // ---- survivors ------------------------------------------------------------------------------------
     {
         Timed t(ws, KS_FILTER_COMPACT, abit / 8);
-        hipLaunchKernelGGL(filter_count_runs_kernel, dim3((uint32_t)((total_runs + 7) / 8)), dim3(256), 0, st, fg.d_abits, total_runs, fg.d_runcnt);
+        hipLaunchKernelGGL(filter_count_runs_kernel, dim3((uint32_t)((total_runs + 4 * kCountRunsPerWave - 1) / (4 * kCountRunsPerWave))), dim3(256), 0, st, fg.d_abits, total_runs, fg.d_runcnt);
         hipLaunchKernelGGL(filter_count_lists_kernel, dim3((uint32_t)((cseg.size() + 3) / 4)), dim3(256), 0, st, fg.d_crun0, fg.ncseg, fg.d_runcnt,
                            d_segcnt);
     }
