@@ -510,6 +510,23 @@ def test_window_filter_equals_unfiltered_join_and_oracle(V, oracle, name, seed, 
             assert (x == y).all()
 
 
+def test_window_filter_with_nothing_to_mark(V, oracle):
+    """Two lists, the first one short: it would be the pivot (kept whole) and the last list is never filtered, so the filter has
+    nothing to mark for such a query -- alone in a batch (once: zero-sized launches) and next to a query that is filtered."""
+    from vlg_matching_amd.index import Workspace
+    rng = np.random.default_rng(77)
+    text = bytes(rng.choice(np.frombuffer(b"aaaaaaab", np.uint8), 60000)) + b"qaab" + bytes(rng.choice(np.frombuffer(b"ab", np.uint8), 500)) + b"q"
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    for qs in (["q.{0,300}?a"], ["q.{0,300}?a", "q.{0,9}?b", "b.{0,40}?a.{0,40}?q", "q"]):
+        ws = Workspace()
+        for k_, v_ in (("filter_min", 0), ("filter_stream_min", 0), ("filter_pivot", 1), ("filter_pivot_ratio", 1)):
+            ws.set_option(k_, v_)
+        r = idx.search(qs, workspace=ws)
+        for i, qy in enumerate(qs):
+            assert r.tuples(i).tolist() == o.search(qy).tolist(), qy
+
+
 @pytest.mark.parametrize("pivot", [1, 0])
 def test_window_filter_extreme_gaps(V, oracle, pivot):
     """Windows wider than the text, windows that start beyond it, exact-distance windows, many sub-patterns."""

@@ -627,6 +627,9 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
         const uint32_t k = (uint32_t)(q->qsub[qi + 1] - s0);
         uint32_t pivot = 0;
         const bool by_pivot = filter_mode(q, pl, ws, qi, &pivot) == 2;
+        // a pivot list keeps every element and the last list is never filtered: with two lists and the first one as the pivot
+        // there is nothing to mark
+        if (by_pivot && k <= 2 && pivot == 0) continue;
         if (by_pivot) {
             ptasks.push_back(PTask{(uint32_t)segs.size(), k, pivot, 0});
             prun0.push_back(prun0.back() + (pl.occ[s0 + pivot] + kPivotRun - 1) / kPivotRun);
@@ -670,7 +673,7 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
         for (unsigned b = 0; b < 24; ++b) if (h[b]) fprintf(stderr, " %u:%llu", b, (unsigned long long)h[b]);
         fprintf(stderr, "\n");
     }
-    fg.any = !segs.empty();
+    fg.any = !cseg.empty();
     if (!fg.any) return VLG_OK;
     fg.ncseg = (uint32_t)cseg.size();
     fg.crun0.assign(crun0.begin(), crun0.end());
