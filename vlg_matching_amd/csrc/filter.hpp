@@ -210,16 +210,19 @@ __global__ void __launch_bounds__(256) filter_pass_kernel(const pos_t* __restric
 // of its smallest a and its largest b + 1, then every lane bisects its own a and b + 1 inside its group's bracket.
 constexpr uint32_t kPivotGroups = 4;
 template <typename pos_t>
-__device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, uint32_t pbegin, uint32_t pend, const uint64_t (&a)[kPivotGroups],
+__device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, const pos_t* __restrict__ F, uint32_t pbegin, uint32_t pend, const uint64_t (&a)[kPivotGroups],
                                              const uint64_t (&b)[kPivotGroups], bool (&on)[kPivotGroups], uint32_t (&i0)[kPivotGroups],
                                              uint32_t (&i1)[kPivotGroups])
 {
     constexpr uint32_t G = kPivotGroups;
     const uint32_t lane = threadIdx.x & 63;
     // ---- brackets: searches 0..G-1 for min a, G..2G-1 for max b + 1, over the whole list ------------------------
+    // With fences (join_device.hpp) the 64-ary rounds run over F -- fences [pbegin >> 6, pend >> 6) are elements of this list --
+    // and end in one block of the list; without them the rounds probe the list itself.
     uint64_t key[2 * G];
     uint32_t A[2 * G], B[2 * G];
     bool any[G];
+    const pos_t* __restrict__ S = F ? F : P;                 // what the rounds probe
 #pragma unroll
     for (uint32_t g = 0; g < G; ++g) {
         const unsigned long long m = __ballot(on[g]);
@@ -228,8 +231,8 @@ __device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, uint32
         key[g] = uniform(__shfl(a[g], first));
         const uint64_t bmax = uniform(__shfl(b[g], last));
         key[G + g] = bmax == ~0ull ? ~0ull : bmax + 1;
-        A[g] = A[G + g] = pbegin;
-        B[g] = B[G + g] = any[g] ? pend : pbegin;           // nothing to search for an empty group
+        A[g] = A[G + g] = F ? pbegin >> 6 : pbegin;
+        B[g] = B[G + g] = any[g] ? (F ? pend >> 6 : pend) : A[g];           // nothing to search for an empty group
     }
     for (;;) {
         bool more = false;
@@ -243,7 +246,7 @@ __device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, uint32
             const uint32_t step = (B[s] - A[s] + 63) / 64;
             const uint64_t idx = (uint64_t)A[s] + (uint64_t)(lane + 1) * step - 1;
             in[s] = B[s] - A[s] > 64 && idx < B[s];
-            v[s] = in[s] ? (uint64_t)P[idx] : 0;
+            v[s] = in[s] ? (uint64_t)S[idx] : 0;
         }
 #pragma unroll
         for (uint32_t s = 0; s < 2 * G; ++s) {
@@ -254,6 +257,21 @@ __device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, uint32
                 A[s] = (uint32_t)na;
                 B[s] = nb < B[s] ? (uint32_t)nb : B[s];
             }
+        }
+    }
+    if (F) {
+        // rank among the last <= 64 fences, then the block behind the fences that are smaller: [A, B) becomes that block of the list
+        uint64_t v[2 * G];
+        bool in[2 * G];
+#pragma unroll
+        for (uint32_t s = 0; s < 2 * G; ++s) { in[s] = A[s] + lane < B[s]; v[s] = in[s] ? (uint64_t)F[A[s] + lane] : 0; }
+#pragma unroll
+        for (uint32_t s = 0; s < 2 * G; ++s) {
+            const uint32_t blk = A[s] + (uint32_t)__popcll(__ballot(in[s] && v[s] < key[s]));
+            const uint64_t w0 = (uint64_t)blk << 6, w1 = w0 + 64;
+            A[s] = w0 > pbegin ? (uint32_t)w0 : pbegin;
+            B[s] = w1 < pend ? (uint32_t)w1 : pend;
+            if (!any[s < G ? s : s - G]) B[s] = A[s] = pbegin;
         }
     }
     uint32_t lo[G], hi[G];
@@ -352,7 +370,8 @@ struct PTask { uint32_t seg0, k, p, pad; };          // first segment of the que
 constexpr uint32_t kPivotRun = 64 * kPivotGroups;     // pivot elements per wave
 
 template <typename pos_t>
-__global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restrict__ P, const RSeg* __restrict__ segs,
+__global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restrict__ P, const pos_t* __restrict__ F /* fences of P, or null */,
+                                                           const RSeg* __restrict__ segs,
                                                            const PTask* __restrict__ tasks, const uint64_t* __restrict__ task_run0,
                                                            uint32_t ntasks, uint64_t* __restrict__ abits)
 {
@@ -382,7 +401,7 @@ __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restri
     auto follow = [&](const RSeg& sg, const uint64_t (&a)[G], const uint64_t (&b)[G], bool (&on)[G], uint64_t (&lo_pos)[G], uint64_t (&hi_pos)[G],
                       bool more_levels) {
         uint32_t i0[G], i1[G];
-        pivot_ranges(P, sg.pbegin, sg.pend, a, b, on, i0, i1);
+        pivot_ranges(P, F, sg.pbegin, sg.pend, a, b, on, i0, i1);
         MarkRun mr;
         mr.bm = abits + (sg.abit >> 6);
 #pragma unroll
@@ -704,7 +723,7 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
         uint64_t probes = 0;                                      // (pivot element, level) pairs: two lower bounds of 8 bytes each
         for (const PTask& pt : ptasks) probes += (uint64_t)(segs[pt.seg0 + pt.p].pend - segs[pt.seg0 + pt.p].pbegin) * (pt.k >= 2 ? pt.k - 2 + (pt.p + 1 == pt.k ? 1 : 0) : 0);
         Timed t(ws, KS_FILTER_PIVOT, 16 * probes);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t>), dim3((uint32_t)((prun0.back() + 3) / 4)), dim3(256), 0, st, P, fg.d_segs,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t>), dim3((uint32_t)((prun0.back() + 3) / 4)), dim3(256), 0, st, P, static_cast<const pos_t*>(ws->fences), fg.d_segs,
                            d_ptasks, d_prun0, (uint32_t)ptasks.size(), fg.d_abits);
         VLG_HIP_TRY(hipGetLastError());
     }

@@ -63,23 +63,39 @@ __device__ __forceinline__ uint32_t gallop_lower_bound(const pos_t* __restrict__
     return lower_bound_dev(P, lo, hi, key);
 }
 
+// ---- fences ------------------------------------------------------------------------------------------------------------------
+// F[g] = P[64 g + 63] for every whole block of 64 elements of the arrays the joins search (fence_build_kernel: the sorted
+// physical lists, and the survivors' private lists once they are compacted).  A search that cannot start from a previous answer
+// first ranks its key among the fences of the list -- dense entries, ONE 256-byte load for 64 blocks, where probing the list
+// itself touches 64 lines -- and then looks at one block of the list.  The fences with index in [a >> 6, b >> 6) are elements of
+// the list P[a,b) whatever its borders, so no list needs fences of its own.  F == nullptr: the lists are probed directly.
+template <typename pos_t>
+__global__ void fence_build_kernel(const pos_t* __restrict__ P, uint64_t g0, uint64_t g1, pos_t* __restrict__ F)
+{
+    for (uint64_t g = g0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += (uint64_t)gridDim.x * blockDim.x) F[g] = P[64 * g + 63];
+}
+
 // Keys the windows did not reach (the list is much denser than the keys): two-level search.  Lane t reads the LAST element of
-// window t behind the fence -- one round trip covers 64 windows -- every lane ranks its key among these 64 fences through
-// cross-lane reads and then bisects the one window that holds its answer (6 probes inside 256 bytes).  A galloping search
+// block t behind the fence `wb` -- one round trip covers 64 blocks -- every lane ranks its key among these 64 fences through
+// cross-lane reads and then bisects the one block that holds its answer (6 probes inside 256 bytes).  A galloping search
 // would pay ~2 log2(distance) dependent, scattered round trips instead.
 constexpr uint32_t kFarRounds = 4;
 template <typename pos_t>
-__device__ __forceinline__ void wave_far_lower_bound(const pos_t* __restrict__ P, uint32_t wb, uint32_t b, pos_t key, bool need, uint32_t& j, pos_t& val)
+__device__ __forceinline__ void wave_far_lower_bound(const pos_t* __restrict__ P, const pos_t* __restrict__ F, uint32_t wb, uint32_t b, pos_t key,
+                                                     bool need, uint32_t& j, pos_t& val)
 {
     const uint32_t lane = threadIdx.x & 63;
     constexpr pos_t kInf = (pos_t)~(pos_t)0;
     for (uint32_t round = 0; round < kFarRounds && wb < b; ++round) {
         if (!__any(need)) return;
-        const uint64_t fi = (uint64_t)wb + 64 * lane + 63;
-        const pos_t f = fi < b ? P[fi] : kInf;                       // windows that reach behind the list end with +inf
+        // without fences the blocks start at wb; with them they are the aligned blocks of the array, the first one cut at wb
+        const uint32_t g0 = F ? wb >> 6 : 0;
+        pos_t f;
+        if (F) f = g0 + lane < (b >> 6) ? F[g0 + lane] : kInf;       // blocks that reach behind the list end with +inf
+        else { const uint64_t fi = (uint64_t)wb + 64 * lane + 63; f = fi < b ? P[fi] : kInf; }
         const pos_t flast = __shfl(f, 63);
         const bool can = need && key <= flast;
-        uint32_t lo = 0, hi = 63;                                    // first window whose last element is >= key
+        uint32_t lo = 0, hi = 63;                                    // first block whose last element is >= key
 #pragma unroll
         for (uint32_t st = 0; st < 6; ++st) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -87,18 +103,20 @@ __device__ __forceinline__ void wave_far_lower_bound(const pos_t* __restrict__ P
             if (v < key) lo = mid + 1; else hi = mid;
         }
         if (can) {
-            const uint64_t w0 = (uint64_t)wb + 64 * lo;              // the answer is in [w0, w0+63] (or b, in a clipped window)
+            uint64_t w0 = F ? ((uint64_t)(g0 + lo) << 6) : (uint64_t)wb + 64 * lo;   // the answer is in [w0, w0+63] (or b, in a clipped block)
+            const uint64_t w1 = w0 + 64 < b ? w0 + 64 : b;
+            if (w0 < wb) w0 = wb;
             uint32_t pos = 0;
 #pragma unroll
             for (uint32_t step = 32; step; step >>= 1) {
                 const uint64_t at = w0 + pos + step - 1;
-                if (at < b && P[at] < key) pos += step;
+                if (at < w1 && P[at] < key) pos += step;
             }
             const uint64_t at = w0 + pos;
             if (at < b) { j = (uint32_t)at; val = P[at]; } else j = b;
             need = false;
         }
-        const uint64_t nwb = (uint64_t)wb + 4096;
+        const uint64_t nwb = F ? ((uint64_t)(g0 + 64) << 6) : (uint64_t)wb + 4096;
         wb = nwb < b ? (uint32_t)nwb : b;
     }
     if (need) {
@@ -117,7 +135,7 @@ constexpr uint32_t kCoopWindows = 4;
 // Keys and list elements are compared as pos_t (one cross-lane read per step for 32-bit positions); `val` receives the list
 // element at the answer, so the caller needs no load of its own for it.
 template <typename pos_t>
-__device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P, uint32_t wb, uint32_t b, pos_t key, bool need, pos_t& val)
+__device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P, const pos_t* __restrict__ F, uint32_t wb, uint32_t b, pos_t key, bool need, pos_t& val)
 {
     const uint32_t lane = threadIdx.x & 63;
     constexpr pos_t kInf = (pos_t)~(pos_t)0;
@@ -139,7 +157,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P
         if (can) { res = wb + lo; val = at; need = false; }
         wb += 64;
     }
-    if (__any(need)) wave_far_lower_bound(P, wb < b ? wb : b, b, key, need, res, val);
+    if (__any(need)) wave_far_lower_bound(P, F, wb < b ? wb : b, b, key, need, res, val);
     return res < b ? res : b;
 }
 
@@ -147,7 +165,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P
 // loop around them, which is most of what a step costs.
 constexpr uint32_t kCoopWindows2 = 6;            // measured on C3: 2 -> 35.2, 3 -> 33.8, 4 -> 33.2, 6 -> 31.9, 8..16 -> 33..34 ms
 template <typename pos_t>
-__device__ __forceinline__ void wave_lower_bound2(const pos_t* __restrict__ P, uint32_t wb, uint32_t b, pos_t key0, bool need0, pos_t key1,
+__device__ __forceinline__ void wave_lower_bound2(const pos_t* __restrict__ P, const pos_t* __restrict__ F, uint32_t wb, uint32_t b, pos_t key0, bool need0, pos_t key1,
                                                   bool need1, uint32_t& j0, pos_t& v0, uint32_t& j1, pos_t& v1)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -174,8 +192,8 @@ __device__ __forceinline__ void wave_lower_bound2(const pos_t* __restrict__ P, u
     }
     if (__any(need0 || need1)) {
         wb = wb < b ? wb : b;
-        wave_far_lower_bound(P, wb, b, key0, need0, j0, v0);
-        wave_far_lower_bound(P, wb, b, key1, need1, j1, v1);
+        wave_far_lower_bound(P, F, wb, b, key0, need0, j0, v0);
+        wave_far_lower_bound(P, F, wb, b, key1, need1, j1, v1);
     }
 }
 
@@ -235,12 +253,27 @@ __device__ __forceinline__ uint32_t wave_kary_lower_bound(const pos_t* __restric
     const uint64_t v = in ? (uint64_t)P[idx] : 0;
     return a + (uint32_t)__popcll(__ballot(in && v < key));
 }
+// The same through the fences: the key is ranked among the list's fences (the same 64-ary search, over F), then inside one block.
+template <typename pos_t>
+__device__ __forceinline__ uint32_t wave_kary_lower_bound(const pos_t* __restrict__ P, const pos_t* __restrict__ F, uint32_t a, uint32_t b, uint64_t key)
+{
+    if (!F) return wave_kary_lower_bound(P, a, b, key);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t g = wave_kary_lower_bound(F, a >> 6, b >> 6, key);            // first block of the list whose last element is >= key
+    uint64_t w0 = (uint64_t)g << 6;
+    const uint64_t w1 = w0 + 64 < b ? w0 + 64 : b;                               // (behind the last whole block: the rest of the list)
+    if (w0 < a) w0 = a;
+    const uint64_t idx = w0 + lane;
+    const bool in = idx < w1;
+    const uint64_t v = in ? (uint64_t)P[idx] : 0;
+    return (uint32_t)w0 + (uint32_t)__popcll(__ballot(in && v < key));
+}
 
 // Lower bounds in P[.,pend) of the keys flagged in `need` (bit i = key[i]).  `wb` is a wave-uniform fence: every element
 // before it is smaller than every flagged key of the wave.  j[i] = the lower bound (pend if there is none), v[i] = P[j[i]].
 // The keys of the wave need not be ordered; tiles that cannot hold an answer are skipped with one probe.
 template <typename pos_t>
-__device__ __forceinline__ void tile_lower_bounds(const pos_t* __restrict__ P, uint32_t wb, const uint32_t pend, pos_t* __restrict__ tile,
+__device__ __forceinline__ void tile_lower_bounds(const pos_t* __restrict__ P, const pos_t* __restrict__ F, uint32_t wb, const uint32_t pend, pos_t* __restrict__ tile,
                                                   const pos_t (&key)[kKeys], uint32_t need, uint32_t (&j)[kKeys], pos_t (&v)[kKeys])
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -294,7 +327,7 @@ __device__ __forceinline__ void tile_lower_bounds(const pos_t* __restrict__ P, u
         if (nwb >= pend) { wb = pend; break; }
         wb = (uint32_t)nwb;
         const uint64_t probe_at = nwb + kTB - 1 < pend ? nwb + kTB - 1 : (uint64_t)pend - 1;
-        if ((uint64_t)P[probe_at] < kmin) wb = wave_kary_lower_bound(P, (uint32_t)probe_at + 1, pend, kmin);
+        if ((uint64_t)P[probe_at] < kmin) wb = wave_kary_lower_bound(P, F, (uint32_t)probe_at + 1, pend, kmin);
     }
 }
 
@@ -436,7 +469,8 @@ __device__ __forceinline__ bool link_finish(const pos_t* __restrict__ P, const S
 // search as a wave behind the previous step's answer and have the next step's positions already in flight.
 // Slot numbers are 32-bit inside a chunk (r1 <= 0xF0000000 + alignment), so all loop arithmetic is.
 template <typename pos_t, bool kLast>
-__global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
+__global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict__ P, const pos_t* __restrict__ F /* fences of P, or null */,
+                                                        const uint32_t* __restrict__ seg_begin, uint32_t nseg,
                                                         const SegMeta* __restrict__ sm, uint32_t r0, uint32_t r1,
                                                         FeasRef fb, uint64_t* __restrict__ fbits_out,
                                                         pos_t* __restrict__ endp, uint32_t* __restrict__ link)
@@ -475,8 +509,8 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
             const bool want1 = gap_window<pos_t>((uint64_t)x1, nx.lo, nx.hi, tlo1, thi1);
             uint32_t j0 = nx.pend, j1 = nx.pend;
             if (hint_seg != s_w)                                   // first step of the run in this segment: the smallest key's bound is the fence
-                hint = wave_kary_lower_bound(P, nx.pbegin, nx.pend, (uint64_t)__shfl(tlo0, 0));
-            wave_lower_bound2(P, hint, nx.pend, tlo0, want0, tlo1, want1, j0, v0, j1, v1);
+                hint = wave_kary_lower_bound(P, F, nx.pbegin, nx.pend, (uint64_t)__shfl(tlo0, 0));
+            wave_lower_bound2(P, F, hint, nx.pend, tlo0, want0, tlo1, want1, j0, v0, j1, v1);
             if (!want0) j0 = nx.pend;
             if (!want1) j1 = nx.pend;
             const bool ok0 = link_finish<pos_t, kLast>(P, nx, fb, e0, want0, j0, v0, thi0, endp, link);
@@ -502,8 +536,8 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
             pos_t tlo, thi, v = 0;
             const bool want = gap_window<pos_t>((uint64_t)x, nx.lo, nx.hi, tlo, thi) && active;    // false: no position can be in the window
             j = nx.pend;
-            if (hint_seg != s_w) hint = wave_kary_lower_bound(P, nx.pbegin, nx.pend, (uint64_t)__shfl(tlo, 0));
-            j = wave_lower_bound(P, hint, nx.pend, tlo, want, v);
+            if (hint_seg != s_w) hint = wave_kary_lower_bound(P, F, nx.pbegin, nx.pend, (uint64_t)__shfl(tlo, 0));
+            j = wave_lower_bound(P, F, hint, nx.pend, tlo, want, v);
             if (!want) j = nx.pend;
             const bool ok = link_finish<pos_t, kLast>(P, nx, fb, e, want, j, v, thi, endp, link);
             const unsigned long long okm = __ballot(ok);
@@ -543,7 +577,7 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
 // slots of other levels get kNone so the tile pass can treat every slot alike.  Also the start of each chain.
 // Same walk as the link pass; the list searched is the element's own (the answers lie behind the element itself).
 template <typename pos_t>
-__global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
+__global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict__ P, const pos_t* __restrict__ F, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
                                                         const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint64_t r0,
                                                         uint64_t r1, FeasRef fb, const pos_t* __restrict__ endp,
                                                         uint32_t* __restrict__ jump, uint32_t* __restrict__ qstart)
@@ -589,7 +623,7 @@ __global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict_
                 const uint32_t own = phys_of(m, (uint32_t)blk0) + 1;                       // every answer lies behind its own element
                 fence = fence > own ? fence : own;
                 const uint32_t asked = need;
-                tile_lower_bounds<pos_t>(P, fence, m.pend, tile, key, need, j, v);
+                tile_lower_bounds<pos_t>(P, F, fence, m.pend, tile, key, need, j, v);
                 uint32_t jm = fence;
 #pragma unroll
                 for (uint32_t i = 0; i < kKeys; ++i) {

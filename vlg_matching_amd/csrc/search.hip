@@ -61,6 +61,7 @@ struct vlg_workspace {
     uint64_t filter_group_bytes = 0;    // cap of the filter state of one group of queries (0: a third of the join budget)
     uint64_t filter_pivot_ratio = 6;    // ... i.e. when all lists together are at least this many times longer (C3, ms per batch: 24 -> 262,
                                         // 12 -> 251, 6 -> 246.6, 4 -> 246.4, <= 3 -> 248: the probes win wherever a list is clearly the shortest)
+    void* fences = nullptr;     // F[g] = P[64 g + 63] over the lists of the super-chunk in work (join_device.hpp), or null
     bool list_sort = true;      // 32-bit positions: every list sorted inside itself (list_sort.hpp); off: the two rocPRIM paths below
     uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
@@ -450,6 +451,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     P_out = nullptr;
     Pc_out = nullptr;
     pc_cap = 0;
+    ws->fences = nullptr;
     if (!acc) return VLG_OK;
     const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (sizeof(pos_t) == 4 ? 32 : 33));
     pos_t* Pa = A.take<pos_t>(acc);
@@ -547,6 +549,19 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
             pc_cap = std::min<uint64_t>(dead_bytes / sizeof(pos_t) - (pc_first - acc) - 64, 0xFFFFFF00ull - pc_first);
         }
     }
+    // fences of the sorted lists (and room for those of the survivors' lists behind them)
+    ws->fences = nullptr;
+    if (P_out) {
+        const uint64_t cover = Pc_out ? (uint64_t)(Pc_out - P_out) + pc_cap : acc;
+        const uint64_t entries = cover / 64 + 2;
+        if (!A.failed && A.size - A.used > entries * sizeof(pos_t) + 4096) {
+            pos_t* F = A.take<pos_t>(entries);
+            if (acc >= 64)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fence_build_kernel<pos_t>), dim3(grid_for(acc / 64, 8192)), dim3(256), 0, st, P_out, (uint64_t)0, acc / 64, F);
+            VLG_HIP_TRY(hipGetLastError());
+            ws->fences = F;
+        }
+    }
     res->sum.located_occurrences += acc;
     return VLG_OK;
 }
@@ -623,8 +638,15 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
             hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_compact_kernel<pos_t>), dim3((uint32_t)(((runs + kCompactRuns - 1) / kCompactRuns + 3) / 4)),
                                dim3(256), 0, st, P, fg->d_segs, d_tseg, d_trun0, (uint32_t)t_seg.size(), fg->d_abits, d_cnt, d_off, Pc);
         }
+        // fences of the survivors' lists: whole blocks of [Pc, Pc + pc_total) (Pc starts on a block)
+        if (ws->fences && pc_total >= 64) {
+            const uint64_t g0 = (uint64_t)(Pc - P) / 64;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fence_build_kernel<pos_t>), dim3(grid_for(pc_total / 64, 8192)), dim3(256), 0, st, P, g0, g0 + pc_total / 64,
+                               static_cast<pos_t*>(ws->fences));
+        }
         VLG_HIP_TRY(hipGetLastError());
     }
+    const pos_t* F = static_cast<const pos_t*>(ws->fences);
     jt.mark("  chunk: compaction launched");
     std::vector<uint32_t> cls_count(kmax + 1, 0), cls_first(kmax + 2, 0);   // segments per dist class
     for (uint64_t qi = q0; qi < q1; ++qi) {
@@ -778,17 +800,17 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
         if (b1 > b0) {
             Timed t(ws, KS_JOIN_LINK, 8ull * (b1 - b0));
             if (dist == 1)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t, true>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, d_segb, nlive, d_sm,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t, true>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, F, d_segb, nlive, d_sm,
                                    (uint32_t)b0, (uint32_t)b1, fref, lvl_ptr[0], endp, link);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t, false>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, d_segb, nlive, d_sm,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t, false>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, F, d_segb, nlive, d_sm,
                                    (uint32_t)b0, (uint32_t)b1, fref, lvl_ptr[0], endp, link);
         }
         if (vlg_status s = summarize_class(dist)) return s;
     }
     {
         Timed t(ws, KS_JOIN_CHAIN, 8ull * (lvl0_end - lvl0_begin));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(runs_grid(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, d_segb, nlive, d_sm,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_jump_kernel<pos_t>), dim3(runs_grid(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, F, d_segb, nlive, d_sm,
                            d_qm, lvl0_begin, lvl0_end, fref, endp, jump, d_qstart);
         if (t0 < lvl0_begin) VLG_HIP_TRY(hipMemsetAsync(jump + t0, 0xFF, (lvl0_begin - t0) * 4, st));   // slots of the first tile before the range
         hipLaunchKernelGGL(chain_tiles_kernel, dim3((uint32_t)((lvl0_end - t0 + kTile - 1) / kTile)), dim3(256), 0, st, jump, t0, lvl0_end, xh);
@@ -1041,7 +1063,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             logical_max_query = std::max(logical_max_query, join_bytes_of(q, qi, [&](uint64_t s) -> uint64_t { return pl.occ[s]; }));
         // the trail table (8 B per text position) and the records (8 B per occurrence) must leave room for the joins
         uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup ? (idx->hdr.n + phys) * 8 + 512 : 0;
-        const uint64_t phys_plain = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20);
+        const uint64_t phys_plain = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20) + phys;    // (+ fences: < 1 B per element)
         if (trail_bytes) {
             const uint64_t left = budget > phys_plain + trail_bytes ? budget - phys_plain - trail_bytes : 0;
             if (left < std::max<uint64_t>(2 * logical_max_query, budget / 8)) trail_bytes = 0;
@@ -1460,6 +1482,7 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
         if (vlg_status s = plan_joins(&qq, pl, ws, 0, n_joins, budget - list_bytes, n_positions, jp)) return s;
         if (vlg_status s = ws_reserve(ws, list_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
         ws->trail_gen = 0;                                       // the lists take the head of the arena
+        ws->fences = nullptr;                                    // (caller-made lists are searched directly)
         Arena A{ws->arena, ws->arena_bytes};
         uint64_t* P = A.take<uint64_t>(pc_first + pc_cap + 64);
         uint64_t* d_off = A.take<uint64_t>(n_lists + 1);
