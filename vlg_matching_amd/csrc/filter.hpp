@@ -298,7 +298,46 @@ __device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, const 
     }
     // wide brackets first shrink 64-fold: lane t reads the last element of the bracket's t-th slice (one load per group), every
     // lane ranks its two keys among these 64 fences through cross-lane reads and goes on inside one slice
-    if (uniform(widest) > 256) {
+    if (F && uniform(widest) > 4096) {
+        // fences: every lane finds the block of the list that holds each of its two answers by bisecting the bracket's FENCES
+        // (dense: a bracket of 65 536 elements has 4 KiB of them, shared by the whole group), then bisects inside the two blocks
+        uint32_t fl0[G], fr0[G], fl1[G], fr1[G];
+        uint32_t widest_f = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t gl = lo[g] >> 6, gh = on[g] ? hi[g] >> 6 : gl;          // fences [gl, gh) lie inside [lo, hi)
+            fl0[g] = fl1[g] = gl;
+            fr0[g] = fr1[g] = gh > gl ? gh : gl;
+            widest_f = fr0[g] - gl > widest_f ? fr0[g] - gl : widest_f;
+        }
+        for (uint32_t w = uniform(wave_max_u32(widest_f)); w; w >>= 1) {
+            uint64_t v0[G], v1[G];
+            uint32_t m0[G], m1[G];
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g) {
+                m0[g] = fl0[g] + ((fr0[g] - fl0[g]) >> 1);
+                m1[g] = fl1[g] + ((fr1[g] - fl1[g]) >> 1);
+                v0[g] = fl0[g] < fr0[g] ? (uint64_t)F[m0[g]] : 0;
+                v1[g] = fl1[g] < fr1[g] ? (uint64_t)F[m1[g]] : 0;
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g) {
+                if (fl0[g] < fr0[g]) { if (v0[g] < a[g]) fl0[g] = m0[g] + 1; else fr0[g] = m0[g]; }
+                if (fl1[g] < fr1[g]) { if (v1[g] <= b[g]) fl1[g] = m1[g] + 1; else fr1[g] = m1[g]; }
+            }
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            if (on[g]) {
+                const uint64_t s0 = (uint64_t)fl0[g] << 6, s1 = (uint64_t)fl1[g] << 6;
+                l0[g] = s0 > lo[g] ? (uint32_t)s0 : lo[g];
+                l1[g] = s1 > lo[g] ? (uint32_t)s1 : lo[g];
+                r0[g] = s0 + 64 < hi[g] ? (uint32_t)(s0 + 64) : hi[g];
+                r1[g] = s1 + 64 < hi[g] ? (uint32_t)(s1 + 64) : hi[g];
+            }
+        }
+        widest = 64;                                                             // what is left is at most one block per key
+    } else if (uniform(widest) > 256) {
         pos_t fence[G];
         uint32_t step[G];
 #pragma unroll
