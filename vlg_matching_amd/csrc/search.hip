@@ -1474,7 +1474,8 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
         // arena: [copy of the lists][room for the survivors of the window filter][filter state][join scratch]
         const uint64_t pc_first = align_up(total, 64);
         uint64_t pc_cap = ws->filter && total ? std::min<uint64_t>(total, 0xFFFFFF00ull - pc_first) : 0;
-        const uint64_t list_bytes = align_up((pc_first + pc_cap + 64) * 8, 256) + align_up((n_lists + 1) * 8, 256) + 4096;
+        const uint64_t fence_entries = (pc_first + pc_cap) / 64 + 2;
+        const uint64_t list_bytes = align_up((pc_first + pc_cap + 64) * 8, 256) + align_up((n_lists + 1) * 8, 256) + align_up(fence_entries * 8, 256) + 4096;
         if (list_bytes >= budget) return fail(VLG_E_WORKSPACE, "the lists do not fit the workspace cap");
         JoinPlan jp;
         // position bound for the filter's block bitmaps: found on the device below, so plan with the widest bound first
@@ -1482,17 +1483,21 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
         if (vlg_status s = plan_joins(&qq, pl, ws, 0, n_joins, budget - list_bytes, n_positions, jp)) return s;
         if (vlg_status s = ws_reserve(ws, list_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
         ws->trail_gen = 0;                                       // the lists take the head of the arena
-        ws->fences = nullptr;                                    // (caller-made lists are searched directly)
+        ws->fences = nullptr;
         Arena A{ws->arena, ws->arena_bytes};
         uint64_t* P = A.take<uint64_t>(pc_first + pc_cap + 64);
         uint64_t* d_off = A.take<uint64_t>(n_lists + 1);
+        uint64_t* F = A.take<uint64_t>(fence_entries);
         if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (join lists)");
         svec<uint64_t> off_stage(h_list_off, h_list_off + n_lists + 1);
         VLG_HIP_TRY(hipMemcpyAsync(d_off, off_stage.data(), (n_lists + 1) * 8, hipMemcpyHostToDevice, st));
         if (total) {
             VLG_HIP_TRY(hipMemcpyAsync(P, d_lists, total * 8, hipMemcpyDeviceToDevice, st));
             hipLaunchKernelGGL(lists_check_kernel, dim3(grid_for((total + 7) / 8, 8192)), dim3(256), 0, st, P, d_off, n_lists, total, d_stats + 4);
+            if (total >= 64)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fence_build_kernel<uint64_t>), dim3(grid_for(total / 64, 8192)), dim3(256), 0, st, P, (uint64_t)0, total / 64, F);
             VLG_HIP_TRY(hipGetLastError());
+            ws->fences = F;                                      // (unsorted input is refused below, before anything searches)
         }
         unsigned long long flags[2] = {0, 0};
         VLG_HIP_TRY(hipMemcpyAsync(flags, d_stats + 4, sizeof flags, hipMemcpyDeviceToHost, st));
