@@ -209,7 +209,6 @@ __global__ void __launch_bounds__(256) filter_pass_kernel(const pos_t* __restric
 // with the lane, so first 2 x kPivotGroups wave-wide 64-ary searches bracket each group's answers between the lower bounds
 // of its smallest a and its largest b + 1, then every lane bisects its own a and b + 1 inside its group's bracket.
 constexpr uint32_t kPivotGroups = 4;
-constexpr uint32_t kPivotFenceMin = 256;        // brackets wider than this are narrowed to one block per key through the fences
 template <typename pos_t>
 __device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, const pos_t* __restrict__ F, uint32_t pbegin, uint32_t pend, const uint64_t (&a)[kPivotGroups],
                                              const uint64_t (&b)[kPivotGroups], bool (&on)[kPivotGroups], uint32_t (&i0)[kPivotGroups],
@@ -299,37 +298,7 @@ __device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, const 
     }
     // wide brackets first shrink 64-fold: lane t reads the last element of the bracket's t-th slice (one load per group), every
     // lane ranks its two keys among these 64 fences through cross-lane reads and goes on inside one slice
-    if (F && uniform(widest) > kPivotFenceMin && uniform(widest) <= 4096) {
-        // a bracket of at most 4096 elements has at most 64 fences inside: one load per group brings them all, every lane ranks
-        // its two keys among them through cross-lane reads and is left with one block of the list per key
-        pos_t fence[G];
-        uint32_t gl[G], nf[G];
-#pragma unroll
-        for (uint32_t g = 0; g < G; ++g) {
-            gl[g] = lo[g] >> 6;
-            nf[g] = (hi[g] >> 6) - gl[g];                                         // fences [gl, gl + nf) lie inside [lo, hi); nf <= 64
-            fence[g] = lane < nf[g] ? F[gl[g] + lane] : (pos_t)0;
-        }
-#pragma unroll
-        for (uint32_t g = 0; g < G; ++g) {
-            uint32_t s0 = 0, e0 = nf[g], s1 = 0, e1 = nf[g];                      // first fence >= a / > b (nf = none)
-#pragma unroll
-            for (uint32_t st = 0; st < 7; ++st) {
-                const uint32_t c0 = (s0 + e0) >> 1, c1 = (s1 + e1) >> 1;
-                const uint64_t f0 = (uint64_t)__shfl(fence[g], (int)(c0 & 63)), f1 = (uint64_t)__shfl(fence[g], (int)(c1 & 63));
-                if (s0 < e0) { if (f0 < a[g]) s0 = c0 + 1; else e0 = c0; }
-                if (s1 < e1) { if (f1 <= b[g]) s1 = c1 + 1; else e1 = c1; }
-            }
-            if (on[g]) {
-                const uint64_t b0 = (uint64_t)(gl[g] + s0) << 6, b1 = (uint64_t)(gl[g] + s1) << 6;
-                l0[g] = b0 > lo[g] ? (uint32_t)b0 : lo[g];
-                l1[g] = b1 > lo[g] ? (uint32_t)b1 : lo[g];
-                r0[g] = b0 + 64 < hi[g] ? (uint32_t)(b0 + 64) : hi[g];
-                r1[g] = b1 + 64 < hi[g] ? (uint32_t)(b1 + 64) : hi[g];
-            }
-        }
-        widest = 64;
-    } else if (F && uniform(widest) > 4096) {
+    if (F && uniform(widest) > 4096) {
         // fences: every lane finds the block of the list that holds each of its two answers by bisecting the bracket's FENCES
         // (dense: a bracket of 65 536 elements has 4 KiB of them, shared by the whole group), then bisects inside the two blocks
         uint32_t fl0[G], fr0[G], fl1[G], fr1[G];
