@@ -34,6 +34,33 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def wait_ranks(procs, poll_s=0.2, grace_s=10.0):
+    """Wait for the rank processes TOGETHER: a rank that dies (OOM, RCCL init failure) leaves the others blocked in a
+    collective, so the first non-zero exit ends the rest (terminate, then kill) and is returned."""
+    rc = 0
+    alive = list(procs)
+    while alive and not rc:
+        time.sleep(poll_s)
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r and not rc:
+                rc = r
+                log("rank process %d exited with code %d: ending the other ranks" % (p.pid, r))
+    for p in alive:
+        p.terminate()
+    deadline = time.time() + grace_s
+    for p in alive:
+        try:
+            p.wait(timeout=max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    return rc
+
+
 def self_launch(args):
     """--gpus N > 1 without a launcher: start N child processes (one per device) and wait.  Decided before this process has
     made any GPU call (it never makes one): a process that has initialised the GPU must not be replaced or forked."""
@@ -47,15 +74,7 @@ def self_launch(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    if rc:                                                   # a rank that died leaves the others in a collective: end them
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    sys.exit(rc)
+    sys.exit(wait_ranks(procs))
 
 
 def load_pmc():

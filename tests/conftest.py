@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# every sort of occurrence lists is verified ascending on the device (search.hip: lists_check_kernel after the sort)
+os.environ.setdefault("VLG_CHECK_SORT", "1")
 
 
 def pytest_configure(config):

@@ -135,3 +135,21 @@ def test_shard_by_affinity_keeps_sharers_together_and_covers_all():
         if world > 1:
             contiguous = [np.arange(b, e) for b, e in (vdist.shard_bounds(400, t, world) for t in range(world))]
             assert located(parts) <= located(contiguous)
+
+
+def test_bench_wait_ranks_ends_the_survivors_of_a_dead_rank():
+    """bench.py --gpus N started plainly: when one rank dies the others sit in a collective; the parent must end them and
+    return the dead rank's exit code instead of waiting for them one after the other."""
+    import subprocess
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    sleeper = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"])
+    dier = subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(3)"])
+    t0 = time.time()
+    rc = bench.wait_ranks([sleeper, dier], poll_s=0.05, grace_s=5.0)
+    assert rc == 3
+    assert sleeper.poll() is not None, "the surviving rank was left running"
+    assert time.time() - t0 < 30
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
+    assert bench.wait_ranks(ok, poll_s=0.05) == 0

@@ -800,9 +800,9 @@ __global__ void __launch_bounds__(256) join_gather_kernel(const pos_t* __restric
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t run_begin = r0 + wave * kRun;
-    if (run_begin >= r1) return;
-    const uint64_t run_end = run_begin + kRun < r1 ? run_begin + kRun : r1;
-    uint32_t s_w = seg_find(seg_begin, nseg, run_begin);
+    const bool live = run_begin < r1;                      // (no early return: every wave of the workgroup reaches the barriers below)
+    const uint64_t run_end = !live ? run_begin : (run_begin + kRun < r1 ? run_begin + kRun : r1);
+    uint32_t s_w = live ? seg_find(seg_begin, nseg, run_begin) : 0;
     unsigned long long local = 0;
     for (uint64_t base = run_begin; base < run_end; base += 64) {
         const uint64_t e = base + lane;

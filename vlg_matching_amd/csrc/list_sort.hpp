@@ -138,6 +138,10 @@ __global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* 
     constexpr uint32_t kItems = kSortTile / 256;
     using Rank = rocprim::block_radix_rank<256, 8, rocprim::block_radix_rank_algorithm::match>;
     static_assert(Rank::digits_per_thread == 1, "thread d holds digit d");
+    // the passes rely on the ranks being STABLE in warp-striped key order (warp w, item i, lane l = element w*64*kItems + 64*i + l),
+    // which is how rocPRIM's match algorithm numbers keys on a 64-wide wavefront; VLG_CHECK_SORT=1 (and the tests) verify the
+    // outcome of every sort with lists_sorted_check_kernel, so a rocPRIM that numbers differently fails loudly, not silently
+    static_assert(kSortTile == 256 * kItems && kItems * 64 * 4 == kSortTile, "four wavefronts of 64 lanes (gfx950), kItems keys per lane");
     __shared__ typename Rank::storage_type s_rank;
     __shared__ uint32_t s_keys[kSortTile];
     __shared__ uint32_t first[256];

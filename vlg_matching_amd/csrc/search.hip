@@ -426,7 +426,44 @@ __global__ void sort_narrow_kernel(const uint64_t* __restrict__ keys, uint64_t t
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) P[t] = (pos_t)(keys[t] & mask);
 }
 
+// flags[0] |= 1 when some list is not ascending; flags[1] = largest element of all lists
+template <typename T>
+__global__ void lists_check_kernel(const T* __restrict__ lists, const uint64_t* __restrict__ off, uint64_t n_lists, uint64_t total,
+                                   unsigned long long* __restrict__ flags)
+{
+    constexpr uint32_t kPer = 8;
+    __shared__ uint64_t s_first;
+    bool bad = false;
+    unsigned long long mx = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
+        if (threadIdx.x == 0) {
+            uint64_t lo = 0, hi = n_lists;                 // last list with off[l] <= base
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (off[mid] <= base) lo = mid; else hi = mid; }
+            s_first = lo;
+        }
+        __syncthreads();
+        uint64_t l = s_first;
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint64_t t = base + i * 256 + threadIdx.x;
+            if (t < total) {
+                while (off[l + 1] <= t) ++l;
+                const uint64_t v = (uint64_t)lists[t];
+                if (t > off[l] && (uint64_t)lists[t - 1] > v) bad = true;
+                mx = v > mx ? v : mx;
+            }
+        }
+        __syncthreads();
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1ull);
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long u = __shfl_xor(mx, o); mx = u > mx ? u : mx; }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&flags[1], mx);
+}
+
+
 #include "list_sort.hpp"
+
+inline bool check_sort_enabled() { static const bool on = [] { const char* e = getenv("VLG_CHECK_SORT"); return e && e[0] == '1'; }(); return on; }
 
 // ---- physical pass: locate + sort every distinct interval used by queries [Q0,Q1) -------------------
 template <typename pos_t>
@@ -539,6 +576,19 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(d_tmp, tb, Pa, Pb, (unsigned)acc, nd, d_off32, d_off32 + 1, 0, bits, st));
         P_out = Pb;
         dead_bytes = acc * kPhysScratchPerElem<pos_t>() - acc * sizeof(pos_t);
+    }
+    // VLG_CHECK_SORT=1 (set by the tests): every list is verified ascending on the device after the sort -- list_sort.hpp leans on
+    // the key order of rocPRIM's block_radix_rank, which a library upgrade could change silently
+    if (check_sort_enabled() && P_out) {
+        unsigned long long* d_flags = A.take<unsigned long long>(2);
+        if (!d_flags) return fail(VLG_E_INTERNAL, "arena carve failed (sort check)");
+        unsigned long long flags[2] = {0, 0};
+        VLG_HIP_TRY(hipMemsetAsync(d_flags, 0, 16, st));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lists_check_kernel<pos_t>), dim3(grid_for((acc + 7) / 8, 8192)), dim3(256), 0, st, P_out, d_off64, (uint64_t)nd, acc, d_flags);
+        VLG_HIP_TRY(hipGetLastError());
+        VLG_HIP_TRY(hipMemcpyAsync(flags, d_flags, 16, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipStreamSynchronize(st));
+        if (flags[0]) return fail(VLG_E_INTERNAL, "an occurrence list is not ascending after the sort (VLG_CHECK_SORT)");
     }
     // no wait here: the staging vectors live in the workspace's pinned pool until the batch ends, so the caller plans the
     // window filter while the sort runs
@@ -1374,43 +1424,6 @@ extern "C" vlg_status vlg_queries_occurrences(const vlg_index* idx, const vlg_qu
 // =============================================================================================
 // K5 on caller-provided lists
 // =============================================================================================
-namespace {
-
-// flags[0] |= 1 when some list is not ascending; flags[1] = largest element of all lists
-__global__ void lists_check_kernel(const uint64_t* __restrict__ lists, const uint64_t* __restrict__ off, uint64_t n_lists, uint64_t total,
-                                   unsigned long long* __restrict__ flags)
-{
-    constexpr uint32_t kPer = 8;
-    __shared__ uint64_t s_first;
-    bool bad = false;
-    unsigned long long mx = 0;
-    for (uint64_t base = (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
-        if (threadIdx.x == 0) {
-            uint64_t lo = 0, hi = n_lists;                 // last list with off[l] <= base
-            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (off[mid] <= base) lo = mid; else hi = mid; }
-            s_first = lo;
-        }
-        __syncthreads();
-        uint64_t l = s_first;
-#pragma unroll
-        for (uint32_t i = 0; i < kPer; ++i) {
-            const uint64_t t = base + i * 256 + threadIdx.x;
-            if (t < total) {
-                while (off[l + 1] <= t) ++l;
-                const uint64_t v = lists[t];
-                if (t > off[l] && lists[t - 1] > v) bad = true;
-                mx = v > mx ? v : mx;
-            }
-        }
-        __syncthreads();
-    }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1ull);
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long u = __shfl_xor(mx, o); mx = u > mx ? u : mx; }
-    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&flags[1], mx);
-}
-
-}  // namespace
-
 extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_list_off, uint64_t n_lists, const uint64_t* h_join_list,
                                      const uint64_t* h_lo, const uint64_t* h_hi, const uint64_t* h_end_len, uint64_t n_joins,
                                      vlg_workspace* ws, vlg_result** out)
@@ -1477,36 +1490,43 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
         const uint64_t fence_entries = (pc_first + pc_cap) / 64 + 2;
         const uint64_t list_bytes = align_up((pc_first + pc_cap + 64) * 8, 256) + align_up((n_lists + 1) * 8, 256) + align_up(fence_entries * 8, 256) + 4096;
         if (list_bytes >= budget) return fail(VLG_E_WORKSPACE, "the lists do not fit the workspace cap");
+        // the input is checked where it lies (ascending lists, largest position) BEFORE anything is planned: the bound on the
+        // positions sizes the block bitmaps of the window filter, so the one plan made below is the one that is executed and the
+        // arena is reserved for exactly that plan
+        unsigned long long flags[2] = {0, 0};
+        uint64_t* d_off_in = nullptr;
+        svec<uint64_t> off_stage(h_list_off, h_list_off + n_lists + 1);
+        if (total) {
+            VLG_HIP_TRY(hipMalloc((void**)&d_off_in, (n_lists + 1) * 8));
+            hipError_t e = hipMemcpyAsync(d_off_in, off_stage.data(), (n_lists + 1) * 8, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lists_check_kernel<uint64_t>), dim3(grid_for((total + 7) / 8, 8192)), dim3(256), 0, st, d_lists, d_off_in, n_lists, total, d_stats + 4);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(flags, d_stats + 4, sizeof flags, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            (void)hipFree(d_off_in);
+            VLG_HIP_TRY(e);
+        }
+        if (flags[0]) return fail(VLG_E_INVALID, "every list must be ascending");
+        if (flags[1] > (1ull << 63)) return fail(VLG_E_INVALID, "positions above 2^63 are not supported");
+        const uint64_t n_positions = flags[1] + 1;
         JoinPlan jp;
-        // position bound for the filter's block bitmaps: found on the device below, so plan with the widest bound first
-        uint64_t n_positions = 1ull << 63;
         if (vlg_status s = plan_joins(&qq, pl, ws, 0, n_joins, budget - list_bytes, n_positions, jp)) return s;
         if (vlg_status s = ws_reserve(ws, list_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
         ws->trail_gen = 0;                                       // the lists take the head of the arena
         ws->fences = nullptr;
         Arena A{ws->arena, ws->arena_bytes};
         uint64_t* P = A.take<uint64_t>(pc_first + pc_cap + 64);
-        uint64_t* d_off = A.take<uint64_t>(n_lists + 1);
         uint64_t* F = A.take<uint64_t>(fence_entries);
         if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (join lists)");
-        svec<uint64_t> off_stage(h_list_off, h_list_off + n_lists + 1);
-        VLG_HIP_TRY(hipMemcpyAsync(d_off, off_stage.data(), (n_lists + 1) * 8, hipMemcpyHostToDevice, st));
         if (total) {
             VLG_HIP_TRY(hipMemcpyAsync(P, d_lists, total * 8, hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(lists_check_kernel, dim3(grid_for((total + 7) / 8, 8192)), dim3(256), 0, st, P, d_off, n_lists, total, d_stats + 4);
             if (total >= 64)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(fence_build_kernel<uint64_t>), dim3(grid_for(total / 64, 8192)), dim3(256), 0, st, P, (uint64_t)0, total / 64, F);
             VLG_HIP_TRY(hipGetLastError());
-            ws->fences = F;                                      // (unsorted input is refused below, before anything searches)
+            ws->fences = F;
         }
-        unsigned long long flags[2] = {0, 0};
-        VLG_HIP_TRY(hipMemcpyAsync(flags, d_stats + 4, sizeof flags, hipMemcpyDeviceToHost, st));
-        VLG_HIP_TRY(hipStreamSynchronize(st));
-        if (flags[0]) return fail(VLG_E_INVALID, "every list must be ascending");
-        if (flags[1] > (1ull << 63)) return fail(VLG_E_INVALID, "positions above 2^63 are not supported");
-        n_positions = flags[1] + 1;
-        // the plan again with the real bound (smaller bitmaps can only need less than what was reserved)
-        if (vlg_status s = plan_joins(&qq, pl, ws, 0, n_joins, budget - list_bytes, n_positions, jp)) return s;
         tr.mark("join lists copied + checked");
         if (vlg_status s = run_joins<uint64_t>(n_positions, &qq, ws, res, pl, poff, P, A, pc_cap ? P + pc_first : nullptr, pc_cap, 0, n_joins, jp,
                                                d_stats, tr)) return s;

@@ -285,7 +285,8 @@ extern "C" vlg_status vlg_wtsa_build(const void* h_text, uint64_t n_symbols, uin
     x->nb = x->n_vals / kBlockBits + 1;
     uint8_t* d_bytes = nullptr;
     uint32_t *d_sa = nullptr, *d_a = nullptr, *d_b = nullptr, *d_ka = nullptr, *d_kb = nullptr, *d_pops = nullptr;
-    void* d_tmp = nullptr;
+    uint32_t *d_flag = nullptr, *d_pos = nullptr, *d_out = nullptr;        // integer texts: the aligned suffixes (freed below on every path)
+    void *d_tmp = nullptr, *d_scan2 = nullptr;
     auto grid = [](uint64_t n) { return dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 16384))); };
     auto run = [&]() -> vlg_status {
         VLG_HIP_TRY(hipMalloc(&x->d_text, std::max<uint64_t>(n_symbols * symbol_bytes, 16)));
@@ -301,7 +302,6 @@ extern "C" vlg_status vlg_wtsa_build(const void* h_text, uint64_t n_symbols, uin
             if (vlg_status st = vlg_suffix_array_device(d_bytes, byte_len, d_sa, nullptr)) return st;
             (void)hipFree(d_bytes); d_bytes = nullptr;
             // the suffixes that start on a symbol, in order
-            uint32_t *d_flag = nullptr, *d_pos = nullptr, *d_out = nullptr;
             const uint64_t nb5 = byte_len + 1;
             VLG_HIP_TRY(hipMalloc((void**)&d_flag, nb5 * 4));
             VLG_HIP_TRY(hipMalloc((void**)&d_pos, nb5 * 4));
@@ -309,14 +309,16 @@ extern "C" vlg_status vlg_wtsa_build(const void* h_text, uint64_t n_symbols, uin
             hipLaunchKernelGGL(wtsa_aligned_flags_kernel, grid(nb5), dim3(256), 0, nullptr, d_sa, nb5, d_flag);
             size_t tb = 0;
             VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_flag, d_pos, 0u, nb5, rocprim::plus<uint32_t>(), nullptr));
-            void* t2 = nullptr;
-            VLG_HIP_TRY(hipMalloc(&t2, tb + 16));
-            hipError_t e = rocprim::exclusive_scan(t2, tb, d_flag, d_pos, 0u, nb5, rocprim::plus<uint32_t>(), nullptr);
-            if (e == hipSuccess) hipLaunchKernelGGL(wtsa_aligned_compact_kernel, grid(nb5), dim3(256), 0, nullptr, d_sa, d_pos, nb5, d_out);
-            if (e == hipSuccess) e = hipDeviceSynchronize();
-            (void)hipFree(t2); (void)hipFree(d_flag); (void)hipFree(d_pos); (void)hipFree(d_sa);
-            d_sa = d_out;
-            VLG_HIP_TRY(e);
+            VLG_HIP_TRY(hipMalloc(&d_scan2, tb + 16));
+            VLG_HIP_TRY(rocprim::exclusive_scan(d_scan2, tb, d_flag, d_pos, 0u, nb5, rocprim::plus<uint32_t>(), nullptr));
+            hipLaunchKernelGGL(wtsa_aligned_compact_kernel, grid(nb5), dim3(256), 0, nullptr, d_sa, d_pos, nb5, d_out);
+            VLG_HIP_TRY(hipGetLastError());
+            VLG_HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(d_scan2); d_scan2 = nullptr;
+            (void)hipFree(d_flag); d_flag = nullptr;
+            (void)hipFree(d_pos); d_pos = nullptr;
+            (void)hipFree(d_sa);
+            d_sa = d_out; d_out = nullptr;
         }
         // ---- the tree, one level at a time: emit the bits of the current arrangement, then sort stably by one more bit of prefix ---------
         const uint64_t n = x->n_vals;
@@ -352,7 +354,9 @@ extern "C" vlg_status vlg_wtsa_build(const void* h_text, uint64_t n_symbols, uin
         return VLG_OK;
     };
     vlg_status st = run();
-    for (void* p : {(void*)d_bytes, (void*)d_sa, (void*)d_a, (void*)d_b, (void*)d_ka, (void*)d_kb, (void*)d_pops, d_tmp}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)d_bytes, (void*)d_sa, (void*)d_a, (void*)d_b, (void*)d_ka, (void*)d_kb, (void*)d_pops, d_tmp, (void*)d_flag, (void*)d_pos,
+                    (void*)d_out, d_scan2})
+        if (p) (void)hipFree(p);
     if (st) { vlg_wtsa_destroy(x); return st; }
     *out = x;
     return VLG_OK;
