@@ -253,6 +253,12 @@ def main():
     ap.add_argument("--tuples", action="store_true", help="also materialise every sub-pattern position of every match (sdsl::locate output)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--dist-at-1", action="store_true",
+                    help="rehearsal: with --gpus 1, still open a 1-rank process group and take the multi-rank code path (RCCL broadcast "
+                         "of the index, scatter of the batches, reductions, strong-scaling region)")
+    ap.add_argument("--index-broadcast", choices=["rccl", "torch"], default="rccl",
+                    help="N > 1: replicate the index by vlg_index_broadcast over a communicator made through the C-ABI (default), or by "
+                         "torch.distributed.broadcast of a uint8 tensor")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -272,8 +278,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_at_1:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
         else:
@@ -312,13 +323,22 @@ def main():
             log("rrr-63 re-encoding on device in %.2f s: %s" % (time.perf_counter() - t0, idx.info()))
             if args.no_cpu_baseline or world > 1:
                 plain_idx = None
-    if world > 1:
+    bcast_via = None
+    if dist is not None:
+        comm = None
+        if args.backend == "nccl" and args.index_broadcast == "rccl":
+            comm = vdist.Comm.from_torch_dist(dist)                # ncclCommInitRank through the C-ABI; the id goes through torch's store
+            bcast_via = "vlg_index_broadcast (RCCL: %s)" % comm.library()
+        else:
+            bcast_via = "torch.distributed.broadcast (%s)" % args.backend
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        idx = vdist.replicate_index(idx, dist, dev, src=0)
+        idx = vdist.replicate_index(idx, dist, dev, src=0, comm=comm)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
-        log("rank %d: index image replicated in %.3f s" % (rank, t_bcast))
+        log("rank %d: index image replicated in %.3f s via %s" % (rank, t_bcast, bcast_via))
+        if comm is not None:
+            comm.close()
     info = idx.info()
 
     # ---- query batches: one per rank (weak scaling), generated where the text is ---------------------------
@@ -327,7 +347,7 @@ def main():
                    for r in range(world)]
     else:
         batches = None
-    if world > 1:
+    if dist is not None:
         mine = [None]
         dist.scatter_object_list(mine, batches if rank == 0 else None, src=0)
         queries = mine[0]
@@ -346,7 +366,7 @@ def main():
 
     def timed(fn, steps):
         """barrier + synchronize on both sides, max over ranks -> (seconds, last return value)"""
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -355,10 +375,10 @@ def main():
             out = fn()
         torch.cuda.synchronize()
         mine_dt = time.perf_counter() - t0
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -366,13 +386,13 @@ def main():
 
     def reduce_sum(vals):
         t = torch.tensor(vals, dtype=torch.int64, device=dev)
-        if world > 1:
+        if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return [int(x) for x in t.tolist()]
 
     def gather_per_rank(vals):
         t = torch.tensor(vals, dtype=torch.float64, device=dev)
-        if world == 1:
+        if dist is None:
             return [t.tolist()]
         outl = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(outl, t)
@@ -429,7 +449,7 @@ def main():
 
     # ---- strong scaling: THE batch (rank 0's) cut by work, every rank searches its slice ------------------------------------
     strong = None
-    if world > 1 and not args.no_strong:
+    if dist is not None and not args.no_strong:
         if rank == 0:
             if args.strong_sharding == "affinity":             # queries that share their longest list stay together
                 l_, r_, q_all = idx.intervals(queries)
@@ -532,7 +552,7 @@ def main():
             "lf_steps_per_occ": s["lf_steps"] / max(s["located_occurrences"], 1),
             "wt_levels_per_lf": s["wt_levels_locate"] / max(s["lf_steps"], 1),
             "chunks_per_step": s["n_chunks"],
-            "index_build_s": t_build, "text_gen_s": t_gen, "index_broadcast_s": t_bcast,
+            "index_build_s": t_build, "text_gen_s": t_gen, "index_broadcast_s": t_bcast, "index_broadcast_via": bcast_via,
             "per_rank": [{"ms_per_step": p[0], "located_occ": int(p[1]), "matches": int(p[2])} for p in per_rank],
             "e2e_ms_per_step": e2e["ms_per_step"] if e2e else None,
             "e2e": e2e,
@@ -552,7 +572,7 @@ def main():
             if sas is not None:
                 out["cpu_baseline"]["sasearch"] = sas
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -163,6 +163,31 @@ vlg_status vlg_index_attach_blob(const void* d_blob, uint64_t bytes, vlg_index**
 vlg_status vlg_index_replicate(const vlg_index* src, int device, vlg_index** out);
 
 /* ------------------------------------------------------------------------------------------
+ * X1: RCCL (one process per GPU over xGMI; SURVEY.md 8b "broadcast(handle, ncclComm)", 8e).  An ncclComm_t crosses this ABI as
+ * void*.  The caller may bring its own communicator (created with the RCCL its process holds: the library binds RCCL at run time
+ * and calls the one already loaded, else librccl.so.1), or make one here: rank 0 calls vlg_comm_unique_id, the host hands the 128
+ * bytes to every rank (a pipe, a file, MPI ...), every rank calls vlg_comm_create with its device current.
+ * ---------------------------------------------------------------------------------------- */
+const char* vlg_comm_library(void);                               /* path of the RCCL that was bound ("" = none)  */
+typedef struct { char bytes[128]; } vlg_comm_id;                  /* ncclUniqueId                                */
+vlg_status vlg_comm_unique_id(vlg_comm_id* out);                  /* ncclGetUniqueId                             */
+vlg_status vlg_comm_create(const vlg_comm_id* id, int n_ranks, int rank, void** nccl_comm);   /* ncclCommInitRank */
+vlg_status vlg_comm_info(void* nccl_comm, int* n_ranks, int* rank);
+void vlg_comm_destroy(void* nccl_comm);
+/* The read-only index of rank `root` in every rank's HBM: one ncclBroadcast of its contiguous image (size first), received
+ * straight into the allocation the new index owns -- `idx.load(istream)` on every rank (gm_search.cpp:68-80) replaced by one load
+ * + one collective.  Root: pass the index, *out (optional) receives the same handle; other ranks: pass NULL, *out receives a new
+ * index to destroy.  Collective: every rank of the communicator calls it. */
+vlg_status vlg_index_broadcast(const vlg_index* idx_or_null, void* nccl_comm, int root, void* stream, vlg_index** out);
+/* Sum over the ranks, in place, modulo 2^64 -- num_results / checksum (gm_search.cpp:110-114) / located occurrences of a sharded
+ * batch.  Host values in, host values out. */
+vlg_status vlg_comm_allreduce_sum_u64(void* nccl_comm, uint64_t* h_vals, uint32_t count, void* stream);
+/* All-gather of device buffers of different sizes: rank r contributes h_counts[r] elements of elem_bytes (d_send); every rank
+ * ends with all of them in rank order in d_recv.  The exchange step of the list-sharded locate (vlg_workspace option "comm"). */
+vlg_status vlg_comm_allgatherv(void* nccl_comm, const void* d_send, const uint64_t* h_counts, uint32_t elem_bytes, void* d_recv,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K1: batched bit-rank.  rank_support_v<1,1>::rank / rank_support_v5<1,1>::rank
  * (include/sdsl/rank_support_v.hpp:114-124, rank_support_v5.hpp:116-134) on a plain bit_vector,
  * re-laid out as 256-bit super-blocks {32-bit count, 224 data bits}.
@@ -337,6 +362,15 @@ vlg_status vlg_wtsa_get_info(const vlg_wtsa* idx, vlg_wtsa_info* info);
 void vlg_wtsa_destroy(vlg_wtsa* idx);
 /* wt[i] (wt_int::operator[], include/sdsl/wt_int.hpp:339-361) = SA[i] for arbitrary indices. */
 vlg_status vlg_wtsa_sa_batch(const vlg_wtsa* idx, const uint64_t* d_i, uint64_t* d_out, uint64_t count, void* stream);
+/* The two walks every search of this index is made of, on arbitrary suffix-array ranges [l, l + len): what the reference gets from
+ * wt_int::expand(v) / expand(v, range) as vlg_iterator's wt_range_walker descends (include/sdsl/wt_int.hpp:824-939,
+ * wt_helper.hpp:726-785).  quantile == 0: out[j] = number of SA[l, l + len) smaller than x[j]; quantile != 0: out[j] = the x[j]-th
+ * smallest of them (0-based, x[j] < len[j]).  A range outside the suffix array (or x[j] >= len[j]) gives ~0. */
+vlg_status vlg_wtsa_range_walk_batch(const vlg_wtsa* idx, const uint64_t* d_l, const uint64_t* d_len, const uint64_t* d_x, int quantile,
+                                     uint64_t* d_out, uint64_t count, void* stream);
+/* Level `level` of the tree as plain words (bit i = h_words[i >> 6] >> (i & 63), ceil(n / 64) words): bits [level * n, (level + 1) * n)
+ * of wt_int::tree (include/sdsl/wt_int.hpp:162, 215-255) -- what m_wt.serialize stores (vlg_index.hpp:181-190). */
+vlg_status vlg_wtsa_export_level(const vlg_wtsa* idx, uint32_t level, uint64_t* h_words);
 /* forward_search(text.begin(), text.end(), wt, 0, wt.size()-1, pat.begin(), pat.end(), sp, ep)
  * (include/sdsl/suffix_array_algorithm.hpp:48-112) for every sub-pattern of the batch: h_sp/h_ep receive the suffix-array
  * range [sp, ep] (sp = ep + 1: no occurrence). */

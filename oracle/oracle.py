@@ -149,6 +149,22 @@ def ref():
         R.vref_bitrank.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         R.vref_rank_v_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         R.vref_rank_v_blocks.restype = C.c_uint64
+        # wt_int<bit_vector_il<>, rank_support_il<>> (the tree of vlg_index) and int_alphabet
+        R.vrefw_create.argtypes = [C.c_void_p, C.c_uint64]
+        R.vrefw_create.restype = C.c_void_p
+        R.vrefw_destroy.argtypes = [C.c_void_p]
+        R.vrefw_size.argtypes = [C.c_void_p]
+        R.vrefw_size.restype = C.c_uint64
+        R.vrefw_levels.argtypes = [C.c_void_p]
+        R.vrefw_levels.restype = C.c_uint32
+        R.vrefw_access.argtypes = [C.c_void_p, C.c_uint64]
+        R.vrefw_access.restype = C.c_uint64
+        R.vrefw_tree_bits.argtypes = [C.c_void_p, C.c_void_p]
+        for nm in ("vrefw_count_less", "vrefw_quantile"):
+            getattr(R, nm).argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+            getattr(R, nm).restype = C.c_uint64
+        R.vref_int_alphabet.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        R.vref_int_alphabet.restype = C.c_uint64
         _REF = R
     return _REF
 
@@ -454,3 +470,51 @@ def rrr_rank(words, nbits, idx):
     bits = int(lib().vlgo_rrr_bits(h))
     lib().vlgo_rrr_free(h)
     return out, bits
+
+
+class RefWtInt:
+    """The reference's own wt_int<bit_vector_il<>, rank_support_il<>> (the tree type of vlg_index, vlg_index.hpp:116-119) over a
+    vector of values, built by its constructor; count_less / quantile walk it through the reference's expand() only."""
+
+    def __init__(self, values):
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        self.h = ref().vrefw_create(v.ctypes.data, len(v))
+        assert self.h, "reference wt_int construction failed"
+        self.n = len(v)
+        self.levels = int(ref().vrefw_levels(self.h))
+        assert int(ref().vrefw_size(self.h)) == self.n
+
+    def __del__(self):
+        try:
+            if self.h:
+                ref().vrefw_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def __getitem__(self, i):
+        return int(ref().vrefw_access(self.h, int(i)))
+
+    def level_bits(self):
+        """[levels][n] array of bits: level l of wt_int::tree is its bits [l * n, (l + 1) * n)"""
+        nb = self.n * self.levels
+        w = np.zeros((nb + 63) // 64 + 1, dtype=np.uint64)
+        ref().vrefw_tree_bits(self.h, w.ctypes.data)
+        bits = np.unpackbits(w.view(np.uint8), bitorder="little")[:nb]
+        return bits.reshape(self.levels, self.n)
+
+    def count_less(self, l, length, x):
+        return int(ref().vrefw_count_less(self.h, int(l), int(length), int(x)))
+
+    def quantile(self, l, length, q):
+        return int(ref().vrefw_quantile(self.h, int(l), int(length), int(q)))
+
+
+def ref_int_alphabet(text):
+    """int_alphabet<> built by the reference's constructor (csa_alphabet_strategy.hpp:394-470) -> (C[sigma+1], comp2char[sigma])"""
+    t = np.ascontiguousarray(text, dtype=np.uint64)
+    sigma = int(ref().vref_int_alphabet(t.ctypes.data, len(t), None, None))
+    assert sigma != (1 << 64) - 1
+    Cc, c2c = np.zeros(sigma + 1, np.uint64), np.zeros(max(sigma, 1), np.uint64)
+    assert int(ref().vref_int_alphabet(t.ctypes.data, len(t), Cc.ctypes.data, c2c.ctypes.data)) == sigma
+    return Cc, c2c[:sigma]

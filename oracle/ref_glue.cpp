@@ -12,6 +12,10 @@
 //                                          rrr_vector.hpp:145-237,444-480)
 //   * byte_alphabet                       (lib/csa_alphabet_strategy.cpp:25-55)
 //   * LF trait traverse_csa_wt            (suffix_array_helper.hpp:336-349)
+//   * wt_int<bit_vector_il<>, rank_support_il<>>  -- the tree type of vlg_index (vlg_index.hpp:116-119): ctor, operator[],
+//                                         the level-concatenated bit-vector `tree`, expand(node) / expand(node, range) / value_range
+//                                         (include/sdsl/wt_int.hpp:182-270, 339-361, 824-939; bit_vector_il.hpp)
+//   * int_alphabet<>                      (include/sdsl/csa_alphabet_strategy.hpp:394-470; lib/csa_alphabet_strategy.cpp)
 //
 // What is NOT buildable in this image (see DESIGN.md "Oracle"):
 //   csa_wt.hpp / wavelet_trees.hpp / suffix_arrays.hpp / vlg_index.hpp / index_sasearch.hpp all
@@ -28,6 +32,8 @@
 #include <sdsl/rank_support_v5.hpp>
 #include <sdsl/rrr_vector.hpp>
 #include <sdsl/wt_huff.hpp>
+#include <sdsl/wt_int.hpp>
+#include <sdsl/bit_vector_il.hpp>
 #include <sdsl/csa_alphabet_strategy.hpp>
 #include <sdsl/suffix_array_helper.hpp>
 #include <sdsl/io.hpp>
@@ -312,6 +318,111 @@ int vref_check_csa_image(const char* path, const uint8_t* bwt, const uint64_t* s
     } catch (...) {
         return 99;
     }
+}
+
+// ---- the tree of vlg_index: wt_int<bit_vector_il<>, rank_support_il<>> over a vector of values (the suffix array) ----------------
+// Built by the reference's own constructor from an int_vector_buffer, as construct(wts, KEY_SA file) does (vlg_index.hpp:386-387,
+// wt_int.hpp:182-270).  count_less / quantile below walk the tree ONLY through the reference's expand(v) / expand(v, range) /
+// value_range / size / is_leaf -- the calls vlg_iterator's wt_range_walker makes (wt_helper.hpp:726-785) -- so they say what the
+// reference's tree answers for a suffix-array range.
+typedef wt_int<bit_vector_il<>, rank_support_il<>> wtsa_ref_type;
+
+void* vrefw_create(const uint64_t* vals, uint64_t n)
+{
+    try {
+        std::string f = "@vref_sa_" + std::to_string(g_seq++);
+        {
+            int_vector<> v(n, 0, 64);
+            for (uint64_t i = 0; i < n; ++i) v[i] = vals[i];
+            store_to_file(v, f);
+        }
+        wtsa_ref_type* wt = nullptr;
+        {
+            int_vector_buffer<> buf(f);
+            wt = new wtsa_ref_type(buf, n);
+        }
+        sdsl::remove(f);
+        return wt;
+    } catch (...) {}
+    return nullptr;
+}
+void vrefw_destroy(void* h) { delete (wtsa_ref_type*)h; }
+uint64_t vrefw_size(void* h) { return ((wtsa_ref_type*)h)->size(); }
+uint32_t vrefw_levels(void* h) { return ((wtsa_ref_type*)h)->max_level; }
+uint64_t vrefw_access(void* h, uint64_t i) { return (*(wtsa_ref_type*)h)[i]; }
+// the concatenation of all level bit-vectors (wt_int::tree): size * max_level bits, level l = bits [l * size, (l + 1) * size)
+void vrefw_tree_bits(void* h, uint64_t* words)
+{
+    const wtsa_ref_type& wt = *(wtsa_ref_type*)h;
+    const uint64_t nb = wt.tree.size();
+    for (uint64_t i = 0; i < (nb + 63) / 64; ++i) words[i] = 0;
+    for (uint64_t i = 0; i < nb; ++i) if (wt.tree[i]) words[i >> 6] |= 1ULL << (i & 63);
+}
+// number of values < x among wt[l, l + len)
+uint64_t vrefw_count_less(void* h, uint64_t l, uint64_t len, uint64_t x)
+{
+    const wtsa_ref_type& wt = *(wtsa_ref_type*)h;
+    if (!len) return 0;
+    auto v = wt.root();
+    sdsl::range_type r = {{l, l + len - 1}};
+    uint64_t acc = 0;
+    while (!wt.is_leaf(v)) {
+        auto vr = wt.value_range(v);
+        if (x <= vr[0]) return acc;
+        if (x > vr[1]) return acc + (r[1] + 1 - r[0]);
+        auto ch = wt.expand(v);
+        auto rs = wt.expand(v, r);
+        const uint64_t left_n = rs[0][1] + 1 - rs[0][0];           // (an empty range has [s, s - 1])
+        if (x > wt.value_range(ch[0])[1]) {                          // everything in the left child is smaller
+            acc += left_n;
+            v = ch[1]; r = rs[1];
+        } else { v = ch[0]; r = rs[0]; }
+        if (r[1] + 1 == r[0]) return acc;
+    }
+    return acc + (wt.sym(v) < x ? r[1] + 1 - r[0] : 0);
+}
+// the q-th smallest (0-based) of wt[l, l + len), q < len
+uint64_t vrefw_quantile(void* h, uint64_t l, uint64_t len, uint64_t q)
+{
+    const wtsa_ref_type& wt = *(wtsa_ref_type*)h;
+    auto v = wt.root();
+    sdsl::range_type r = {{l, l + len - 1}};
+    while (!wt.is_leaf(v)) {
+        auto ch = wt.expand(v);
+        auto rs = wt.expand(v, r);
+        const uint64_t left_n = rs[0][1] + 1 - rs[0][0];
+        if (q < left_n) { v = ch[0]; r = rs[0]; }
+        else { q -= left_n; v = ch[1]; r = rs[1]; }
+    }
+    return wt.sym(v);
+}
+
+// ---- int_alphabet (csa_alphabet_strategy.hpp:394-470): built by the reference's constructor from an integer text -----------------
+// out_C must hold sigma + 1 entries, out_comp2char sigma entries (call with nulls first to get sigma).
+uint64_t vref_int_alphabet(const uint64_t* text, uint64_t n, uint64_t* out_C, uint64_t* out_comp2char)
+{
+    try {
+        std::string f = "@vref_itext_" + std::to_string(g_seq++);
+        {
+            int_vector<> v(n, 0, 64);
+            for (uint64_t i = 0; i < n; ++i) v[i] = text[i];
+            store_to_file(v, f);
+        }
+        uint64_t sigma = 0;
+        {
+            int_vector_buffer<> buf(f);
+            int_alphabet<> a(buf, n);
+            sigma = a.sigma;
+            if (out_C) for (uint64_t i = 0; i <= sigma; ++i) out_C[i] = a.C[i];
+            if (out_comp2char) for (uint64_t i = 0; i < sigma; ++i) {
+                out_comp2char[i] = a.comp2char[i];
+                if (a.char2comp[a.comp2char[i]] != i) return ~0ull;
+            }
+        }
+        sdsl::remove(f);
+        return sigma;
+    } catch (...) {}
+    return ~0ull;
 }
 
 } // extern "C"

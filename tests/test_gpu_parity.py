@@ -368,6 +368,53 @@ def test_cpp_example_lazy_iterator_on_a_file(V, oracle, tmp_path):
     assert got == want
 
 
+def test_c1_plumbing(V, oracle, tmp_path):
+    """BASELINE config 1: 2^20 characters of uniform DNA (seed 1), the three queries of
+    examples/vlg_matching.cpp:40-42 (lower case: no match on this text) and ACGTA.{0,100}?TTGCA -- through the example binary
+    given the text as a file, through VlgIndex.search (FM-index path) and through the paper's index (vlg_wtsa_*), all equal to
+    the oracle; the one query that matches is also checked against a plain scan of the text."""
+    import subprocess
+    from vlg_matching_amd import workload
+    from vlg_matching_amd.index import WtsaIndex
+    cfg = workload.config("C1")
+    assert cfg["kind"] == "dna" and cfg["n"] == 1 << 20 and cfg["seed"] == 1
+    text = workload.gen_text(cfg["kind"], cfg["n"], cfg["seed"]).tobytes()
+    assert len(text) == 1 << 20 and set(text) == set(b"ACGT")
+    queries = ["ac.{2,5}?a.{4,8}?b", "a.{0,10}?a.{0,10}?a", "foo.{0,10}?bar", "ACGTA.{0,100}?TTGCA"]
+    o = oracle.Index.from_text(text)
+    want = [o.search(q).tolist() for q in queries]
+    assert [len(w) for w in want[:3]] == [0, 0, 0] and len(want[3]) > 50
+    # independent truth for the matching query: left-most, lazy, non-overlapping pairs from a scan of the text
+    a = np.array([i for i in range(len(text) - 4) if text[i:i + 5] == b"ACGTA"], dtype=np.int64)
+    b = np.array([i for i in range(len(text) - 4) if text[i:i + 5] == b"TTGCA"], dtype=np.int64)
+    scan, nxt = [], 0
+    for x in a:
+        if x < nxt:
+            continue
+        j = np.searchsorted(b, x + 5)
+        if j < len(b) and b[j] <= x + 5 + 100:
+            scan.append([int(x), int(b[j])])
+            nxt = int(b[j]) + 5
+    assert scan == want[3]
+    (tmp_path / "c1.txt").write_bytes(text)
+    out = subprocess.run([_bin("vlg_matching_example"), str(tmp_path / "c1.txt")] + queries, capture_output=True, text=True, check=True).stdout
+    blocks = out.split("\ncount(")[1:]
+    assert len(blocks) == len(queries)
+    for q, w, blk in zip(queries, want, blocks):
+        assert blk.startswith("%s)=%d\n" % (q, len(w)))
+        got = [[int(x) for x in l.split(":")[1].split()] for l in blk.splitlines() if "Subpattern positions" in l]
+        first = [int(l.rsplit(" ", 1)[1]) for l in blk.splitlines() if "occ starting at position" in l]
+        assert got == w and first == [t[0] for t in w]
+    idx = V.VlgIndex.build(text)
+    res = idx.search(queries)
+    for i, w in enumerate(want):
+        assert res.tuples(i).tolist() == w
+        assert V.count(idx, queries[i]) == len(w)
+    wres = WtsaIndex(text).search(queries)
+    for i, w in enumerate(want):
+        assert wres.tuples(i).tolist() == w
+
+
 def test_cpp_driver_pipeline_matches_oracle(V, oracle, tmp_path):
     """gm_index_gpu + gm_search_gpu on a generated collection: the machine-readable lines of gm_search.cpp:142-160."""
     import subprocess
@@ -411,6 +458,12 @@ def test_cpp_driver_pipeline_matches_oracle(V, oracle, tmp_path):
         outg = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt"), "-g", g], check=True, capture_output=True, text=True).stdout
         kvg = dict(l[2:].split(" = ") for l in outg.splitlines() if l.startswith("# ") and " = " in l)
         assert kvg["num_results"] == kv["num_results"] and kvg["checksum"] == kv["checksum"] and kvg["num_gpus"] == g
+    # -g 1 -P: one PROCESS per GPU over RCCL (forked before any GPU call; vlg_comm_create from a unique id passed through a file,
+    # vlg_index_broadcast, counters through vlg_comm_allreduce_sum_u64) -- with the one rank a one-GPU box can host
+    outp = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt"), "-g", "1", "-P"], check=True, capture_output=True,
+                          text=True, timeout=300).stdout
+    kvp = dict(l[2:].split(" = ") for l in outp.splitlines() if l.startswith("# ") and " = " in l)
+    assert kvp["num_results"] == kv["num_results"] and kvp["checksum"] == kv["checksum"] and kvp["gpu_mode"] == "processes"
 
 
 @pytest.mark.parametrize("name,seed,tail", [("dna_50k", 71, 16), ("zipf40", 72, 1), ("100a", 73, 4), ("dna_skew", 74, 1000), ("abracadabra", 75, 1)])
@@ -978,3 +1031,85 @@ def test_replicate_index_two_ranks_on_one_device(V, oracle):
     o = oracle.Index.from_text(text)
     for i in (0, 10, 150, 299):
         assert int(one.counts[i]) == len(o.search(queries[i]))
+
+
+def _nccl_one_rank_worker(port, text, queries, out_q):
+    """Everything bench.py does with the `nccl` backend, in a 1-rank process group on cuda:0, plus the product's own RCCL entry
+    points (vlg_comm_*, vlg_index_broadcast, vlg_comm_allgatherv)."""
+    import torch
+    import torch.distributed as dist
+    import vlg_matching_amd as V
+    from vlg_matching_amd import dist as vdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)              # bench.py: init_process_group("nccl", device_id=...)
+    assert dist.get_backend() == "nccl"
+    idx0 = V.VlgIndex.build(text)
+    # torch-side collectives of bench.py: replicate (broadcast of a uint8 tensor), scatter_object_list, all_reduce MAX / SUM, all_gather
+    idx = vdist.replicate_index(idx0, dist, dev, src=0)
+    mine = [None]
+    dist.scatter_object_list(mine, [queries], src=0)
+    assert mine[0] == queries
+    r = idx.search(mine[0])
+    t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tot = torch.tensor([r.summary["n_matches"], r.summary["located_occurrences"]], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    outl = [torch.zeros_like(t)]
+    dist.all_gather(outl, t)
+    chk = vdist.reduce_checksum(r.summary["checksum"], dist, dev)
+    dist.barrier()
+    # the product's RCCL: communicator through the C-ABI, index broadcast, counter reduction, variable all-gather
+    comm = vdist.Comm.from_torch_dist(dist)
+    n_ranks, rank = comm.info()
+    same = comm.broadcast_index(idx0, root=0)
+    sums = comm.allreduce_sum_u64([r.summary["n_matches"], (1 << 64) - 1, 7])
+    send = torch.arange(1000, dtype=torch.int32, device=dev)
+    recv = torch.zeros(1000, dtype=torch.int32, device=dev)
+    comm.allgatherv(send.data_ptr(), [1000], 4, recv.data_ptr())
+    torch.cuda.synchronize()
+    r2 = vdist.replicate_index(idx0, dist, dev, src=0, comm=comm).search(queries)
+    lib_path = comm.library()
+    comm.close()
+    out_q.put({"counts": [int(c) for c in r.counts], "tot": [int(x) for x in tot.tolist()], "max": float(t.item()), "chk": chk,
+               "gathered": float(outl[0].item()), "comm": (n_ranks, rank), "same": same is idx0, "sums": sums,
+               "recv_ok": bool((recv == send).all().item()), "counts2": [int(c) for c in r2.counts], "rccl": lib_path,
+               "summary": {k: int(v) for k, v in r.summary.items()}})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_branch_runs_with_one_rank(V, oracle):
+    """The `nccl` (= RCCL) branch of bench.py and of the product must have executed before an 8-GPU node ever sees it: a
+    world-size-1 process group on cuda:0 runs replicate_index, scatter_object_list, all_reduce, all_gather, reduce_checksum exactly
+    as bench.py calls them, and the C-ABI's own RCCL path (vlg_comm_create, vlg_index_broadcast, vlg_comm_allreduce_sum_u64,
+    vlg_comm_allgatherv); results equal the plain single-process run and the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    text = dna_text(40000, 21).tobytes()
+    rng = np.random.default_rng(23)
+    queries = random_queries(text, rng, 120, kmax=3, mmax=4)
+    one = V.VlgIndex.build(text).search(queries)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(port, text, queries, out_q))
+    p.start()
+    got = out_q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert got["counts"] == [int(c) for c in one.counts] == got["counts2"]
+    assert got["tot"] == [one.summary["n_matches"], one.summary["located_occurrences"]]
+    assert got["chk"] == one.summary["checksum"] and got["max"] == 1.5 and got["gathered"] == 1.5
+    assert got["comm"] == (1, 0) and got["same"] and got["recv_ok"]
+    assert got["sums"] == [one.summary["n_matches"], (1 << 64) - 1, 7]
+    assert "rccl" in got["rccl"].lower()
+    o = oracle.Index.from_text(text)
+    for i in (0, 17, 60, 119):
+        assert got["counts"][i] == len(o.search(queries[i]))

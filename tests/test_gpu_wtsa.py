@@ -166,3 +166,58 @@ def test_integer_alphabet_index_vs_brute_force(V, oracle):
         V.capi.check(V.lib().vlg_wtsa_search_batch(idx._h, V.index.Queries(["a"])._h, 0, V.index.Workspace()._h, None)) if False else idx.search(V.index.Queries(["a"]))
     with pytest.raises(V.VlgError):
         V.VlgIndex.build(b"abcabc").search(idx.queries(["1 2"]))
+
+
+@pytest.mark.parametrize("name", ["abracadabra", "one_byte", "100a", "dna", "zipf", "ints"])
+def test_tree_equals_reference_wt_int(V, oracle, refmod, name):
+    """The device tree against the reference's OWN wt_int<bit_vector_il<>, rank_support_il<>> (oracle/_ref, built by its constructor
+    from the same suffix array, as construct(wts, KEY_SA) does, vlg_index.hpp:386-387): number of levels, every level's bits ==
+    wt_int::tree, wt[i] for every i (wt_int.hpp:339-361), and count_less / quantile on random suffix-array ranges == what the
+    reference's expand(v) / expand(v, range) descent answers (wt_int.hpp:824-939)."""
+    import torch
+    if name == "ints":
+        rng = np.random.default_rng(8)
+        itext = rng.choice(np.array([3, 7, 7, 19, 1000, 70000, 2 ** 31 + 5], dtype=np.uint32), 1500)
+        idx = V.WtsaIndex(itext)
+        vals = np.concatenate([itext.astype(np.int64) + 1, [0]])                 # the sentinel is smaller than every symbol
+        sa = np.array(sorted(range(len(vals)), key=lambda i: vals[i:].tolist()), dtype=np.uint64)
+    else:
+        text = {"abracadabra": b"abracadabrasimsalabim", "one_byte": b"a", "100a": b"a" * 100, "dna": dna_text(3000, 4).tobytes(),
+                "zipf": skewed_text(5000, 6).tobytes()}[name]
+        idx = V.WtsaIndex(text)
+        sa = oracle.suffix_array(np.frombuffer(text + b"\0", dtype=np.uint8))
+    n = len(sa)
+    ref = oracle.RefWtInt(sa)
+    info = idx.info()
+    assert info["n"] == n and info["levels"] == ref.levels
+    want_bits = ref.level_bits()
+    for lvl in range(ref.levels):
+        assert (idx.level_bits(lvl) == want_bits[lvl]).all(), lvl
+    d_i = torch.arange(n, dtype=torch.int64, device="cuda")
+    d_o = torch.zeros_like(d_i)
+    idx.sa_device(d_i.data_ptr(), d_o.data_ptr(), n)
+    torch.cuda.synchronize()
+    got = d_o.cpu().numpy().view(np.uint64)
+    assert [int(x) for x in got] == [ref[i] for i in range(n)]
+    rng = np.random.default_rng(17)
+    m = 400
+    l = rng.integers(0, n, m).astype(np.uint64)
+    ln = np.array([rng.integers(1, n - int(a) + 1) for a in l], dtype=np.uint64)
+    x = rng.integers(0, n + 3, m).astype(np.uint64)
+    q = np.array([rng.integers(0, int(b)) for b in ln], dtype=np.uint64)
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    d_l, d_n, d_x, d_q, d_out = dev(l), dev(ln), dev(x), dev(q), torch.zeros(m, dtype=torch.int64, device="cuda")
+    idx.range_walk_device(d_l.data_ptr(), d_n.data_ptr(), d_x.data_ptr(), False, d_out.data_ptr(), m)
+    torch.cuda.synchronize()
+    assert [int(v) for v in d_out.cpu().numpy().view(np.uint64)] == [ref.count_less(a, b, c) for a, b, c in zip(l, ln, x)]
+    idx.range_walk_device(d_l.data_ptr(), d_n.data_ptr(), d_q.data_ptr(), True, d_out.data_ptr(), m)
+    torch.cuda.synchronize()
+    assert [int(v) for v in d_out.cpu().numpy().view(np.uint64)] == [ref.quantile(a, b, c) for a, b, c in zip(l, ln, q)]
+    # out-of-range requests are refused per element, not walked
+    bad = dev(np.array([n + 5], dtype=np.uint64))
+    one = dev(np.array([1], dtype=np.uint64))
+    idx.range_walk_device(bad.data_ptr(), one.data_ptr(), one.data_ptr(), False, d_out.data_ptr(), 1)
+    torch.cuda.synchronize()
+    assert int(d_out.cpu().numpy().view(np.uint64)[0]) == (1 << 64) - 1

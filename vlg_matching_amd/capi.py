@@ -82,6 +82,14 @@ SYMBOLS = [
     ("vlg_index_blob_export", _I, [_P, _P, _U64, _P]),
     ("vlg_index_attach_blob", _I, [_P, _U64, C.POINTER(_P)]),
     ("vlg_index_replicate", _I, [_P, _I, C.POINTER(_P)]),
+    ("vlg_comm_library", C.c_char_p, []),
+    ("vlg_comm_unique_id", _I, [_P]),
+    ("vlg_comm_create", _I, [_P, _I, _I, C.POINTER(_P)]),
+    ("vlg_comm_info", _I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("vlg_comm_destroy", None, [_P]),
+    ("vlg_index_broadcast", _I, [_P, _P, _I, _P, C.POINTER(_P)]),
+    ("vlg_comm_allreduce_sum_u64", _I, [_P, _P, C.c_uint32, _P]),
+    ("vlg_comm_allgatherv", _I, [_P, _P, _P, C.c_uint32, _P, _P]),
     ("vlg_bitvector_create", _I, [_P, _U64, C.POINTER(_P)]),
     ("vlg_bitvector_rank_batch", _I, [_P, _P, _P, _U64, _P]),
     ("vlg_bitvector_hbm_bytes", _U64, [_P]),
@@ -115,6 +123,8 @@ SYMBOLS = [
     ("vlg_wtsa_destroy", None, [_P]),
     ("vlg_wtsa_sa_batch", _I, [_P, _P, _P, _U64, _P]),
     ("vlg_wtsa_ranges", _I, [_P, _P, _P, _P, _P]),
+    ("vlg_wtsa_range_walk_batch", _I, [_P, _P, _P, _P, _I, _P, _U64, _P]),
+    ("vlg_wtsa_export_level", _I, [_P, C.c_uint32, _P]),
     ("vlg_queries_parse_int", _I, [C.c_char_p, _P, _U64, _P, C.POINTER(_P)]),
     ("vlg_wtsa_search_batch", _I, [_P, _P, _U64, _P, C.POINTER(_P)]),
     ("vlg_workspace_profile", _I, [_P, _I]),

@@ -380,6 +380,67 @@ extern "C" vlg_status vlg_wtsa_sa_batch(const vlg_wtsa* x, const uint64_t* d_i, 
 }
 
 namespace {
+// bits of one level as plain 64-bit words (bit i of the level = word[i >> 6] >> (i & 63)): what wt_int::tree holds for it
+__global__ void wtsa_level_words_kernel(WtsaView w, uint32_t lvl, uint64_t* __restrict__ out, uint64_t n_words)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_words; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t word = 0;
+        for (uint32_t half = 0; half < 2; ++half) {                 // 32 bits at a time: a 32-bit data word of a block, or parts of two
+            const uint64_t bit = t * 64 + 32 * half;
+            if (bit >= w.n_vals) break;
+            const uint64_t blk = bit / kBlockBits;
+            const uint32_t off = (uint32_t)(bit - blk * kBlockBits), wi = off >> 5, sh = off & 31;
+            const Block* B = w.blocks + (uint64_t)lvl * w.nb + blk;
+            uint64_t v = B->w[wi] >> sh;
+            if (sh) {                                                // the rest comes from the next data word (maybe of the next block)
+                const uint32_t nx = wi + 1 < 7 ? B->w[wi + 1] : (blk + 1 < w.nb ? B[1].w[0] : 0u);
+                v |= (uint64_t)nx << (32 - sh);
+            }
+            word |= (v & 0xFFFFFFFFull) << (32 * half);
+        }
+        const uint64_t left = w.n_vals - t * 64;
+        if (left < 64) word &= (1ull << left) - 1;
+        out[t] = word;
+    }
+}
+__global__ void __launch_bounds__(256) wtsa_range_walk_kernel(WtsaView w, const uint64_t* __restrict__ l, const uint64_t* __restrict__ len,
+                                                              const uint64_t* __restrict__ x, int quantile, uint64_t* __restrict__ out, uint64_t count)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = l[t], n = len[t];
+        const bool ok = a <= w.n_vals && n <= w.n_vals - a && (!quantile || x[t] < n);
+        out[t] = !ok ? ~0ull : (quantile ? wtsa_walk<true>(w, a, n, x[t]) : (n ? wtsa_walk<false>(w, a, n, x[t]) : 0));
+    }
+}
+}  // namespace
+
+extern "C" vlg_status vlg_wtsa_export_level(const vlg_wtsa* x, uint32_t level, uint64_t* h_words)
+{
+    if (!x || !h_words) return fail(VLG_E_INVALID, "null argument");
+    if (level >= x->levels) return fail(VLG_E_INVALID, "no such level");
+    const uint64_t nw = (x->n_vals + 63) / 64;
+    uint64_t* d = nullptr;
+    VLG_HIP_TRY(hipMalloc((void**)&d, nw * 8));
+    hipLaunchKernelGGL(wtsa_level_words_kernel, dim3(grid_for(nw, 8192)), dim3(256), 0, nullptr, wtsa_view(x), level, d, nw);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(h_words, d, nw * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    VLG_HIP_TRY(e);
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_wtsa_range_walk_batch(const vlg_wtsa* x, const uint64_t* d_l, const uint64_t* d_len, const uint64_t* d_x, int quantile,
+                                                uint64_t* d_out, uint64_t count, void* stream)
+{
+    if (!x || (count && (!d_l || !d_len || !d_x || !d_out))) return fail(VLG_E_INVALID, "null argument");
+    if (!count) return VLG_OK;
+    hipLaunchKernelGGL(wtsa_range_walk_kernel, dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream, wtsa_view(x), d_l, d_len, d_x,
+                       quantile, d_out, count);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+
+namespace {
 vlg_status wtsa_ranges_device(const vlg_wtsa* x, const vlg_queries* q, uint64_t* d_sp, uint64_t* d_len, hipStream_t st)
 {
     if (q->sym_bytes != x->sym_bytes) return fail(VLG_E_INVALID, "the query batch and the index have different alphabets");

@@ -69,8 +69,90 @@ def shard_by_affinity(l, r, qsub, world):
     return [np.sort(np.concatenate(o)) if o else np.zeros(0, dtype=np.int64) for o in out]
 
 
-def replicate_index(idx, dist, device, src=0):
-    """Broadcast the index image from rank `src` to every rank's HBM and attach to it.  `idx` is None elsewhere."""
+class Comm:
+    """An RCCL communicator made through the C-ABI (vlg_comm_*): what a host without PyTorch uses, and what
+    vlg_index_broadcast / vlg_comm_allgatherv take.  One per process, bound to the process's current device."""
+
+    def __init__(self, handle, n_ranks, rank):
+        self._h, self.n_ranks, self.rank = handle, n_ranks, rank
+
+    @classmethod
+    def create(cls, n_ranks, rank, share_id):
+        """share_id(bytes_or_None) -> bytes: hands rank 0's 128-byte id to every rank (called on every rank; rank 0 passes the id,
+        the others None) -- e.g. a torch.distributed broadcast_object_list, a pipe, a file."""
+        import ctypes as C
+        from .capi import check, lib
+        ident = None
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            check(lib().vlg_comm_unique_id(buf))
+            ident = buf.raw
+        ident = share_id(ident)
+        h = C.c_void_p()
+        check(lib().vlg_comm_create(C.create_string_buffer(ident, 128), n_ranks, rank, C.byref(h)))
+        return cls(h, n_ranks, rank)
+
+    @classmethod
+    def from_torch_dist(cls, dist):
+        """A communicator over the ranks of an initialised torch.distributed job (the id travels through its object broadcast)."""
+        def share(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        return cls.create(dist.get_world_size(), dist.get_rank(), share)
+
+    def library(self):
+        from .capi import lib
+        return (lib().vlg_comm_library() or b"").decode()
+
+    def info(self):
+        import ctypes as C
+        from .capi import check, lib
+        n, r = C.c_int(), C.c_int()
+        check(lib().vlg_comm_info(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def broadcast_index(self, idx, root=0, stream=None):
+        """vlg_index_broadcast: the root passes its VlgIndex and gets it back; the other ranks pass None and get a new one"""
+        import ctypes as C
+        from .capi import check, lib
+        from .index import VlgIndex
+        out = C.c_void_p()
+        check(lib().vlg_index_broadcast(idx._h if idx is not None else None, self._h, root, stream, C.byref(out)))
+        return idx if self.rank == root else VlgIndex(out)
+
+    def allreduce_sum_u64(self, values, stream=None):
+        """sum over the ranks modulo 2^64 (num_results, checksum, located occurrences) -> list of ints"""
+        from .capi import check, lib
+        v = np.array([int(x) % (1 << 64) for x in values], dtype=np.uint64)
+        check(lib().vlg_comm_allreduce_sum_u64(self._h, v.ctypes.data, len(v), stream))
+        return [int(x) for x in v]
+
+    def allgatherv(self, d_send_ptr, counts, elem_bytes, d_recv_ptr, stream=None):
+        from .capi import check, lib
+        c = np.ascontiguousarray(counts, dtype=np.uint64)
+        assert len(c) == self.n_ranks
+        check(lib().vlg_comm_allgatherv(self._h, d_send_ptr, c.ctypes.data, int(elem_bytes), d_recv_ptr, stream))
+
+    def close(self):
+        if self._h:
+            from .capi import lib
+            lib().vlg_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def replicate_index(idx, dist, device, src=0, comm=None):
+    """Broadcast the index image from rank `src` to every rank's HBM and attach to it.  `idx` is None elsewhere.
+    With a Comm (RCCL through the C-ABI) this is vlg_index_broadcast: one ncclBroadcast straight out of / into the index's own
+    allocation; without one the image goes through a torch.distributed broadcast of a uint8 tensor (gloo rehearsals on CPU hosts)."""
+    if comm is not None:
+        return comm.broadcast_index(idx, root=src)
     import torch
     from .index import VlgIndex
     rank = dist.get_rank()

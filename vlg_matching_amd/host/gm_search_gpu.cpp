@@ -1,13 +1,17 @@
 // gm_search equivalent for the GPU index (benchmark/gapped-matching/src/gm_search.cpp): same command line (-c, -p),
 // same machine-readable "# key = value" lines on stdout.  Queries are searched as ONE batch; the per-query "TIMING"
 // and quartile lines therefore report the batch time divided by the number of patterns (-1 runs query by query, with real
-// per-query times).  -g N shards the pattern file over N GPUs of the node (index replicated, no exchange between the slices).
+// per-query times).  -g N shards the pattern file over N GPUs of the node (index replicated, no exchange between the slices):
+// by default one process drives all of them (a host thread per device, replicas by peer copies); -g N -P starts ONE PROCESS PER
+// GPU instead -- rank 0 loads the index, its image goes to the others by one RCCL broadcast (vlg_index_broadcast), every rank
+// searches its slice and the counters are all-reduced.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <sys/wait.h>
 #include <unistd.h>
 #include "index_fm_gpu.hpp"
 
@@ -27,20 +31,109 @@ static std::vector<gapped_pattern> parse_pattern_file(const std::string& file)
     return pats;
 }
 
+static void print_summary(std::vector<long long> timings, size_t num_results, size_t checksum, long long total_us, long long load_us, size_t n_pat, int n_gpus,
+                          const char* mode);
+
+// One rank of `-g N -P`: nothing here has touched a GPU before the fork in main().  The communicator's id travels through a file
+// that rank 0 writes (atomically: write + rename) and the others wait for.
+static int run_rank(const std::string& col_dir, const std::string& pat_file, int rank, int n_ranks, const std::string& id_file)
+{
+    try {
+        int ndev = 0;
+        check(vlg_device_count(&ndev));
+        check(vlg_set_device(rank % ndev));
+        vlg_comm_id id;
+        if (rank == 0) {
+            check(vlg_comm_unique_id(&id));
+            const std::string tmp = id_file + ".tmp";
+            { std::ofstream o(tmp, std::ios::binary); o.write(id.bytes, sizeof id.bytes); if (!o) throw std::runtime_error("cannot write " + tmp); }
+            if (rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("cannot publish " + id_file);
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 12000 && !got; ++tries) {                 // two minutes
+                std::ifstream i(id_file, std::ios::binary);
+                if (i && i.read(id.bytes, sizeof id.bytes)) got = true; else usleep(10000);
+            }
+            if (!got) throw std::runtime_error("rank 0 never published the communicator id");
+        }
+        void* comm = nullptr;
+        check(vlg_comm_create(&id, n_ranks, rank, &comm));
+        collection col(col_dir);
+        index_fm_gpu idx;
+        auto t_load = high_resolution_clock::now();
+        if (rank == 0) {                                             // one load (or build), then one broadcast of the HBM image
+            std::ifstream ifs(col.path + "/index/index-" + idx.name() + ".vlg", std::ios::binary);
+            if (ifs.is_open()) idx.load(ifs);
+            else { index_fm_gpu built(col); idx.swap(built); }
+        }
+        idx.broadcast(comm, 0);
+        auto load_us = duration_cast<microseconds>(high_resolution_clock::now() - t_load).count();
+        std::vector<gapped_pattern> pats = parse_pattern_file(pat_file);
+        const index_fm_gpu& cidx = idx;
+        uint64_t sums[3] = {0, 0, 0};                                // num_results, checksum (mod 2^64), slowest... time is max, below
+        auto t0 = high_resolution_clock::now();
+        const std::vector<uint64_t> cut = cidx.work_cuts(pats, n_ranks);              // every rank computes the same cuts from its replica
+        auto res = cidx.search_slice(pats, cut[rank], cut[rank + 1]);
+        for (auto& r : res) for (auto pos : r.positions) { sums[1] += pos; sums[0]++; }
+        long long my_us = duration_cast<microseconds>(high_resolution_clock::now() - t0).count();
+        check(vlg_comm_allreduce_sum_u64(comm, sums, 2, nullptr));
+        // the batch time is the slowest rank's: ranks publish theirs in a vector that is summed (one non-zero entry each)
+        std::vector<uint64_t> times(n_ranks, 0);
+        times[rank] = (uint64_t)my_us;
+        check(vlg_comm_allreduce_sum_u64(comm, times.data(), (uint32_t)n_ranks, nullptr));
+        const long long total_us = (long long)*std::max_element(times.begin(), times.end());
+        if (rank == 0) {
+            std::vector<long long> timings(pats.size(), pats.empty() ? 0 : total_us / (long long)pats.size());
+            print_summary(timings, sums[0], sums[1], total_us, load_us, pats.size(), n_ranks, "processes");
+            remove(id_file.c_str());
+        }
+        vlg_comm_destroy(comm);
+        return 0;
+    } catch (const std::exception& e) {
+        std::cerr << "rank " << rank << ": error: " << e.what() << std::endl;
+        return EXIT_FAILURE;
+    }
+}
+
 int main(int argc, char* const argv[])
 {
     std::string col_dir, pat_file;
-    bool one_by_one = false;
+    bool one_by_one = false, per_process = false;
     int op, n_gpus = 1;
-    while ((op = getopt(argc, argv, "c:p:1g:")) != -1) {
+    while ((op = getopt(argc, argv, "c:p:1g:P")) != -1) {
         if (op == 'c') col_dir = optarg;
         else if (op == 'p') pat_file = optarg;
         else if (op == '1') one_by_one = true;
         else if (op == 'g') n_gpus = atoi(optarg);
+        else if (op == 'P') per_process = true;
     }
     if (col_dir.empty() || pat_file.empty() || n_gpus < 1) {
-        fprintf(stdout, "%s -c <collection directory> -p <pattern file> [-1] [-g <GPUs>]\n", argv[0]);
+        fprintf(stdout, "%s -c <collection directory> -p <pattern file> [-1] [-g <GPUs> [-P]]\n", argv[0]);
         return EXIT_FAILURE;
+    }
+    if (per_process) {
+        // fork BEFORE anything initialises the GPU (no HIP call has been made: the C-ABI is only touched inside the children)
+        const std::string id_file = "/tmp/vlg_comm_id_" + std::to_string((long long)getpid());
+        remove(id_file.c_str());
+        std::vector<pid_t> kids;
+        for (int r = 0; r < n_gpus; ++r) {
+            const pid_t pid = fork();
+            if (pid < 0) { perror("fork"); return EXIT_FAILURE; }
+            if (pid == 0) _exit(run_rank(col_dir, pat_file, r, n_gpus, id_file));
+            kids.push_back(pid);
+        }
+        int rc = 0;
+        size_t left = kids.size();
+        while (left) {                                               // any rank that fails ends the others (they would wait in a collective)
+            int status = 0;
+            const pid_t done = wait(&status);
+            if (done < 0) break;
+            --left;
+            const int code = WIFEXITED(status) ? WEXITSTATUS(status) : EXIT_FAILURE;
+            if (code && !rc) { rc = code; for (pid_t k : kids) if (k != done) kill(k, SIGTERM); }
+        }
+        remove(id_file.c_str());
+        return rc;
     }
     try {
         collection col(col_dir);
@@ -69,26 +162,33 @@ int main(int argc, char* const argv[])
         }
         long long total_us = duration_cast<microseconds>(high_resolution_clock::now() - t0).count();
         if (!one_by_one) timings.assign(pats.size(), pats.empty() ? 0 : total_us / (long long)pats.size());
-        for (auto t : timings) std::cout << "TIMING = " << t << std::endl;
-        std::sort(timings.begin(), timings.end());
-        auto q = [&](double f) { return timings.empty() ? 0LL : timings[std::min(timings.size() - 1, (size_t)(f * timings.size()))]; };
-        std::cout << "# info =" << std::endl;
-        std::cout << "# num_results = " << num_results << std::endl;
-        std::cout << "# checksum = " << checksum << std::endl;
-        std::cout << "# total_time_mus = " << total_us << std::endl;
-        std::cout << "# min_time_mus = " << q(0.0) << std::endl;
-        std::cout << "# qrt_1st_time_mus = " << q(0.25) << std::endl;
-        std::cout << "# mean_time_mus = " << (timings.empty() ? 0 : total_us / (long long)timings.size()) << std::endl;
-        std::cout << "# median_time_mus = " << q(0.5) << std::endl;
-        std::cout << "# qrt_3rd_time_mus = " << q(0.75) << std::endl;
-        std::cout << "# max_time_mus = " << q(1.0) << std::endl;
-        for (const char* k : {"total", "min", "qrt_1st", "mean", "median", "qrt_3rd", "max"}) std::cout << "# prep_" << k << "_time_mus = 0" << std::endl;
-        std::cout << "# load_time_mus = " << load_us << std::endl;
-        std::cout << "# num_patterns = " << pats.size() << std::endl;
-        std::cout << "# num_gpus = " << n_gpus << std::endl;
+        print_summary(timings, num_results, checksum, total_us, load_us, pats.size(), n_gpus, n_gpus > 1 ? "threads" : "single");
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << std::endl;
         return EXIT_FAILURE;
     }
     return 0;
+}
+
+static void print_summary(std::vector<long long> timings, size_t num_results, size_t checksum, long long total_us, long long load_us, size_t n_pat, int n_gpus,
+                          const char* mode)
+{
+    for (auto t : timings) std::cout << "TIMING = " << t << std::endl;
+    std::sort(timings.begin(), timings.end());
+    auto q = [&](double f) { return timings.empty() ? 0LL : timings[std::min(timings.size() - 1, (size_t)(f * timings.size()))]; };
+    std::cout << "# info =" << std::endl;
+    std::cout << "# num_results = " << num_results << std::endl;
+    std::cout << "# checksum = " << checksum << std::endl;
+    std::cout << "# total_time_mus = " << total_us << std::endl;
+    std::cout << "# min_time_mus = " << q(0.0) << std::endl;
+    std::cout << "# qrt_1st_time_mus = " << q(0.25) << std::endl;
+    std::cout << "# mean_time_mus = " << (timings.empty() ? 0 : total_us / (long long)timings.size()) << std::endl;
+    std::cout << "# median_time_mus = " << q(0.5) << std::endl;
+    std::cout << "# qrt_3rd_time_mus = " << q(0.75) << std::endl;
+    std::cout << "# max_time_mus = " << q(1.0) << std::endl;
+    for (const char* k : {"total", "min", "qrt_1st", "mean", "median", "qrt_3rd", "max"}) std::cout << "# prep_" << k << "_time_mus = 0" << std::endl;
+    std::cout << "# load_time_mus = " << load_us << std::endl;
+    std::cout << "# num_patterns = " << n_pat << std::endl;
+    std::cout << "# num_gpus = " << n_gpus << std::endl;
+    std::cout << "# gpu_mode = " << mode << std::endl;
 }

@@ -3,6 +3,8 @@
 // the C-ABI, plus the batched entry a GPU needs (search_batch).  Value semantics like the reference: the object owns
 // its HBM-resident index.
 #pragma once
+#include <algorithm>
+#include <cstring>
 #include <iostream>
 #include <memory>
 #include <thread>
@@ -163,6 +165,62 @@ class index_fm_gpu
         return out;
     }
 
+    // Contiguous slices of equal estimated work for n shards: the sum of the SA-interval sizes of a query's sub-patterns (0 when one
+    // of them does not occur: such a query locates nothing), from one backward-search pass on this index -- what SURVEY.md 8(e)
+    // shards by.  Every rank of a multi-process run computes the same cuts from its own replica.  -> cut[n + 1]
+    std::vector<uint64_t> work_cuts(const std::vector<gapped_pattern>& pats, int n, int dialect = VLG_DIALECT_BENCHMARK) const
+    {
+        std::vector<uint64_t> cut(n + 1, pats.size());
+        cut[0] = 0;
+        if (n <= 1 || pats.empty()) return cut;
+        parsed_batch pb;
+        parse(pats, 0, pats.size(), dialect, pb);
+        std::vector<uint32_t> k(pats.size() + 1);
+        std::vector<uint64_t> occ(vlg_queries_subpatterns(pb.q) + 1);
+        check(vlg_queries_k(pb.q, k.data()));
+        check(vlg_queries_occurrences(m_idx, pb.q, occ.data(), nullptr));
+        std::vector<double> cum(pats.size() + 1, 0.0);
+        size_t s = 0;
+        for (size_t i = 0; i < pats.size(); ++i) {
+            double w = 0;
+            bool dead = false;
+            for (uint32_t j = 0; j < k[i]; ++j) { w += (double)occ[s + j]; dead |= occ[s + j] == 0; }
+            s += k[i];
+            cum[i + 1] = cum[i] + (dead ? 0.0 : w) + 1.0;
+        }
+        for (int d = 1; d < n; ++d) {                             // the nearer of the two cuts around the target
+            const double target = cum.back() * d / n;
+            size_t i = (size_t)(std::lower_bound(cum.begin() + 1, cum.end(), target) - (cum.begin() + 1));
+            if (i < pats.size() && cum[i + 1] - target <= target - cum[i]) ++i;
+            cut[d] = std::max<uint64_t>(cut[d - 1], std::min<uint64_t>(i, pats.size()));
+        }
+        return cut;
+    }
+
+    // pats[b, e) on the current device (one rank's slice of a sharded batch); the other entries of the result stay empty
+    std::vector<gapped_search_result> search_slice(const std::vector<gapped_pattern>& pats, size_t b, size_t e, int dialect = VLG_DIALECT_BENCHMARK,
+                                                   vlg_result_summary* summary = nullptr) const
+    {
+        ensure_ws();
+        std::vector<gapped_search_result> out(pats.size());
+        if (summary) memset(summary, 0, sizeof *summary);
+        if (b < e) search_range(m_idx, m_ws, pats, b, e, dialect, out, summary);
+        return out;
+    }
+
+    // One process per GPU (RCCL over xGMI): rank `root` holds the index, every other rank of the communicator
+    // (vlg_comm_create) receives its image by one broadcast into its own HBM -- `idx.load` on every rank replaced by one load + one
+    // collective.  Collective call.
+    void broadcast(void* nccl_comm, int root)
+    {
+        int n = 0, rank = 0;
+        check(vlg_comm_info(nccl_comm, &n, &rank));
+        if (rank == root) { check(vlg_index_broadcast(m_idx, nccl_comm, root, nullptr, nullptr)); return; }
+        drop_replicas();
+        if (m_idx) { vlg_index_destroy(m_idx); m_idx = nullptr; }
+        check(vlg_index_broadcast(nullptr, nccl_comm, root, nullptr, &m_idx));
+    }
+
     // The query loop of gm_search.cpp:91-121 sharded over the GPUs of the node: the index is replicated once
     // (peer copies over xGMI), the batch is cut into contiguous slices of equal estimated work -- the sum of the SA-interval sizes
     // of a query's sub-patterns, from one backward-search pass -- and one host thread per device searches its slice.  Queries are
@@ -181,32 +239,7 @@ class index_fm_gpu
             check(vlg_index_replicate(m_idx, r.device, &r.idx));
             m_replicas.push_back(r);
         }
-        // weights: one backward-search pass over the whole batch on device 0
-        std::vector<uint64_t> cut(n_devices + 1, pats.size());
-        cut[0] = 0;
-        {
-            parsed_batch pb;
-            parse(pats, 0, pats.size(), dialect, pb);
-            std::vector<uint32_t> k(pats.size() + 1);
-            std::vector<uint64_t> occ(vlg_queries_subpatterns(pb.q) + 1);
-            check(vlg_queries_k(pb.q, k.data()));
-            check(vlg_queries_occurrences(m_idx, pb.q, occ.data(), nullptr));
-            std::vector<double> cum(pats.size() + 1, 0.0);
-            size_t s = 0;
-            for (size_t i = 0; i < pats.size(); ++i) {
-                double w = 0;
-                bool dead = false;
-                for (uint32_t j = 0; j < k[i]; ++j) { w += (double)occ[s + j]; dead |= occ[s + j] == 0; }
-                s += k[i];
-                cum[i + 1] = cum[i] + (dead ? 0.0 : w) + 1.0;
-            }
-            for (int d = 1; d < n_devices; ++d) {                 // the nearer of the two cuts around the target
-                const double target = cum.back() * d / n_devices;
-                size_t i = (size_t)(std::lower_bound(cum.begin() + 1, cum.end(), target) - (cum.begin() + 1));
-                if (i < pats.size() && cum[i + 1] - target <= target - cum[i]) ++i;
-                cut[d] = std::max<uint64_t>(cut[d - 1], std::min<uint64_t>(i, pats.size()));
-            }
-        }
+        const std::vector<uint64_t> cut = work_cuts(pats, n_devices, dialect);
         std::vector<gapped_search_result> out(pats.size());
         std::vector<std::string> errors(n_devices);
         if (summaries) summaries->assign(n_devices, vlg_result_summary());

@@ -401,6 +401,17 @@ class WtsaIndex:
     def sa_device(self, d_idx_ptr, d_out_ptr, count, stream=None):
         check(lib().vlg_wtsa_sa_batch(self._h, d_idx_ptr, d_out_ptr, count, stream))
 
+    def range_walk_device(self, d_l_ptr, d_len_ptr, d_x_ptr, quantile, d_out_ptr, count, stream=None):
+        """count_less (quantile False) / quantile (True) on suffix-array ranges, device pointers"""
+        check(lib().vlg_wtsa_range_walk_batch(self._h, d_l_ptr, d_len_ptr, d_x_ptr, 1 if quantile else 0, d_out_ptr, count, stream))
+
+    def level_bits(self, level):
+        """bits of one level of the tree -> uint8 array of n zeros / ones (wt_int::tree[level * n : (level + 1) * n])"""
+        n = self.info()["n"]
+        w = np.zeros((n + 63) // 64, dtype=np.uint64)
+        check(lib().vlg_wtsa_export_level(self._h, int(level), w.ctypes.data))
+        return np.unpackbits(w.view(np.uint8), bitorder="little")[:n]
+
     def ranges(self, queries):
         """forward_search of every sub-pattern -> (sp[], ep[]) suffix-array ranges (sp = ep + 1: no occurrence)"""
         q = self.queries(queries)
