@@ -88,7 +88,8 @@ typedef struct {
     uint64_t n_blocks;            /* 32-byte super-blocks in HBM                               */
     uint64_t n_samples;
     uint64_t hbm_bytes;           /* total device bytes of the index                           */
-    uint32_t pos_bytes;           /* 4 (n <= 2^32) or 8: width of positions inside kernels      */
+    uint32_t pos_bytes;           /* 4 (n <= 2^32) or 8: width of SA samples / SA indices; text positions inside the
+                                     kernels are 32-bit up to n = 2^32 + 1 whatever this says     */
     uint32_t bv_kind;             /* VLG_BV_PLAIN or VLG_BV_RRR63                               */
 } vlg_index_info;
 

@@ -792,12 +792,15 @@ def test_save_sdsl_is_loadable_by_the_reference(V, oracle, refmod, tmp_path, nam
         assert (x == y).all()
 
 
-def test_64bit_position_kernels(torch_cuda, V, oracle, monkeypatch):
+@pytest.mark.parametrize("force", ["1", "2"])
+def test_64bit_position_kernels(torch_cuda, V, oracle, monkeypatch, force):
     """Texts beyond 4 GiB run on the pos_t = uint64_t instantiations (locate, expand, sort, join, gather, samples).
-    VLG_FORCE_POS64=1 selects them on a small text so that they are exercised bit for bit against the oracle."""
+    VLG_FORCE_POS64=1 selects them on a small text so that they are exercised bit for bit against the oracle; =2 selects the mix
+    BASELINE config 4 (n = 2^32 + 1) runs on: 64-bit samples and 33-bit SA indices inside locate, 32-bit text positions -- and
+    with them the per-list sort, fences, filter and join of the 32-bit path -- behind it."""
     torch = torch_cuda
     from vlg_matching_amd.index import Workspace
-    monkeypatch.setenv("VLG_FORCE_POS64", "1")
+    monkeypatch.setenv("VLG_FORCE_POS64", force)
     text = TEXTS["zipf40"]()
     o = oracle.Index.from_text(text)
     idx = V.VlgIndex.build(text)

@@ -174,10 +174,11 @@ vlg_status alloc_blob(vlg_index* idx, uint64_t n, uint32_t dens, hipStream_t str
     h.n_nodes = t.n_nodes;
     h.max_code_len = t.max_code_len;
     h.n_samples = (n + dens - 1) / dens;
-    // positions inside kernels are 32-bit up to n = 2^32; VLG_FORCE_POS64=1 selects the 64-bit instantiations on any text
-    // (they are what a text beyond 4 GiB runs on; tests use the switch to exercise them on small inputs)
+    // SA samples and SA indices are 32-bit up to n = 2^32 and 64-bit words beyond; VLG_FORCE_POS64=1 or 2 selects the wide form on any
+    // text (what a text of 4 GiB and more runs on; tests use the switch to exercise it on small inputs: 1 = 64-bit positions
+    // everywhere, 2 = wide SA indices with 32-bit text positions, the mix BASELINE config 4 runs on -- see vlg_search_batch)
     const char* f64 = getenv("VLG_FORCE_POS64");
-    h.sample_bytes = (n <= 0x100000000ull && !(f64 && f64[0] == '1')) ? 4 : 8;
+    h.sample_bytes = (n <= 0x100000000ull && !(f64 && (f64[0] == '1' || f64[0] == '2'))) ? 4 : 8;
     uint64_t off = align_up(sizeof(BlobHeader), 256);
     h.off_blocks = off;  off = align_up(off + h.n_blocks * sizeof(Block), 256);
     h.off_nodes = off;   off = align_up(off + (uint64_t)kMaxNodes * sizeof(DNode), 256);

@@ -441,14 +441,19 @@ __device__ __forceinline__ void block_add(unsigned long long (&v)[N], unsigned l
 // kTail: the same walk for the stragglers of the sorted sweep (K3s below): the elements are val[] = slot << kShift | SA index, they
 // have walked `step` steps already, positions go to out[slot] -- or to rec[slot0 + slot] when trails are shared, and then a walk
 // also ends on the first index another element stood on during the sweep (sweep_step_kernel explains the records).
-template <typename pos_t, class BV, bool kTail = false>
+// kWide: SA indices need 33 bits and the samples are 64-bit words (n > 2^32, or VLG_FORCE_POS64); the positions written may still be
+// 32-bit (pos_t) when the text has at most 2^32 characters -- only the tail mode can split the two, the in-place mode keeps the SA
+// index in io[] itself.
+template <typename pos_t, class BV, bool kTail = false, bool kWide = (sizeof(pos_t) == 8)>
 __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __restrict__ io, uint64_t total, uint32_t per_wave,
                                                      unsigned long long* __restrict__ stats /* [2]: lf steps, levels */,
                                                      const uint64_t* __restrict__ val = nullptr, uint32_t step = 0,
                                                      uint64_t* __restrict__ rec = nullptr, uint64_t slot0 = 0,
                                                      const uint64_t* __restrict__ trail = nullptr, uint64_t gen = 0)
 {
-    constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
+    static_assert(kTail || kWide == (sizeof(pos_t) == 8), "in place, io[] holds the SA index: its width is the index width");
+    using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
+    constexpr uint32_t kShift = kWide ? 33 : 32;
     constexpr uint64_t kPosMask = (1ull << kShift) - 1;
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
@@ -460,7 +465,7 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
     const bool pow2 = (dens & (dens - 1)) == 0;
     const uint32_t dmask = dens - 1;
     const uint32_t dshift = 31 - __clz(dens);
-    const pos_t* samples = reinterpret_cast<const pos_t*>(iv.samples);
+    const sample_t* samples = reinterpret_cast<const sample_t*>(iv.samples);
 
     uint64_t t = 0;          // slot being worked on
     uint64_t i = 0;          // SA index at the root, node-relative index below it
@@ -609,7 +614,7 @@ __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t
 // element that arrives there later has the same future, so it stops and records (that element, steps apart) in rec -- or,
 // when that element has a record already, the record one hop further.  rec[slot]: a position (high bits 0), or
 // delta << kShift | slot of the element it follows; ~0 while the element is still walking.  slot0 = first slot of the sweep.
-template <class BV, typename pos_t, bool kTrail>
+template <class BV, typename pos_t, bool kTrail, bool kWide>
 __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count,
                                                          uint32_t step, pos_t* __restrict__ out,
                                                          unsigned long long* __restrict__ stats /* lf, levels */,
@@ -622,8 +627,9 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
     const bool pow2 = (dens & (dens - 1)) == 0;
     const uint32_t dmask = dens - 1;
     const uint32_t dshift = 31 - __clz(dens);
-    const pos_t* samples = reinterpret_cast<const pos_t*>(iv.samples);
-    constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
+    using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
+    const sample_t* samples = reinterpret_cast<const sample_t*>(iv.samples);
+    constexpr uint32_t kShift = kWide ? 33 : 32;
     constexpr uint64_t kPosMask = (1ull << kShift) - 1;
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
@@ -688,11 +694,11 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
 // one's own thread is doing; chains collapse as the elements ahead finish (measured on C3: 2 + 2 hops per round over four
 // rounds 24.5 ms, to the end in one round + one checking round 18.6 ms).
 constexpr uint32_t kResolveHops = 64;
-template <typename pos_t>
+template <typename pos_t, bool kWide>
 __global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict__ rec, uint64_t count, pos_t* __restrict__ out,
                                                             unsigned long long* __restrict__ n_open, uint32_t round)
 {
-    constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
+    constexpr uint32_t kShift = kWide ? 33 : 32;
     constexpr uint64_t kLow = (1ull << kShift) - 1;
     uint32_t open = 0;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
@@ -827,7 +833,7 @@ size_t sweep_temp_bytes(uint64_t total, uint32_t sigma, hipStream_t stream)
 // d_l / d_out_off: SA interval starts and output offsets of the n_pat lists; d_out receives SA values (unsorted, SA order).
 // Scratch (caller-provided): val_a, val_b (u64 each), key_a, key_b (u16 each) for min(total, sweep_batch_max<pos_t>()) elements,
 // temp (sweep_temp_bytes), counter (8 B, zeroed here).
-template <typename pos_t>
+template <typename pos_t, bool kWide>
 vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
                                pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
@@ -836,10 +842,12 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
                                const std::function<vlg_status()>* while_first_step /* host work to do while the first step runs, or null */)
 {
     bool hook_due = while_first_step != nullptr;
-    constexpr uint32_t kShift = sizeof(pos_t) == 4 ? 32 : 33;
+    constexpr uint32_t kShift = kWide ? 33 : 32;
     if (iv.n > (1ull << kShift)) return fail(VLG_E_UNSUPPORTED, "sorted sweep: text too long for the packed position");
+    if (iv.sample_bytes != (kWide ? 8u : 4u)) return fail(VLG_E_INTERNAL, "sorted sweep: sample width does not match the instantiation");
+    if (sizeof(pos_t) == 4 && iv.n > (1ull << 32) + 1) return fail(VLG_E_INTERNAL, "sorted sweep: positions do not fit 32 bits");
     const unsigned bits = bit_width64(iv.sigma);            // keys 0..sigma (sigma = finished, sorts last)
-    const uint64_t batch_max = sweep_batch_max<pos_t>();
+    const uint64_t batch_max = sweep_batch_max<kWide>();
     if (trail) VLG_HIP_TRY(hipMemsetAsync(rec, 0xFF, total * 8, stream));
     for (uint64_t t0 = 0; t0 < total; t0 += batch_max) {
         const uint64_t t1 = std::min(total, t0 + batch_max);
@@ -864,14 +872,14 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             if (timer) timer->begin(0);
             const dim3 grid(grid_for(alive, 4096));
             if (iv.bv_kind == kBvRrr63) {
-                if (trail) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t, true>), grid, dim3(256), 0, stream, iv, val_a, key_a,
+                if (trail) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t, true, kWide>), grid, dim3(256), 0, stream, iv, val_a, key_a,
                                               alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t, false>), grid, dim3(256), 0, stream, iv, val_a, key_a,
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t, false, kWide>), grid, dim3(256), 0, stream, iv, val_a, key_a,
                                         alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
             } else {
-                if (trail) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t, true>), grid, dim3(256), 0, stream, iv, val_a, key_a,
+                if (trail) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t, true, kWide>), grid, dim3(256), 0, stream, iv, val_a, key_a,
                                               alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t, false>), grid, dim3(256), 0, stream, iv, val_a, key_a,
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t, false, kWide>), grid, dim3(256), 0, stream, iv, val_a, key_a,
                                         alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
             }
             if (timer) timer->end(0);
@@ -903,10 +911,10 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             const dim3 grid((uint32_t)((waves + 3) / 4));
             if (timer) timer->begin(0);
             if (iv.bv_kind == kBvRrr63)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, RrrBV, true>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, RrrBV, true, kWide>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave,
                                    d_stats, val_a, step, trail ? rec : nullptr, t0, trail, gen);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, PlainBV, true>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, PlainBV, true, kWide>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave,
                                    d_stats, val_a, step, trail ? rec : nullptr, t0, trail, gen);
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
@@ -918,7 +926,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
         for (uint32_t round = 0;; ++round) {
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
             if (timer) timer->begin(2, round == 0 ? total * (8ull + sizeof(pos_t)) : 0);     // every record read, every position written
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_kernel<pos_t>), dim3(grid_for(total, 16384)), dim3(256), 0, stream, rec, total, d_out,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_kernel<pos_t, kWide>), dim3(grid_for(total, 16384)), dim3(256), 0, stream, rec, total, d_out,
                                d_counter, round);
             if (timer) timer->end(2);
             VLG_HIP_TRY(hipGetLastError());
@@ -931,12 +939,25 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     }
     return VLG_OK;
 }
-template vlg_status launch_locate_sweep<uint32_t>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint32_t*, uint64_t*,
-                                                  uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, uint64_t,
-                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*, uint32_t*, const std::function<vlg_status()>*);
-template vlg_status launch_locate_sweep<uint64_t>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint64_t*, uint64_t*,
-                                                  uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, uint64_t,
-                                                  hipStream_t, LaunchTimer*, uint64_t*, uint64_t*, uint32_t*, const std::function<vlg_status()>*);
+#define VLG_SWEEP_INST(P, W)                                                                                                          \
+    template vlg_status launch_locate_sweep<P, W>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, P*, uint64_t*, \
+                                                  uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, \
+                                                  uint64_t, hipStream_t, LaunchTimer*, uint64_t*, uint64_t*, uint32_t*,                   \
+                                                  const std::function<vlg_status()>*);
+VLG_SWEEP_INST(uint32_t, false)
+VLG_SWEEP_INST(uint32_t, true)        // n = 2^32 + 1 (BASELINE config 4): 33-bit SA indices, 32-bit text positions
+VLG_SWEEP_INST(uint64_t, true)
+#undef VLG_SWEEP_INST
+
+template <typename T>
+vlg_status launch_narrow(const uint64_t* d_in, T* d_out, uint64_t count, hipStream_t stream)
+{
+    if (!count) return VLG_OK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(narrow_kernel<T>), dim3(grid_for(count)), dim3(256), 0, stream, d_in, d_out, count);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+template vlg_status launch_narrow<uint32_t>(const uint64_t*, uint32_t*, uint64_t, hipStream_t);
 
 }  // namespace vlg
 

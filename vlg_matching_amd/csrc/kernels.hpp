@@ -21,13 +21,16 @@ struct LaunchTimer {
 };
 
 size_t sweep_temp_bytes(uint64_t total, uint32_t sigma, hipStream_t stream);
-// occurrences one sweep can cover: slots share a 64-bit word with the position (32+32 bits, or 31+33 for n > 2^32)
-template <typename pos_t> constexpr uint64_t sweep_batch_max() { return sizeof(pos_t) == 4 ? 0xFFFFFF00ull : (1ull << 31); }
-template <typename pos_t>
+// occurrences one sweep can cover: slots share a 64-bit word with the SA index (32 + 32 bits, or 31 + 33 when SA indices are wide)
+template <bool kWide> constexpr uint64_t sweep_batch_max() { return kWide ? (1ull << 31) : 0xFFFFFF00ull; }
+// kWide: the index keeps 64-bit samples and SA indices may need 33 bits (n > 2^32, or VLG_FORCE_POS64); pos_t is the width of the
+// text positions written -- uint32_t whenever the text has at most 2^32 characters, whatever the width of the SA indices.
+template <typename pos_t, bool kWide>
 vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
                                pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
                                hipStream_t stream, LaunchTimer* timer, uint64_t* trail, uint64_t* rec, uint32_t* trail_gen,
                                const std::function<vlg_status()>* while_first_step = nullptr);
+template <typename T> vlg_status launch_narrow(const uint64_t* d_in, T* d_out, uint64_t count, hipStream_t stream);
 
 }  // namespace vlg

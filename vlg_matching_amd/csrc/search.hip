@@ -470,7 +470,8 @@ template <typename pos_t>
 vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* res, const std::vector<uint32_t>& dlist /* distinct ids */,
                           const Plan& pl, Arena& A, pos_t*& P_out, std::vector<uint32_t>& poff /* per distinct id -> offset (size dl) */,
                           uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats, pos_t*& Pc_out, uint64_t& pc_cap,
-                          uint64_t* trail /* n words at the head of the arena when trails are shared, else null */)
+                          uint64_t* trail /* n words at the head of the arena when trails are shared, else null */,
+                          bool wide /* SA indices need 33 bits / 64-bit samples (always so for 64-bit positions) */)
 {
     hipStream_t st = ws->stream;
     PhaseTrace bt(st);
@@ -490,7 +491,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     pc_cap = 0;
     ws->fences = nullptr;
     if (!acc) return VLG_OK;
-    const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (sizeof(pos_t) == 4 ? 32 : 33));
+    const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (wide ? 33 : 32));
     pos_t* Pa = A.take<pos_t>(acc);
     // scratch of the sweep (20 B per element); the sorted lists Pb reuse it once locate is done
     uint8_t* scratch = A.take<uint8_t>(acc * kPhysScratchPerElem<pos_t>());
@@ -521,16 +522,36 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         return VLG_OK;
     };
     if (use_sweep) {
-        const uint64_t cap = std::min<uint64_t>(acc, sweep_batch_max<pos_t>());
+        const uint64_t cap = std::min<uint64_t>(acc, wide ? sweep_batch_max<true>() : sweep_batch_max<false>());
         uint64_t* val_a = reinterpret_cast<uint64_t*>(scratch);
         uint64_t* val_b = val_a + cap;
         uint16_t* key_a = reinterpret_cast<uint16_t*>(val_b + cap);
         uint16_t* key_b = key_a + cap;
         SweepTimer timer(ws);
         bt.mark("  physical: tables + sort plan");
-        if (vlg_status s = launch_locate_sweep<pos_t>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b,
-                                               d_tmp, sort_tmp, d_counter, d_stats, ws->sweep_tail, st, &timer, trail, rec, &ws->trail_gen, &plan_sort)) return s;
+        vlg_status s = VLG_OK;
+        if (wide)
+            s = launch_locate_sweep<pos_t, true>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b, d_tmp, sort_tmp, d_counter, d_stats,
+                                                 ws->sweep_tail, st, &timer, trail, rec, &ws->trail_gen, &plan_sort);
+        else if constexpr (sizeof(pos_t) == 4)                      // (a 64-bit position type always comes with wide indices)
+            s = launch_locate_sweep<uint32_t, false>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b, d_tmp, sort_tmp, d_counter, d_stats,
+                                                     ws->sweep_tail, st, &timer, trail, rec, &ws->trail_gen, &plan_sort);
+        else s = fail(VLG_E_INTERNAL, "64-bit positions with 32-bit SA indices");
+        if (s) return s;
         bt.mark("  physical: sweep");
+    } else if (wide && sizeof(pos_t) == 4) {
+        // few occurrences, 33-bit SA indices, 32-bit positions: the in-place kernel walks in 64-bit words of the scratch, then narrows
+        if (vlg_status s = plan_sort()) return s;
+        uint64_t* io64 = reinterpret_cast<uint64_t*>(scratch);
+        {
+            Timed t(ws, KS_EXPAND, 0);
+            if (vlg_status s = launch_expand<uint64_t>(d_lh, d_off64, nd, acc, io64, nullptr, st)) return s;
+        }
+        {
+            Timed t(ws, KS_LOCATE, 0);
+            if (vlg_status s = launch_locate<uint64_t>(idx->view, io64, acc, d_stats, st)) return s;
+            if (vlg_status s = launch_narrow<uint32_t>(io64, reinterpret_cast<uint32_t*>(Pa), acc, st)) return s;
+        }
     } else {
         if (vlg_status s = plan_sort()) return s;
         {
@@ -1048,7 +1069,7 @@ vlg_status run_joins(uint64_t n_positions, const vlg_queries* q, vlg_workspace* 
 // the queries are joined in chunks bounded by the logical budget.
 template <typename pos_t>
 vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result* res, const Plan& pl,
-                     unsigned long long* d_stats)
+                     unsigned long long* d_stats, bool wide)
 {
     const uint64_t fixed = 8ull << 20;      // alignment slack + per-chunk metadata
     if (ws->cap_bytes <= 2 * fixed) return fail(VLG_E_WORKSPACE, "workspace cap too small");
@@ -1154,7 +1175,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         tr.mark("plan super-chunk");
         pos_t* Pc = nullptr;
         uint64_t pc_cap = 0;
-        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, trail)) return s;
+        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, trail, wide)) return s;
         if (launch_first)
             if (vlg_status s = plan_joins(q, pl, ws, Q0, Q1, join_budget, idx->hdr.n, jp)) return s;
         tr.mark("locate + sort");
@@ -1356,8 +1377,13 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         }
         }
         tr.mark("intervals to host + plan");
-        const uint64_t pos_bytes = idx->hdr.sample_bytes;
-        vlg_status s = (pos_bytes == 4) ? run_batch<uint32_t>(idx, q, ws, res, pl, d_stats) : run_batch<uint64_t>(idx, q, ws, res, pl, d_stats);
+        // SA indices are wide (33 bits, 64-bit samples) for n > 2^32; text positions still fit 32 bits up to n = 2^32 + 1 (the largest
+        // one is n - 2), and then everything behind locate -- sort, fences, filter, join -- runs on 32-bit positions.
+        // VLG_FORCE_POS64=1 keeps 64-bit positions on any text (the instantiations for longer texts), =2 only the wide indices.
+        const bool wide = idx->hdr.sample_bytes == 8;
+        const char* f64 = getenv("VLG_FORCE_POS64");
+        const bool pos64 = wide && (idx->hdr.n > (1ull << 32) + 1 || (f64 && f64[0] == '1'));
+        vlg_status s = pos64 ? run_batch<uint64_t>(idx, q, ws, res, pl, d_stats, true) : run_batch<uint32_t>(idx, q, ws, res, pl, d_stats, wide);
         if (s) return s;
         unsigned long long hs[kStatsWords];
         VLG_HIP_TRY(hipMemcpyAsync(hs, d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -1368,7 +1394,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         for (uint32_t i = 0; i < kChecksumSlots; ++i) res->sum.checksum += hs[kStatsChecksum + i];      // modulo 2^64, like gm_search.cpp:110-114
         res->sum.wt_levels_bsearch = hs[3];
         // algorithmic bytes: 32 B per super-block read (+ one sample per occurrence)
-        ws->stats[KS_LOCATE].algorithmic_bytes += 32ull * hs[1] + pos_bytes * res->sum.located_occurrences;
+        ws->stats[KS_LOCATE].algorithmic_bytes += 32ull * hs[1] + (uint64_t)idx->hdr.sample_bytes * res->sum.located_occurrences;
         ws->stats[KS_BSEARCH].algorithmic_bytes += 32ull * hs[3];
         return VLG_OK;
     };
