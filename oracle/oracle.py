@@ -30,7 +30,7 @@ class Query(C.Structure):
 def build(force=False):
     """Compile the C restatement (and oracle/_ref when /root/reference is present)."""
     so = os.path.join(_HERE, "libvlgoracle.so")
-    src = [os.path.join(_HERE, f) for f in ("vlg_oracle.c", "vlg_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("vlg_oracle.c", "vlg_oracle_int.c", "vlg_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "libvlgoracle.so", "-B"], stdout=subprocess.DEVNULL)
     ref_so = os.path.join(_HERE, "_ref", "libvlgref.so")
@@ -109,6 +109,48 @@ def lib():
         L.vlgo_sasearch.restype = C.c_uint64
         L.vlgo_sa_forward_search.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.vlgo_sa_forward_search.restype = C.c_uint64
+        # integer alphabets / text-order sampling (vlg_oracle_int.c)
+        P, U = C.c_void_p, C.c_uint64
+        L.vlgo_int_suffix_array.argtypes = [P, U, P]
+        L.vlgo_int_build.argtypes = [P, U, C.c_uint32, C.c_int]
+        L.vlgo_int_build.restype = P
+        L.vlgo_int_free.argtypes = [P]
+        for nm in ("vlgo_int_size", "vlgo_int_sigma", "vlgo_int_n_samples"):
+            getattr(L, nm).argtypes = [P]
+            getattr(L, nm).restype = U
+        L.vlgo_int_levels.argtypes = [P]
+        L.vlgo_int_levels.restype = C.c_uint32
+        for nm in ("vlgo_int_C", "vlgo_int_comp2char", "vlgo_int_tree", "vlgo_int_bwt", "vlgo_int_samples", "vlgo_int_marked"):
+            getattr(L, nm).argtypes = [P]
+            getattr(L, nm).restype = C.POINTER(C.c_uint64)
+        L.vlgo_int_char2comp.argtypes = [P, U]
+        L.vlgo_int_char2comp.restype = U
+        L.vlgo_int_rank.argtypes = [P, U, U]
+        L.vlgo_int_rank.restype = U
+        L.vlgo_int_inverse_select.argtypes = [P, U, C.POINTER(U)]
+        L.vlgo_int_inverse_select.restype = U
+        L.vlgo_int_lf.argtypes = [P, U]
+        L.vlgo_int_lf.restype = U
+        L.vlgo_int_sa.argtypes = [P, U, C.POINTER(U)]
+        L.vlgo_int_sa.restype = U
+        L.vlgo_int_backward_search.argtypes = [P, P, U, C.POINTER(U), C.POINTER(U)]
+        L.vlgo_int_backward_search.restype = U
+        L.vlgo_int_locate.argtypes = [P, P, U, P, U]
+        L.vlgo_int_locate.restype = U
+        L.vlgo_parse_int.argtypes = [C.c_char_p, U, C.POINTER(Query), P, U, P]
+        L.vlgo_parse_int.restype = C.c_int
+        L.vlgo_int_search.argtypes = [P, C.POINTER(Query), P, P, P, U, P]
+        L.vlgo_int_search.restype = U
+        L.vlgo_text_order_build.argtypes = [P, C.c_uint32]
+        L.vlgo_text_order_build.restype = P
+        L.vlgo_text_order_free.argtypes = [P]
+        for nm in ("vlgo_text_order_marked", "vlgo_text_order_samples"):
+            getattr(L, nm).argtypes = [P]
+            getattr(L, nm).restype = C.POINTER(C.c_uint64)
+        L.vlgo_text_order_n_samples.argtypes = [P]
+        L.vlgo_text_order_n_samples.restype = U
+        L.vlgo_text_order_sa.argtypes = [P, P, U, C.POINTER(U)]
+        L.vlgo_text_order_sa.restype = U
         _LIB = L
     return _LIB
 
@@ -163,6 +205,18 @@ def ref():
         for nm in ("vrefw_count_less", "vrefw_quantile"):
             getattr(R, nm).argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
             getattr(R, nm).restype = C.c_uint64
+        R.vrefi_create.argtypes = [C.c_void_p, C.c_uint64]
+        R.vrefi_create.restype = C.c_void_p
+        R.vrefi_destroy.argtypes = [C.c_void_p]
+        R.vrefi_levels.argtypes = [C.c_void_p]
+        R.vrefi_levels.restype = C.c_uint32
+        R.vrefi_sigma.argtypes = [C.c_void_p]
+        R.vrefi_sigma.restype = C.c_uint64
+        R.vrefi_rank.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        R.vrefi_rank.restype = C.c_uint64
+        R.vrefi_inverse_select.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        R.vrefi_inverse_select.restype = C.c_uint64
+        R.vrefi_tree_bits.argtypes = [C.c_void_p, C.c_void_p]
         R.vref_int_alphabet.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         R.vref_int_alphabet.restype = C.c_uint64
         _REF = R
@@ -518,3 +572,152 @@ def ref_int_alphabet(text):
     Cc, c2c = np.zeros(sigma + 1, np.uint64), np.zeros(max(sigma, 1), np.uint64)
     assert int(ref().vref_int_alphabet(t.ctypes.data, len(t), Cc.ctypes.data, c2c.ctypes.data)) == sigma
     return Cc, c2c[:sigma]
+
+
+class IntIndex:
+    """csa_wt<wt_int<>, dens, ., sa_order | text_order sampling, ., int_alphabet<>> restated (vlg_oracle_int.c): the FM-index of an
+    integer text.  Symbols are positive integers (construct() refuses a 0, construct.hpp:36-45)."""
+
+    def __init__(self, text, dens=32, text_order=False):
+        t = np.ascontiguousarray(text, dtype=np.uint64)
+        self.h = lib().vlgo_int_build(t.ctypes.data, len(t), dens, 1 if text_order else 0)
+        if not self.h:
+            raise ValueError("integer text contains the symbol 0")
+        self.n, self.sigma, self.levels = int(lib().vlgo_int_size(self.h)), int(lib().vlgo_int_sigma(self.h)), int(lib().vlgo_int_levels(self.h))
+        self.dens, self.text_order = dens, bool(text_order)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().vlgo_int_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _arr(self, fn, count):
+        return np.ctypeslib.as_array(fn(self.h), shape=(max(count, 1),))[:count].copy()
+
+    def C(self):
+        return self._arr(lib().vlgo_int_C, self.sigma + 1)
+
+    def comp2char(self):
+        return self._arr(lib().vlgo_int_comp2char, self.sigma)
+
+    def bwt(self):
+        return self._arr(lib().vlgo_int_bwt, self.n)
+
+    def level_bits(self):
+        nb = self.n * self.levels
+        w = self._arr(lib().vlgo_int_tree, nb // 64 + 1)
+        return np.unpackbits(w.view(np.uint8), bitorder="little")[:nb].reshape(self.levels, self.n)
+
+    def samples(self):
+        return self._arr(lib().vlgo_int_samples, int(lib().vlgo_int_n_samples(self.h)))
+
+    def marked(self):
+        w = self._arr(lib().vlgo_int_marked, self.n // 64 + 1)
+        return np.unpackbits(w.view(np.uint8), bitorder="little")[: self.n]
+
+    def rank(self, i, c):
+        return int(lib().vlgo_int_rank(self.h, int(i), int(c)))
+
+    def inverse_select(self, i):
+        c = C.c_uint64()
+        r = lib().vlgo_int_inverse_select(self.h, int(i), C.byref(c))
+        return int(r), int(c.value)
+
+    def lf(self, i):
+        return int(lib().vlgo_int_lf(self.h, int(i)))
+
+    def sa(self, i):
+        return int(lib().vlgo_int_sa(self.h, int(i), None))
+
+    def backward_search(self, pat):
+        p = np.ascontiguousarray(pat, dtype=np.uint64)
+        l, r = C.c_uint64(), C.c_uint64()
+        cnt = lib().vlgo_int_backward_search(self.h, p.ctypes.data, len(p), C.byref(l), C.byref(r))
+        return int(cnt), int(l.value), int(r.value)
+
+    def search(self, regexp, stats=None):
+        """tuples [matches, k] of the integer-alphabet query (library dialect)"""
+        raw = regexp.encode("latin-1") if isinstance(regexp, str) else bytes(regexp)
+        q = Query()
+        syms = np.zeros(len(raw) + 2, dtype=np.uint64)
+        sub_off = np.zeros(66, dtype=np.uint64)
+        rc = lib().vlgo_parse_int(raw, len(raw), C.byref(q), syms.ctypes.data, len(syms), sub_off.ctypes.data)
+        if rc:
+            raise ParseError(rc)
+        cap = 1 << 12
+        while True:
+            out = np.zeros(cap * q.k, dtype=np.uint64)
+            st = np.zeros(4, dtype=np.uint64)
+            m = int(lib().vlgo_int_search(self.h, C.byref(q), syms.ctypes.data, sub_off.ctypes.data, out.ctypes.data, cap, st.ctypes.data))
+            if m <= cap:
+                if stats is not None:
+                    stats += st
+                return out[: m * q.k].reshape(m, q.k)
+            cap = m
+
+
+class TextOrder:
+    """text_order_sa_sampling on top of the byte index (csa_sampling_strategy.hpp:127-246): marked bit-vector + condensed samples"""
+
+    def __init__(self, index, dens=32):
+        self.index, self.dens = index, dens
+        self.h = lib().vlgo_text_order_build(index.h, dens)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().vlgo_text_order_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def marked(self):
+        n = self.index.n
+        w = np.ctypeslib.as_array(lib().vlgo_text_order_marked(self.h), shape=(n // 64 + 1,)).copy()
+        return np.unpackbits(w.view(np.uint8), bitorder="little")[:n]
+
+    def samples(self):
+        k = int(lib().vlgo_text_order_n_samples(self.h))
+        return np.ctypeslib.as_array(lib().vlgo_text_order_samples(self.h), shape=(max(k, 1),))[:k].copy()
+
+    def sa(self, i, steps=None):
+        st = C.c_uint64(0)
+        v = int(lib().vlgo_text_order_sa(self.index.h, self.h, int(i), C.byref(st)))
+        if steps is not None:
+            steps[0] += int(st.value)
+        return v
+
+
+class RefWtIntPlain:
+    """The reference's own wt_int<> (bit_vector + rank_support_v) over a vector of integers: what csa_wt<wt_int<>> keeps its BWT in."""
+
+    def __init__(self, values):
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        self.h = ref().vrefi_create(v.ctypes.data, len(v))
+        assert self.h
+        self.n, self.levels, self.sigma = len(v), int(ref().vrefi_levels(self.h)), int(ref().vrefi_sigma(self.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                ref().vrefi_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def rank(self, i, c):
+        return int(ref().vrefi_rank(self.h, int(i), int(c)))
+
+    def inverse_select(self, i):
+        c = C.c_uint64()
+        r = ref().vrefi_inverse_select(self.h, int(i), C.byref(c))
+        return int(r), int(c.value)
+
+    def level_bits(self):
+        nb = self.n * self.levels
+        w = np.zeros((nb + 63) // 64 + 1, dtype=np.uint64)
+        ref().vrefi_tree_bits(self.h, w.ctypes.data)
+        return np.unpackbits(w.view(np.uint8), bitorder="little")[:nb].reshape(self.levels, self.n)

@@ -15,6 +15,8 @@
 //   * wt_int<bit_vector_il<>, rank_support_il<>>  -- the tree type of vlg_index (vlg_index.hpp:116-119): ctor, operator[],
 //                                         the level-concatenated bit-vector `tree`, expand(node) / expand(node, range) / value_range
 //                                         (include/sdsl/wt_int.hpp:182-270, 339-361, 824-939; bit_vector_il.hpp)
+//   * wt_int<> (bit_vector, rank_support_v)  ctor / rank / inverse_select / tree: the BWT container of csa_wt<wt_int<>>
+//                                         (include/sdsl/wt_int.hpp:182-270, 370-395, 405-430)
 //   * int_alphabet<>                      (include/sdsl/csa_alphabet_strategy.hpp:394-470; lib/csa_alphabet_strategy.cpp)
 //
 // What is NOT buildable in this image (see DESIGN.md "Oracle"):
@@ -395,6 +397,45 @@ uint64_t vrefw_quantile(void* h, uint64_t l, uint64_t len, uint64_t q)
         else { q -= left_n; v = ch[1]; r = rs[1]; }
     }
     return wt.sym(v);
+}
+
+// ---- wt_int<> (bit_vector + rank_support_v), the BWT container of csa_wt<wt_int<>> for integer alphabets ----------------------------
+typedef wt_int<> wt_int_plain;
+void* vrefi_create(const uint64_t* vals, uint64_t n)
+{
+    try {
+        std::string f = "@vref_ibwt_" + std::to_string(g_seq++);
+        {
+            int_vector<> v(n, 0, 64);
+            for (uint64_t i = 0; i < n; ++i) v[i] = vals[i];
+            store_to_file(v, f);
+        }
+        wt_int_plain* wt = nullptr;
+        {
+            int_vector_buffer<> buf(f);
+            wt = new wt_int_plain(buf, n);
+        }
+        sdsl::remove(f);
+        return wt;
+    } catch (...) {}
+    return nullptr;
+}
+void vrefi_destroy(void* h) { delete (wt_int_plain*)h; }
+uint32_t vrefi_levels(void* h) { return ((wt_int_plain*)h)->max_level; }
+uint64_t vrefi_sigma(void* h) { return ((wt_int_plain*)h)->sigma; }
+uint64_t vrefi_rank(void* h, uint64_t i, uint64_t c) { return ((wt_int_plain*)h)->rank(i, c); }
+uint64_t vrefi_inverse_select(void* h, uint64_t i, uint64_t* c)
+{
+    auto rc = ((wt_int_plain*)h)->inverse_select(i);
+    *c = rc.second;
+    return rc.first;
+}
+void vrefi_tree_bits(void* h, uint64_t* words)
+{
+    const wt_int_plain& wt = *(wt_int_plain*)h;
+    const uint64_t nb = wt.tree.size();
+    for (uint64_t i = 0; i < (nb + 63) / 64; ++i) words[i] = 0;
+    for (uint64_t i = 0; i < nb; ++i) if (wt.tree[i]) words[i >> 6] |= 1ULL << (i & 63);
 }
 
 // ---- int_alphabet (csa_alphabet_strategy.hpp:394-470): built by the reference's constructor from an integer text -----------------

@@ -125,6 +125,41 @@ uint64_t vlgo_sa_forward_search(const uint8_t* text, uint64_t n, const uint32_t*
 uint64_t vlgo_sasearch(const uint8_t* text, uint64_t n, const uint32_t* sa, const vlgo_query* q, uint64_t* tuples_out, uint64_t cap,
                        uint64_t* stats);
 
+/* ---- integer alphabets and text-order SA sampling (vlg_oracle_int.c) --------------------------------------------
+ * csa_wt<wt_int<>, dens, ., sa_order | text_order sampling, ., int_alphabet<>> restated in the reference's layout. */
+typedef struct vlgo_int_index vlgo_int_index;
+int vlgo_int_suffix_array(const uint64_t* text, uint64_t n, uint64_t* sa);     /* text[n-1] = 0, the unique smallest symbol */
+vlgo_int_index* vlgo_int_build(const uint64_t* text, uint64_t n_text, uint32_t dens, int text_order);   /* NULL: a 0 symbol in the text */
+void vlgo_int_free(vlgo_int_index*);
+uint64_t vlgo_int_size(const vlgo_int_index*);
+uint64_t vlgo_int_sigma(const vlgo_int_index*);
+const uint64_t* vlgo_int_C(const vlgo_int_index*);
+const uint64_t* vlgo_int_comp2char(const vlgo_int_index*);
+uint32_t vlgo_int_levels(const vlgo_int_index*);
+const uint64_t* vlgo_int_tree(const vlgo_int_index*);          /* n * levels bits */
+const uint64_t* vlgo_int_bwt(const vlgo_int_index*);
+uint64_t vlgo_int_n_samples(const vlgo_int_index*);
+const uint64_t* vlgo_int_samples(const vlgo_int_index*);
+const uint64_t* vlgo_int_marked(const vlgo_int_index*);        /* text-order sampling only */
+uint64_t vlgo_int_char2comp(const vlgo_int_index*, uint64_t c);
+uint64_t vlgo_int_rank(const vlgo_int_index*, uint64_t i, uint64_t c);                    /* wt_int::rank */
+uint64_t vlgo_int_inverse_select(const vlgo_int_index*, uint64_t i, uint64_t* c);         /* wt_int::inverse_select */
+uint64_t vlgo_int_lf(const vlgo_int_index*, uint64_t i);
+uint64_t vlgo_int_sa(const vlgo_int_index*, uint64_t i, uint64_t* lf_steps);              /* csa[i] */
+uint64_t vlgo_int_backward_search(const vlgo_int_index*, const uint64_t* pat, uint64_t m, uint64_t* l, uint64_t* r);
+uint64_t vlgo_int_locate(const vlgo_int_index*, const uint64_t* pat, uint64_t m, uint64_t* out, uint64_t cap);
+/* gapped_pattern_query<int_alphabet_tag>: q->sub / sub_len point into the regexp (characters), syms / sub_off hold the symbols */
+int vlgo_parse_int(const uint8_t* regexp, uint64_t len, vlgo_query* q, uint64_t* syms, uint64_t syms_cap, uint64_t* sub_off /* [k+1] */);
+uint64_t vlgo_int_search(const vlgo_int_index*, const vlgo_query* q, const uint64_t* syms, const uint64_t* sub_off, uint64_t* tuples_out,
+                         uint64_t cap, uint64_t* stats);
+/* text-order sampling on top of the byte index */
+typedef struct vlgo_text_order vlgo_text_order;
+vlgo_text_order* vlgo_text_order_build(const vlgo_index*, uint32_t dens);
+void vlgo_text_order_free(vlgo_text_order*);
+const uint64_t* vlgo_text_order_marked(const vlgo_text_order*);
+const uint64_t* vlgo_text_order_samples(const vlgo_text_order*);
+uint64_t vlgo_text_order_n_samples(const vlgo_text_order*);
+uint64_t vlgo_text_order_sa(const vlgo_index*, const vlgo_text_order*, uint64_t i, uint64_t* lf_steps);
 #ifdef __cplusplus
 }
 #endif

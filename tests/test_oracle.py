@@ -286,3 +286,94 @@ def test_reference_int_alphabet(refmod):
     text = np.array([5, 6, 7, 5, 6, 7, 1000, 5, 0], dtype=np.uint64)
     Cc, c2c = refmod.ref_int_alphabet(text)
     assert c2c.tolist() == [0, 5, 6, 7, 1000] and Cc.tolist() == [0, 1, 4, 6, 8, 9]
+
+
+def _int_texts():
+    rng = np.random.default_rng(31)
+    return {
+        "survey": np.array([5, 6, 7, 5, 6, 7, 1000, 5], dtype=np.uint64),
+        "abra": np.frombuffer(b"abracadabrasimsalabim", dtype=np.uint8).astype(np.uint64),
+        "sparse": rng.choice(np.array([3, 7, 7, 19, 1000, 70000, 2 ** 31 + 5], dtype=np.uint64), 900),
+        "dense": rng.integers(1, 40, 700).astype(np.uint64),                   # continuous alphabet 0..39 (int_alphabet's direct map)
+        "one": np.array([42], dtype=np.uint64),
+    }
+
+
+@pytest.mark.parametrize("name", ["survey", "abra", "sparse", "dense", "one"])
+def test_int_fm_oracle_pinned_by_reference_wt_int_and_int_alphabet(oracle, refmod, name):
+    """The integer-alphabet FM-index restatement (vlg_oracle_int.c) against the reference's OWN wt_int<> and int_alphabet<> built by
+    their constructors over the same BWT (oracle/_ref): tree bits, levels, rank(i, c) for present and absent symbols,
+    inverse_select(i), C and comp2char; then LF and csa[i] against the suffix array (csa_byte_test.cpp:136-147 checks csa[j] == SA[j])."""
+    text = _int_texts()[name]
+    x = oracle.IntIndex(text, dens=4)
+    bwt = x.bwt()
+    ref = refmod.RefWtIntPlain(bwt)
+    assert ref.levels == x.levels
+    assert (ref.level_bits() == x.level_bits()).all()
+    Cc, c2c = refmod.ref_int_alphabet(bwt)
+    assert Cc.tolist() == x.C().tolist() and c2c.tolist() == x.comp2char().tolist() and ref.sigma == x.sigma
+    rng = np.random.default_rng(5)
+    syms = [int(s) for s in set(bwt.tolist())] + [1, 2, 123456789, (1 << x.levels) + 3]
+    for _ in range(400):
+        i, c = int(rng.integers(0, x.n + 1)), syms[int(rng.integers(0, len(syms)))]
+        assert x.rank(i, c) == ref.rank(i, c), (i, c)
+    for i in range(x.n):
+        assert x.inverse_select(i) == ref.inverse_select(i)
+    tz = np.concatenate([text, [0]]).astype(np.int64)
+    sa = sorted(range(len(tz)), key=lambda i: tz[i:].tolist())
+    assert [x.sa(i) for i in range(x.n)] == sa
+    inv = {v: i for i, v in enumerate(sa)}
+    for i in range(x.n):                                                      # LF(i) = ISA[SA[i] - 1]
+        assert x.lf(i) == inv[(sa[i] - 1) % x.n]
+
+
+def test_int_fm_oracle_known_answers_and_brute_force(oracle):
+    """VLG level of the integer oracle: the survey's six integer known answers of sdsl::locate(vlg_index<int_alphabet_tag>, query)
+    (tests/golden), then random queries against a scan of the text with Appendix C's join."""
+    import json
+    from util import reference_semantics_join
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vlg_known_answers.json")))
+    for case in gold["int_cases"]:
+        x = oracle.IntIndex(np.array(case["int_text"], dtype=np.uint64))
+        assert x.search(case["query"]).tolist() == case["tuples"], case
+    rng = np.random.default_rng(9)
+    text = rng.integers(1, 6, 3000).astype(np.uint64)
+    x = oracle.IntIndex(text, dens=32)
+    t = text.tolist()
+    for _ in range(60):
+        k = int(rng.integers(1, 4))
+        subs = [t[s:s + int(rng.integers(1, 4))] for s in rng.integers(0, len(t) - 4, k)]
+        gaps = [(int(a), int(a) + int(rng.integers(0, 30))) for a in rng.integers(0, 10, k - 1)]
+        q = " ".join(map(str, subs[0]))
+        for sp, (a, b) in zip(subs[1:], gaps):
+            q += " .{%d,%d}? %s" % (a, b, " ".join(map(str, sp)))
+        lists = [[i for i in range(len(t) - len(sp) + 1) if t[i:i + len(sp)] == sp] for sp in subs]
+        lo = [gaps[i][0] + len(subs[i]) for i in range(k - 1)]
+        hi = [gaps[i][1] + len(subs[i]) for i in range(k - 1)]
+        want = reference_semantics_join(lists, lo, hi, len(subs[-1]))
+        assert x.search(q).tolist() == want, q
+    with pytest.raises(ValueError):
+        oracle.IntIndex(np.array([4, 0, 4], dtype=np.uint64))                # construct.hpp:36-45: a 0 symbol is refused
+
+
+@pytest.mark.parametrize("dens", [1, 4, 32])
+def test_text_order_sampling_oracle(oracle, dens):
+    """text_order_sa_sampling restated (csa_sampling_strategy.hpp:127-246): marked[i] <=> SA[i] % dens == 0, samples = SA / dens in the
+    order of the marked indices, csa[i] == SA[i] through it, and a walk never takes more than dens - 1 LF steps -- for the byte
+    index and the integer index.  (The header cannot be compiled here: pinned by these defining properties only.)"""
+    from util import dna_text
+    text = dna_text(2000, 3).tobytes()
+    idx = oracle.Index.from_text(text)
+    sa = oracle.suffix_array(np.frombuffer(text + bytes(1), dtype=np.uint8)).astype(np.int64)
+    to = oracle.TextOrder(idx, dens)
+    assert (to.marked() == (sa % dens == 0)).all()
+    assert to.samples().tolist() == [int(v) // dens for v in sa if v % dens == 0]
+    for i in range(idx.n):
+        steps = [0]
+        assert to.sa(i, steps) == sa[i] and steps[0] == sa[i] % dens
+    itext = np.random.default_rng(2).integers(1, 9, 500).astype(np.uint64)
+    x = oracle.IntIndex(itext, dens=dens, text_order=True)
+    tz = np.concatenate([itext, [0]]).astype(np.int64)
+    isa = sorted(range(len(tz)), key=lambda i: tz[i:].tolist())
+    assert (x.marked() == (np.array(isa) % dens == 0)).all()
+    assert [x.sa(i) for i in range(x.n)] == isa
