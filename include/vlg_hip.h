@@ -91,6 +91,8 @@ typedef struct {
     uint32_t pos_bytes;           /* 4 (n <= 2^32) or 8: width of SA samples / SA indices; text positions inside the
                                      kernels are 32-bit up to n = 2^32 + 1 whatever this says     */
     uint32_t bv_kind;             /* VLG_BV_PLAIN or VLG_BV_RRR63                               */
+    uint32_t sampling;            /* VLG_SAMPLING_SA_ORDER or VLG_SAMPLING_TEXT_ORDER           */
+    uint32_t reserved;
 } vlg_index_info;
 
 /* Build on the device from raw text (no 0 byte; the sentinel is appended like
@@ -126,6 +128,19 @@ vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_parts* sizes, 
 #define VLG_BV_PLAIN 0
 #define VLG_BV_RRR63 1
 vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out);
+/* The other SA sampling strategy of the reference, and other densities: a second index over the same BWT whose SA samples are
+ *   VLG_SAMPLING_SA_ORDER    SA[0], SA[d], SA[2d], ...                   sa_order_sa_sampling, csa_wt's default
+ *                            (include/sdsl/csa_sampling_strategy.hpp:64-112)
+ *   VLG_SAMPLING_TEXT_ORDER  the SA values that are multiples of d, found through a marked bit-vector over the SA indices:
+ *                            is_sampled(i) = marked[i], csa[i] = samples[rank_marked(i)] * d   text_order_sa_sampling (:127-246) --
+ *                            the locate indexes of benchmark/indexing_locate/index.config:9-12; a walk takes SA[i] % d LF steps
+ * Every search entry point accepts it and returns identical results.  `src` must be SA-order sampled (plain or rrr) with n <= 2^32;
+ * for a text-order index vlg_index_export_parts' sa_samples receives the condensed values SA / d, vlg_index_export_marked the
+ * marks (bit i = h_words[i >> 6] >> (i & 63), ceil(n / 64) words). */
+#define VLG_SAMPLING_SA_ORDER 0
+#define VLG_SAMPLING_TEXT_ORDER 1
+vlg_status vlg_index_resample(const vlg_index* src, int sampling, uint32_t sa_sample_dens, vlg_index** out);
+vlg_status vlg_index_export_marked(const vlg_index* idx, uint64_t* h_words);
 vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* info);
 void vlg_index_destroy(vlg_index* idx);
 

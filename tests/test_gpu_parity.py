@@ -1116,3 +1116,67 @@ def test_rccl_branch_runs_with_one_rank(V, oracle):
     o = oracle.Index.from_text(text)
     for i in (0, 17, 60, 119):
         assert got["counts"][i] == len(o.search(queries[i]))
+
+
+@pytest.mark.parametrize("name,dens", [("dna_50k", 32), ("zipf40", 8), ("100a", 4), ("abracadabra", 1), ("dna_skew", 64)])
+def test_text_order_sa_sampling(torch_cuda, V, oracle, name, dens):
+    """text_order_sa_sampling (include/sdsl/csa_sampling_strategy.hpp:127-246) as an index variant made by
+    vlg_index_resample: the marked bit-vector and the condensed samples equal the oracle's restatement, csa[i] == SA[i] for every i
+    through vlg_sa_batch, every search mode returns the tuples of the SA-order index and the oracle -- with exactly
+    sum(SA[i] % dens) LF steps when nothing is shared (the strategy's defining property) -- and it stacks on the rrr variant."""
+    torch = torch_cuda
+    from vlg_matching_amd.index import Workspace
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    sa = oracle.suffix_array(np.frombuffer(text + bytes(1), np.uint8)).astype(np.int64)
+    base = V.VlgIndex.build(text)
+    idx = base.resample(text_order=True, dens=dens)
+    info = idx.info()
+    assert info["sampling"] == 1 and info["sa_sample_dens"] == dens and info["n_samples"] == (len(sa) + dens - 1) // dens
+    to = oracle.TextOrder(o, dens)
+    assert (idx.marked() == to.marked()).all() and (idx.marked() == (sa % dens == 0)).all()
+    want_samples = to.samples()
+    got_samples = idx.export_parts()["samples"]
+    assert got_samples[: len(want_samples)].tolist() == want_samples.tolist()
+    L = V.lib()
+    ii = np.arange(len(sa), dtype=np.uint64)
+    for h in (idx, base.compress().resample(text_order=True, dens=dens)):
+        d_i = dev_u64(torch, ii)
+        d_o = torch.zeros_like(d_i)
+        V.capi.check(L.vlg_sa_batch(h._h, d_i.data_ptr(), d_o.data_ptr(), len(ii), None))
+        torch.cuda.synchronize()
+        assert (host_u64(d_o).astype(np.int64) == sa).all()
+    rng = np.random.default_rng(5)
+    qs = random_queries(text, rng, 150, kmax=4, mmax=4)
+    want = [o.search(q).tolist() for q in qs]
+    ref = base.search(qs)
+    for opts in ({"sweep_min": 1 << 30, "dedup": 0}, {"sweep_min": 1, "sweep_tail": 16, "dedup": 0}, {"sweep_min": 1, "sweep_tail": 16},
+                 {"sweep_min": 1, "sweep_tail": 1 << 30}):
+        ws = Workspace()
+        for k_, v_ in opts.items():
+            ws.set_option(k_, v_)
+        res = idx.search(qs, workspace=ws)
+        for i in range(len(qs)):
+            assert res.tuples(i).tolist() == want[i], (qs[i], opts)
+        assert res.summary["checksum"] == ref.summary["checksum"] and res.summary["n_matches"] == ref.summary["n_matches"]
+        if opts.get("dedup", 1) == 0:
+            # every occurrence walks SA[i] % dens steps to its sample: count them from the located positions themselves
+            steps = 0
+            for q in qs:
+                subs, _, _, _ = oracle.query_fields(oracle.parse(q))
+                occs = [o.backward_search(sp) for sp in subs]
+                if min(c for c, _, _ in occs) == 0:
+                    continue
+                for c, l, r in occs:
+                    steps += int((sa[l:r + 1] % dens).sum())
+            assert res.summary["lf_steps"] == steps, opts
+    # SA-order resampling with another density gives the samples the builder would
+    re8 = base.resample(text_order=False, dens=8)
+    assert_parts_equal(re8.export_parts(), V.VlgIndex.build(text, dens=8).export_parts())
+    # a text-order index travels as a blob like any other
+    blob = torch.empty(idx.blob_bytes(), dtype=torch.uint8, device="cuda")
+    idx.blob_export(blob.data_ptr(), blob.numel())
+    att = V.VlgIndex.attach_blob(blob.data_ptr(), blob.numel(), keep=blob)
+    assert att.info()["sampling"] == 1
+    r2 = att.search(qs)
+    assert (r2.counts == ref.counts).all() and r2.summary["checksum"] == ref.summary["checksum"]

@@ -34,7 +34,7 @@ class IndexPartsOut(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("n", C.c_uint64), ("sigma", C.c_uint32), ("sa_sample_dens", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("max_code_len", C.c_uint32), ("wt_bits", C.c_uint64), ("n_blocks", C.c_uint64), ("n_samples", C.c_uint64),
-                ("hbm_bytes", C.c_uint64), ("pos_bytes", C.c_uint32), ("bv_kind", C.c_uint32)]
+                ("hbm_bytes", C.c_uint64), ("pos_bytes", C.c_uint32), ("bv_kind", C.c_uint32), ("sampling", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ResultSummary(C.Structure):
@@ -69,6 +69,8 @@ SYMBOLS = [
     ("vlg_index_from_parts", _I, [C.POINTER(IndexParts), C.POINTER(_P)]),
     ("vlg_index_export_parts", _I, [_P, C.POINTER(IndexParts), C.POINTER(IndexPartsOut)]),
     ("vlg_index_compress", _I, [_P, _I, C.POINTER(_P)]),
+    ("vlg_index_resample", _I, [_P, _I, C.c_uint32, C.POINTER(_P)]),
+    ("vlg_index_export_marked", _I, [_P, _P]),
     ("vlg_index_get_info", _I, [_P, C.POINTER(IndexInfo)]),
     ("vlg_index_destroy", None, [_P]),
     ("vlg_sdsl_file_open", _I, [C.c_char_p, C.c_uint32, C.POINTER(_P)]),

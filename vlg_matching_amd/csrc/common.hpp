@@ -14,7 +14,10 @@
 //          leaf and carries the alphabet rank (comp) of its symbol in the low bits.
 // C      : u64[sigma+1] cumulative counts (lib/csa_alphabet_strategy.cpp:25-55)
 // paths  : u64[256] m_path of wt_helper.hpp:219-240 (code bits, first edge in bit 0; length in 56..63)
-// samples: SA[0], SA[d], SA[2d], ... as u32 (n <= 2^32) or u64.
+// samples: SA[0], SA[d], SA[2d], ... as u32 (n <= 2^32) or u64 (sa_order_sa_sampling, the default); or, for
+//          text_order_sa_sampling (csa_sampling_strategy.hpp:127-246), SA[i] / d of the SA indices i with SA[i] % d == 0 in
+//          ascending i, plus [marked]: super-blocks {224 marks, ones before} over the SA indices -- is_sampled(i) and the rank
+//          that addresses the sample come out of ONE 32-byte read.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -53,11 +56,12 @@ struct BlobHeader {
     uint32_t n_nodes;
     uint32_t max_code_len;
     uint32_t sample_bytes;
-    uint32_t pad0;
+    uint32_t sampling;            // 0 = SA order (SA[0], SA[d], ...: _sa_order_sampling), 1 = text order (_text_order_sampling: a marked
+                                  // bit-vector over SA indices + SA / d of the marked ones)
     uint64_t off_blocks, off_nodes, off_C, off_paths, off_c2c, off_samples, off_refnodes;
     uint64_t bv_kind;             // 0 = plain 256-bit super-blocks, 1 = rrr-63 (headers + offset stream as K6, block code of rrr_code.hpp)
     uint64_t off_rrr_hdr, off_rrr_stream, off_binom, n_rrr_sb, rrr_stream_words;
-    uint64_t reserved[1];
+    uint64_t off_marked;          // text-order sampling: n / 224 + 1 super-blocks {224 marks, ones before} over the SA indices
 };
 
 // What kernels receive (by value).
@@ -76,13 +80,15 @@ struct IndexView {
     uint32_t sample_bytes;
     // rrr-63 variant of the wavelet-tree bit-vectors (bv_kind == 1): DNode.base counts 32-byte headers
     uint32_t bv_kind;
-    uint32_t pad;
+    uint32_t sampling;                    // kSamplingSaOrder / kSamplingTextOrder
+    const Block* marked;                  // text-order sampling: marks over the SA indices (samples = SA / dens of the marked ones)
     const uint4* rrr_hdr;
     const uint64_t* rrr_stream;
     const struct RrrTables* rrr_tables;   // rrr_code.hpp
 };
 
 constexpr uint32_t kBvPlain = 0, kBvRrr63 = 1;
+constexpr uint32_t kSamplingSaOrder = 0, kSamplingTextOrder = 1;
 constexpr uint32_t kRrrBlockBits = 63, kRrrBlocksPerSuper = 32, kRrrSuperBits = 63 * 32;
 
 void set_error(const std::string& msg);

@@ -141,6 +141,42 @@ struct RrrBV {
     }
 };
 
+// ---- SA sampling policies: is SA index i sampled, and if so what is SA[i] --------------------------------------------------------
+// SaOrder: _sa_order_sampling (include/sdsl/csa_sampling_strategy.hpp:64-112): every dens-th SA index, samples[i / dens].
+template <typename sample_t>
+struct SaOrderSampling {
+    uint32_t dens, dmask, dshift;
+    bool pow2;
+    const sample_t* samples;
+    __device__ __forceinline__ explicit SaOrderSampling(const IndexView& iv)
+        : dens(iv.dens), dmask(iv.dens - 1), dshift(31 - __clz(iv.dens)), pow2((iv.dens & (iv.dens - 1)) == 0),
+          samples(reinterpret_cast<const sample_t*>(iv.samples)) {}
+    __device__ __forceinline__ bool probe(uint64_t i, uint64_t& value) const
+    {
+        const bool sampled = pow2 ? ((i & dmask) == 0) : (i % dens == 0);
+        if (sampled) value = (uint64_t)samples[pow2 ? (i >> dshift) : (i / dens)];
+        return sampled;
+    }
+};
+// TextOrder: _text_order_sampling (csa_sampling_strategy.hpp:127-246): is_sampled(i) = marked[i] (:185-188), value =
+// samples[rank_marked(i)] * dens (:191-194).  The mark and the rank come out of the same 32-byte super-block.
+struct TextOrderSampling {
+    uint32_t dens;
+    const Block* marked;
+    const uint32_t* samples;
+    __device__ __forceinline__ explicit TextOrderSampling(const IndexView& iv)
+        : dens(iv.dens), marked(iv.marked), samples(reinterpret_cast<const uint32_t*>(iv.samples)) {}
+    __device__ __forceinline__ bool probe(uint64_t i, uint64_t& value) const
+    {
+        uint32_t blk, off;
+        split224(i, blk, off);
+        const BlockRegs r = load_block(marked, blk);
+        const bool sampled = block_bit(r, off) != 0;
+        if (sampled) value = (uint64_t)samples[block_rank(r, off)] * dens;
+        return sampled;
+    }
+};
+
 // Node table + C (+ whatever the bit-vector policy needs) staged in LDS by every workgroup that walks the tree.
 template <class BV>
 struct WalkLds {

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <string.h>
 #include "common.hpp"
+#include "device_rank.hpp"
 #include "rrr_code.hpp"
 #include <rocprim/rocprim.hpp>
 
@@ -150,10 +151,39 @@ void bind_view(vlg_index* idx)
     idx->view.dens = h.dens;
     idx->view.sample_bytes = h.sample_bytes;
     idx->view.bv_kind = (uint32_t)h.bv_kind;
-    idx->view.pad = 0;
+    idx->view.sampling = h.sampling;
+    idx->view.marked = h.sampling == kSamplingTextOrder ? reinterpret_cast<const Block*>(b + h.off_marked) : nullptr;
     idx->view.rrr_hdr = reinterpret_cast<const uint4*>(b + h.off_rrr_hdr);
     idx->view.rrr_stream = reinterpret_cast<const uint64_t*>(b + h.off_rrr_stream);
     idx->view.rrr_tables = reinterpret_cast<const RrrTables*>(b + h.off_binom);
+}
+
+// Section offsets and the total size from the counts in the header (sections in a fixed order, 256-byte aligned).
+struct BlobSection { uint64_t BlobHeader::*off; uint64_t bytes; };
+inline void blob_sections(const BlobHeader& h, BlobSection (&sec)[11])
+{
+    const BlobSection all[11] = {
+        {&BlobHeader::off_blocks, h.n_blocks * sizeof(Block)},
+        {&BlobHeader::off_nodes, (uint64_t)kMaxNodes * sizeof(DNode)},
+        {&BlobHeader::off_C, 257 * 8},
+        {&BlobHeader::off_paths, 256 * 8},
+        {&BlobHeader::off_c2c, 256},
+        {&BlobHeader::off_samples, h.n_samples * h.sample_bytes},
+        {&BlobHeader::off_refnodes, (uint64_t)kMaxNodes * sizeof(vlg_wt_node)},
+        {&BlobHeader::off_rrr_hdr, h.n_rrr_sb * 32},
+        {&BlobHeader::off_rrr_stream, (h.rrr_stream_words + 2) * 8},
+        {&BlobHeader::off_binom, h.n_rrr_sb ? 64ull * 64 * 8 : 0ull},
+        {&BlobHeader::off_marked, h.sampling == kSamplingTextOrder ? (h.n / kBlockBits + 1) * sizeof(Block) : 0ull},
+    };
+    for (int i = 0; i < 11; ++i) sec[i] = all[i];
+}
+inline void layout_blob(BlobHeader& h)
+{
+    BlobSection sec[11];
+    blob_sections(h, sec);
+    uint64_t off = align_up(sizeof(BlobHeader), 256);
+    for (const BlobSection& s : sec) { h.*(s.off) = off; off = align_up(off + s.bytes, 256); }
+    h.total_bytes = off;
 }
 
 // Plan the blob from the host tree, allocate it, upload the small tables. Blocks + samples stay to be filled.
@@ -179,18 +209,7 @@ vlg_status alloc_blob(vlg_index* idx, uint64_t n, uint32_t dens, hipStream_t str
     // everywhere, 2 = wide SA indices with 32-bit text positions, the mix BASELINE config 4 runs on -- see vlg_search_batch)
     const char* f64 = getenv("VLG_FORCE_POS64");
     h.sample_bytes = (n <= 0x100000000ull && !(f64 && (f64[0] == '1' || f64[0] == '2'))) ? 4 : 8;
-    uint64_t off = align_up(sizeof(BlobHeader), 256);
-    h.off_blocks = off;  off = align_up(off + h.n_blocks * sizeof(Block), 256);
-    h.off_nodes = off;   off = align_up(off + (uint64_t)kMaxNodes * sizeof(DNode), 256);
-    h.off_C = off;       off = align_up(off + 257 * 8, 256);
-    h.off_paths = off;   off = align_up(off + 256 * 8, 256);
-    h.off_c2c = off;     off = align_up(off + 256, 256);
-    h.off_samples = off; off = align_up(off + h.n_samples * h.sample_bytes, 256);
-    h.off_refnodes = off; off = align_up(off + (uint64_t)kMaxNodes * sizeof(vlg_wt_node), 256);
-    h.off_rrr_hdr = off; off = align_up(off + n_rrr_sb * 32, 256);
-    h.off_rrr_stream = off; off = align_up(off + (rrr_words + 2) * 8, 256);
-    h.off_binom = off; off = align_up(off + (n_rrr_sb ? 64 * 64 * 8 : 0), 256);
-    h.total_bytes = off;
+    layout_blob(h);
     VLG_HIP_TRY(hipMalloc(&idx->d_blob, h.total_bytes));
     idx->owns_blob = true;
     uint8_t* b = reinterpret_cast<uint8_t*>(idx->d_blob);
@@ -388,6 +407,8 @@ extern "C" vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* i
     info->hbm_bytes = h.total_bytes;
     info->pos_bytes = h.sample_bytes;
     info->bv_kind = (uint32_t)h.bv_kind;
+    info->sampling = h.sampling;
+    info->reserved = 0;
     return VLG_OK;
 }
 
@@ -580,6 +601,7 @@ extern "C" vlg_status vlg_index_compress(const vlg_index* src, int kind, vlg_ind
     *out = nullptr;
     if (kind != VLG_BV_RRR63) return fail(VLG_E_INVALID, "unknown bit-vector kind");
     if (src->hdr.bv_kind != kBvPlain) return fail(VLG_E_INVALID, "source index must use plain bit-vectors");
+    if (src->hdr.sampling != kSamplingSaOrder) return fail(VLG_E_INVALID, "compress the SA-order index first, then resample it (vlg_index_resample)");
     vlg_index* idx = new vlg_index();
     idx->tree = src->tree;
     HostTree& t = idx->tree;
@@ -647,6 +669,189 @@ extern "C" vlg_status vlg_index_compress(const vlg_index* src, int kind, vlg_ind
     vlg_status st = run();
     if (st) { vlg_index_destroy(idx); return st; }
     *out = idx;
+    return VLG_OK;
+}
+
+// =============================================================================================
+// SA sampling strategies: vlg_index_resample makes a second index over the same BWT with another sample density
+// and / or text_order_sa_sampling (include/sdsl/csa_sampling_strategy.hpp:127-246: the SA values that are multiples of dens, found
+// through a marked bit-vector over the SA indices) instead of sa_order_sa_sampling (:64-112: every dens-th SA index).
+// =============================================================================================
+namespace {
+
+// every SA value from the SA-order samples: a lane starts at one sample (i, SA[i]) and walks LF -- (LF(i), SA[i] - 1) -- up to the next
+// sampled index, so that every SA index is visited exactly once with its value
+template <class BV, typename sample_t>
+__global__ void __launch_bounds__(256) sa_expand_kernel(IndexView iv, uint32_t* __restrict__ sa)
+{
+    __shared__ WalkLds<BV> s;
+    stage_walk(s, iv);
+    const sample_t* samples = reinterpret_cast<const sample_t*>(iv.samples);
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < iv.n_samples; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t i = j * iv.dens, v = samples[j];
+        do {
+            sa[i] = (uint32_t)v;
+            uint32_t node = 0, c = 0;
+            uint64_t pos = i;
+            if (iv.sigma > 1) {
+                for (;;) {                                       // inverse_select: wt_pc.hpp:385-402
+                    const DNode nd = s.nodes[node];
+                    uint32_t bit;
+                    uint64_t r1;
+                    BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
+                    pos = bit ? r1 : pos - r1;
+                    const uint32_t ch = nd.child[bit];
+                    if (ch & kLeafFlag) { c = ch & ~kLeafFlag; break; }
+                    node = ch;
+                }
+                i = s.C[c] + pos;                                // LF
+            } else i = 0;
+            v = v ? v - 1 : iv.n - 1;
+        } while (i % iv.dens);
+    }
+}
+
+// marks of one super-block: bit = (SA[i] % dens == 0); pops[b] = its ones
+__global__ void marked_pack_kernel(const uint32_t* __restrict__ sa, uint64_t n, uint32_t dens, Block* __restrict__ blocks, uint64_t nb,
+                                   uint32_t* __restrict__ pops)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
+        Block B;
+        uint32_t pc = 0;
+        for (uint32_t w = 0; w < 7; ++w) {
+            uint32_t word = 0;
+            const uint64_t first = b * kBlockBits + 32ull * w;
+            for (uint32_t j = 0; j < 32 && first + j < n; ++j) word |= (sa[first + j] % dens == 0 ? 1u : 0u) << j;
+            B.w[w] = word;
+            pc += __popc(word);
+        }
+        B.cnt = 0;
+        blocks[b] = B;
+        pops[b] = pc;
+    }
+}
+__global__ void marked_counts_kernel(Block* __restrict__ blocks, const uint32_t* __restrict__ before, uint64_t nb)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) blocks[b].cnt = before[b];
+}
+// samples[rank_marked(i)] = SA[i] / dens for the marked i (csa_sampling_strategy.hpp:158-164)
+__global__ void text_order_samples_kernel(const uint32_t* __restrict__ sa, uint64_t n, uint32_t dens, const Block* __restrict__ blocks,
+                                          uint32_t* __restrict__ samples)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = sa[i];
+        if (v % dens) continue;
+        const uint64_t blk = i / kBlockBits;
+        const uint32_t off = (uint32_t)(i - blk * kBlockBits);
+        const Block& B = blocks[blk];
+        uint32_t r = B.cnt;
+        for (uint32_t w = 0; w < (off >> 5); ++w) r += __popc(B.w[w]);
+        if (off & 31) r += __popc(B.w[off >> 5] & ((1u << (off & 31)) - 1u));
+        samples[r] = v / dens;
+    }
+}
+__global__ void sa_order_samples_kernel(const uint32_t* __restrict__ sa, uint64_t n_samples, uint32_t dens, uint32_t* __restrict__ samples)
+{
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_samples; j += (uint64_t)gridDim.x * blockDim.x) samples[j] = sa[j * dens];
+}
+// marks as plain words (bit i = word[i >> 6] >> (i & 63)), for export
+__global__ void marked_words_kernel(const Block* __restrict__ blocks, uint64_t n, uint64_t* __restrict__ out, uint64_t n_words)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_words; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t word = 0;
+        for (uint32_t j = 0; j < 64; ++j) {
+            const uint64_t i = t * 64 + j;
+            if (i >= n) break;
+            const uint64_t blk = i / kBlockBits;
+            const uint32_t off = (uint32_t)(i - blk * kBlockBits);
+            word |= (uint64_t)((blocks[blk].w[off >> 5] >> (off & 31)) & 1u) << j;
+        }
+        out[t] = word;
+    }
+}
+
+}  // namespace
+
+extern "C" vlg_status vlg_index_resample(const vlg_index* src, int sampling, uint32_t dens, vlg_index** out)
+{
+    release_cached_device_memory();
+    if (!src || !out) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    if (sampling != VLG_SAMPLING_SA_ORDER && sampling != VLG_SAMPLING_TEXT_ORDER) return fail(VLG_E_INVALID, "unknown sampling strategy");
+    if (!dens) dens = 32;
+    if (src->hdr.sampling != kSamplingSaOrder) return fail(VLG_E_INVALID, "the source index must be sampled in SA order");
+    if (src->hdr.sample_bytes != 4) return fail(VLG_E_UNSUPPORTED, "resampling is built for n <= 2^32 (32-bit SA indices)");
+    const uint64_t n = src->hdr.n;
+    vlg_index* idx = new vlg_index();
+    idx->tree = src->tree;
+    hipStream_t stream = nullptr;
+    auto run = [&]() -> vlg_status {
+        DevBuf d_sa, d_pops, d_tmp;
+        VLG_HIP_TRY(d_sa.alloc(n * 4));
+        const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((src->view.n_samples + 255) / 256, 8192)));
+        if (src->view.bv_kind == kBvRrr63) hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_expand_kernel<RrrBV, uint32_t>), grid, dim3(256), 0, stream, src->view, d_sa.as<uint32_t>());
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_expand_kernel<PlainBV, uint32_t>), grid, dim3(256), 0, stream, src->view, d_sa.as<uint32_t>());
+        VLG_HIP_TRY(hipGetLastError());
+        BlobHeader& h = idx->hdr;
+        h = src->hdr;
+        h.dens = dens;
+        h.sampling = (uint32_t)sampling;
+        h.n_samples = (n + dens - 1) / dens;
+        layout_blob(h);
+        VLG_HIP_TRY(hipMalloc(&idx->d_blob, h.total_bytes));
+        idx->owns_blob = true;
+        uint8_t* b = reinterpret_cast<uint8_t*>(idx->d_blob);
+        const uint8_t* sb = reinterpret_cast<const uint8_t*>(src->d_blob);
+        VLG_HIP_TRY(hipMemcpyAsync(b, &h, sizeof h, hipMemcpyHostToDevice, stream));
+        BlobSection sec[11], old[11];
+        blob_sections(h, sec);
+        blob_sections(src->hdr, old);
+        for (int i = 0; i < 11; ++i) {
+            if (sec[i].off == &BlobHeader::off_samples || sec[i].off == &BlobHeader::off_marked || !sec[i].bytes) continue;
+            if (old[i].bytes != sec[i].bytes) return fail(VLG_E_INTERNAL, "blob sections changed size");
+            VLG_HIP_TRY(hipMemcpyAsync(b + h.*(sec[i].off), sb + src->hdr.*(old[i].off), sec[i].bytes, hipMemcpyDeviceToDevice, stream));
+        }
+        uint32_t* samples = reinterpret_cast<uint32_t*>(b + h.off_samples);
+        if (sampling == VLG_SAMPLING_SA_ORDER) {
+            hipLaunchKernelGGL(sa_order_samples_kernel, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((h.n_samples + 255) / 256, 8192))), dim3(256), 0, stream,
+                               d_sa.as<uint32_t>(), h.n_samples, dens, samples);
+        } else {
+            const uint64_t nb = n / kBlockBits + 1;
+            Block* mk = reinterpret_cast<Block*>(b + h.off_marked);
+            VLG_HIP_TRY(d_pops.alloc((nb + 1) * 4));
+            const dim3 gb((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((nb + 255) / 256, 8192)));
+            hipLaunchKernelGGL(marked_pack_kernel, gb, dim3(256), 0, stream, d_sa.as<uint32_t>(), n, dens, mk, nb, d_pops.as<uint32_t>());
+            size_t tb = 0;
+            VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_pops.as<uint32_t>(), d_pops.as<uint32_t>(), 0u, nb, rocprim::plus<uint32_t>(), stream));
+            VLG_HIP_TRY(d_tmp.alloc(tb + 16));
+            VLG_HIP_TRY(rocprim::exclusive_scan(d_tmp.p, tb, d_pops.as<uint32_t>(), d_pops.as<uint32_t>(), 0u, nb, rocprim::plus<uint32_t>(), stream));
+            hipLaunchKernelGGL(marked_counts_kernel, gb, dim3(256), 0, stream, mk, d_pops.as<uint32_t>(), nb);
+            VLG_HIP_TRY(hipMemsetAsync(samples, 0, h.n_samples * 4, stream));
+            hipLaunchKernelGGL(text_order_samples_kernel, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 16384))), dim3(256), 0, stream,
+                               d_sa.as<uint32_t>(), n, dens, mk, samples);
+        }
+        VLG_HIP_TRY(hipGetLastError());
+        VLG_HIP_TRY(hipStreamSynchronize(stream));
+        bind_view(idx);
+        return VLG_OK;
+    };
+    const vlg_status st = run();
+    if (st) { vlg_index_destroy(idx); return st; }
+    *out = idx;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_index_export_marked(const vlg_index* idx, uint64_t* h_words)
+{
+    if (!idx || !h_words) return fail(VLG_E_INVALID, "null argument");
+    if (idx->hdr.sampling != kSamplingTextOrder) return fail(VLG_E_INVALID, "the index is not sampled in text order");
+    const uint64_t n = idx->hdr.n, nw = (n + 63) / 64;
+    DevBuf d;
+    VLG_HIP_TRY(d.alloc(nw * 8));
+    hipLaunchKernelGGL(marked_words_kernel, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((nw + 255) / 256, 8192))), dim3(256), 0, nullptr, idx->view.marked, n,
+                       d.as<uint64_t>(), nw);
+    VLG_HIP_TRY(hipGetLastError());
+    VLG_HIP_TRY(hipMemcpy(h_words, d.p, nw * 8, hipMemcpyDeviceToHost));
     return VLG_OK;
 }
 

@@ -444,7 +444,7 @@ __device__ __forceinline__ void block_add(unsigned long long (&v)[N], unsigned l
 // kWide: SA indices need 33 bits and the samples are 64-bit words (n > 2^32, or VLG_FORCE_POS64); the positions written may still be
 // 32-bit (pos_t) when the text has at most 2^32 characters -- only the tail mode can split the two, the in-place mode keeps the SA
 // index in io[] itself.
-template <typename pos_t, class BV, bool kTail = false, bool kWide = (sizeof(pos_t) == 8)>
+template <typename pos_t, class BV, bool kTail = false, bool kWide = (sizeof(pos_t) == 8), bool kTextOrder = false>
 __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __restrict__ io, uint64_t total, uint32_t per_wave,
                                                      unsigned long long* __restrict__ stats /* [2]: lf steps, levels */,
                                                      const uint64_t* __restrict__ val = nullptr, uint32_t step = 0,
@@ -461,11 +461,9 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint64_t next = wave * per_wave;                       // wave-uniform cursor into the slice
     const uint64_t slice_end = next + per_wave < total ? next + per_wave : total;
-    const uint32_t dens = iv.dens;
-    const bool pow2 = (dens & (dens - 1)) == 0;
-    const uint32_t dmask = dens - 1;
-    const uint32_t dshift = 31 - __clz(dens);
-    const sample_t* samples = reinterpret_cast<const sample_t*>(iv.samples);
+    static_assert(!kTextOrder || !kWide, "text-order sampling is built for n <= 2^32");
+    using Sampling = typename std::conditional<kTextOrder, TextOrderSampling, SaOrderSampling<sample_t>>::type;
+    const Sampling sampling(iv);
 
     uint64_t t = 0;          // slot being worked on
     uint64_t i = 0;          // SA index at the root, node-relative index below it
@@ -492,10 +490,9 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
         }
         if (!__any(active)) break;
         if (active) {
-            bool sampled = pow2 ? ((i & dmask) == 0) : (i % dens == 0);
-            if (v == 0 && sampled) {                       // csa_sampling_strategy.hpp:102-111
-                uint64_t q = pow2 ? (i >> dshift) : (i / dens);
-                uint64_t r = (uint64_t)samples[q] + off;
+            uint64_t sv = 0;
+            if (v == 0 && sampling.probe(i, sv)) {         // csa_sampling_strategy.hpp:102-111 / :185-194
+                uint64_t r = sv + off;
                 if (r >= iv.n) r -= iv.n;                  // csa_wt.hpp:343-347
                 if (kTail && rec) rec[slot0 + t] = r;
                 else io[t] = (pos_t)r;
@@ -614,7 +611,7 @@ __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t
 // element that arrives there later has the same future, so it stops and records (that element, steps apart) in rec -- or,
 // when that element has a record already, the record one hop further.  rec[slot]: a position (high bits 0), or
 // delta << kShift | slot of the element it follows; ~0 while the element is still walking.  slot0 = first slot of the sweep.
-template <class BV, typename pos_t, bool kTrail, bool kWide>
+template <class BV, typename pos_t, bool kTrail, bool kWide, bool kTextOrder>
 __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count,
                                                          uint32_t step, pos_t* __restrict__ out,
                                                          unsigned long long* __restrict__ stats /* lf, levels */,
@@ -623,22 +620,19 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
 {
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
-    const uint32_t dens = iv.dens;
-    const bool pow2 = (dens & (dens - 1)) == 0;
-    const uint32_t dmask = dens - 1;
-    const uint32_t dshift = 31 - __clz(dens);
+    static_assert(!kTextOrder || !kWide, "text-order sampling is built for n <= 2^32");
     using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
-    const sample_t* samples = reinterpret_cast<const sample_t*>(iv.samples);
+    using Sampling = typename std::conditional<kTextOrder, TextOrderSampling, SaOrderSampling<sample_t>>::type;
+    const Sampling sampling(iv);
     constexpr uint32_t kShift = kWide ? 33 : 32;
     constexpr uint64_t kPosMask = (1ull << kShift) - 1;
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t v64 = val[e];
         uint64_t i = v64 & kPosMask;
-        bool sampled = pow2 ? ((i & dmask) == 0) : (i % dens == 0);
-        if (sampled) {
-            uint64_t q = pow2 ? (i >> dshift) : (i / dens);
-            uint64_t r = (uint64_t)samples[q] + step;
+        uint64_t sv = 0;
+        if (sampling.probe(i, sv)) {
+            uint64_t r = sv + step;
             if (r >= iv.n) r -= iv.n;                        // csa_wt.hpp:343-347
             if (kTrail) rec[slot0 + (v64 >> kShift)] = r;
             else out[v64 >> kShift] = (pos_t)r;
@@ -808,12 +802,18 @@ vlg_status launch_locate(const IndexView& iv, pos_t* d_io, uint64_t total, unsig
     per_wave = std::min<uint64_t>(per_wave, 1u << 20);
     uint64_t waves = (total + per_wave - 1) / per_wave;
     uint64_t wgs = (waves + 3) / 4;
-    if (iv.bv_kind == kBvRrr63)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, RrrBV>), dim3((uint32_t)wgs), dim3(256), 0, stream, iv, d_io, total,
-                           (uint32_t)per_wave, d_stats);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, PlainBV>), dim3((uint32_t)wgs), dim3(256), 0, stream, iv, d_io, total,
-                           (uint32_t)per_wave, d_stats);
+    const bool rrr = iv.bv_kind == kBvRrr63, text_order = iv.sampling == kSamplingTextOrder;
+    if (iv.sample_bytes != sizeof(pos_t)) return fail(VLG_E_INTERNAL, "locate: sample width does not match the instantiation");
+    const dim3 grid((uint32_t)wgs);
+#define VLG_LOCATE(BV, TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, BV, false, (sizeof(pos_t) == 8), TO>), grid, dim3(256), 0, stream, iv, d_io, total, (uint32_t)per_wave, d_stats)
+    if constexpr (sizeof(pos_t) == 4) {
+        if (text_order) { if (rrr) VLG_LOCATE(RrrBV, true); else VLG_LOCATE(PlainBV, true); }
+        else { if (rrr) VLG_LOCATE(RrrBV, false); else VLG_LOCATE(PlainBV, false); }
+    } else {
+        if (text_order) return fail(VLG_E_UNSUPPORTED, "text-order sampling with 64-bit SA indices");
+        if (rrr) VLG_LOCATE(RrrBV, false); else VLG_LOCATE(PlainBV, false);
+    }
+#undef VLG_LOCATE
     VLG_HIP_TRY(hipGetLastError());
     return VLG_OK;
 }
@@ -846,6 +846,8 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     if (iv.n > (1ull << kShift)) return fail(VLG_E_UNSUPPORTED, "sorted sweep: text too long for the packed position");
     if (iv.sample_bytes != (kWide ? 8u : 4u)) return fail(VLG_E_INTERNAL, "sorted sweep: sample width does not match the instantiation");
     if (sizeof(pos_t) == 4 && iv.n > (1ull << 32) + 1) return fail(VLG_E_INTERNAL, "sorted sweep: positions do not fit 32 bits");
+    const bool rrr = iv.bv_kind == kBvRrr63, text_order = iv.sampling == kSamplingTextOrder;
+    if (kWide && text_order) return fail(VLG_E_UNSUPPORTED, "text-order sampling with 64-bit SA indices");
     const unsigned bits = bit_width64(iv.sigma);            // keys 0..sigma (sigma = finished, sorts last)
     const uint64_t batch_max = sweep_batch_max<kWide>();
     if (trail) VLG_HIP_TRY(hipMemsetAsync(rec, 0xFF, total * 8, stream));
@@ -871,17 +873,16 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
             if (timer) timer->begin(0);
             const dim3 grid(grid_for(alive, 4096));
-            if (iv.bv_kind == kBvRrr63) {
-                if (trail) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t, true, kWide>), grid, dim3(256), 0, stream, iv, val_a, key_a,
-                                              alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<RrrBV, pos_t, false, kWide>), grid, dim3(256), 0, stream, iv, val_a, key_a,
-                                        alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
+#define VLG_STEP(BV, TR, TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<BV, pos_t, TR, kWide, TO>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, step, out, d_stats, d_counter, trail, rec, t0, gen)
+#define VLG_STEP_BV(TR, TO) do { if (rrr) VLG_STEP(RrrBV, TR, TO); else VLG_STEP(PlainBV, TR, TO); } while (0)
+            if constexpr (!kWide) {
+                if (text_order) { if (trail) VLG_STEP_BV(true, true); else VLG_STEP_BV(false, true); }
+                else { if (trail) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false); }
             } else {
-                if (trail) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t, true, kWide>), grid, dim3(256), 0, stream, iv, val_a, key_a,
-                                              alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<PlainBV, pos_t, false, kWide>), grid, dim3(256), 0, stream, iv, val_a, key_a,
-                                        alive, step, out, d_stats, d_counter, trail, rec, t0, gen);
+                if (trail) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false);
             }
+#undef VLG_STEP_BV
+#undef VLG_STEP
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
             size_t tb = temp_bytes;
@@ -910,12 +911,14 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             const uint64_t waves = (alive + per_wave - 1) / per_wave;
             const dim3 grid((uint32_t)((waves + 3) / 4));
             if (timer) timer->begin(0);
-            if (iv.bv_kind == kBvRrr63)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, RrrBV, true, kWide>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave,
-                                   d_stats, val_a, step, trail ? rec : nullptr, t0, trail, gen);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, PlainBV, true, kWide>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave,
-                                   d_stats, val_a, step, trail ? rec : nullptr, t0, trail, gen);
+#define VLG_TAIL(BV, TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, BV, true, kWide, TO>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave, d_stats, val_a, step, trail ? rec : nullptr, t0, trail, gen)
+            if constexpr (!kWide) {
+                if (text_order) { if (rrr) VLG_TAIL(RrrBV, true); else VLG_TAIL(PlainBV, true); }
+                else { if (rrr) VLG_TAIL(RrrBV, false); else VLG_TAIL(PlainBV, false); }
+            } else {
+                if (rrr) VLG_TAIL(RrrBV, false); else VLG_TAIL(PlainBV, false);
+            }
+#undef VLG_TAIL
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
         }
@@ -1032,6 +1035,7 @@ extern "C" vlg_status vlg_index_isa_samples(const vlg_index* idx, uint32_t inv_d
     if (!idx || !h_out || !inv_dens) return fail(VLG_E_INVALID, "null argument");
     const uint64_t n = idx->hdr.n;
     if (count != (n - 1) / inv_dens + 1) return fail(VLG_E_INVALID, "ISA sample count must be (n-1)/inv_dens + 1");
+    if (idx->hdr.sampling != kSamplingSaOrder) return fail(VLG_E_UNSUPPORTED, "ISA samples are computed from an SA-order index");
     uint64_t* d_out = nullptr;
     VLG_HIP_TRY(hipMalloc((void**)&d_out, count * 8));
     VLG_HIP_TRY(hipMemset(d_out, 0, count * 8));

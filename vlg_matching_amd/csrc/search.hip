@@ -1191,16 +1191,19 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
 namespace {
 
 // ---- distinct SA intervals of a batch, found on the device ----------------------------------------------------------------------
-// key of a sub-pattern: l << 32 | (occurrences - 1) (n <= 2^32), ~0 for the sub-patterns of a query that has an empty list
+// key of a sub-pattern: l << kbits | (occurrences - 1), ~0 for the sub-patterns of a query that has an empty list.  kbits = 64 - (bits
+// of the largest SA index): 32 for n <= 2^32, 31 for BASELINE config 4 (n = 2^32 + 1); an interval too long for its field raises
+// *overflow and the caller plans on the host instead.
 __global__ void interval_keys_kernel(const uint64_t* __restrict__ l, const uint64_t* __restrict__ r, const uint64_t* __restrict__ qsub,
-                                     uint64_t nq, uint64_t* __restrict__ keys, uint32_t* __restrict__ sub)
+                                     uint64_t nq, uint32_t kbits, uint64_t* __restrict__ keys, uint32_t* __restrict__ sub, uint32_t* __restrict__ overflow)
 {
     for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < nq; qi += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t a = qsub[qi], b = qsub[qi + 1];
         bool live = b > a;
         for (uint64_t s = a; s < b && live; ++s) live = r[s] + 1 - l[s] > 0;
         for (uint64_t s = a; s < b; ++s) {
-            keys[s] = live ? (l[s] << 32) | (r[s] - l[s]) : ~0ull;
+            if (live && ((r[s] - l[s]) >> kbits)) *overflow = 1;
+            keys[s] = live ? (l[s] << kbits) | (r[s] - l[s]) : ~0ull;
             sub[s] = (uint32_t)s;
         }
     }
@@ -1212,22 +1215,26 @@ __global__ void interval_heads_kernel(const uint64_t* __restrict__ keys, uint64_
 }
 // gid = inclusive scan of the heads: the (gid-1)-th distinct interval, in ascending SA order
 __global__ void interval_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ sub, const uint32_t* __restrict__ gid,
-                                        uint64_t n, uint32_t* __restrict__ did, uint64_t* __restrict__ dl, uint64_t* __restrict__ docc)
+                                        uint64_t n, uint32_t kbits, uint32_t* __restrict__ did, uint64_t* __restrict__ dl, uint64_t* __restrict__ docc)
 {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t k = keys[j];
         if (k == ~0ull) { did[sub[j]] = 0xFFFFFFFFu; continue; }
         const uint32_t g = gid[j] - 1;
         did[sub[j]] = g;
-        if (j == 0 || keys[j - 1] != k) { dl[g] = k >> 32; docc[g] = (k & 0xFFFFFFFFull) + 1; }
+        if (j == 0 || keys[j - 1] != k) { dl[g] = k >> kbits; docc[g] = (k & ((1ull << kbits) - 1)) + 1; }
     }
 }
 
 // Plan of a batch (which sub-patterns are live, which distinct interval each one is) from the intervals in d_l / d_r.
 // Identical SA intervals are the same occurrence list: each distinct one is located + sorted once per super-chunk and shared.
 // The distinct intervals are numbered in ascending SA order, so the sweep that locates them starts globally sorted.
-vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_t* d_l, const uint64_t* d_r, Plan& pl, uint64_t& logical)
+// *fallback is set (and nothing planned) when an interval does not fit its key field: the caller then plans on the host.
+vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_t* d_l, const uint64_t* d_r, uint64_t n, Plan& pl, uint64_t& logical,
+                          bool* fallback)
 {
+    *fallback = false;
+    const uint32_t kbits = 64 - std::max(32u, bit_width64(n - 1));
     hipStream_t st = ws->stream;
     const uint64_t nsub = q->nsub, nq = q->nq;
     pl.occ.assign(nsub, 0);
@@ -1243,7 +1250,7 @@ vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_
         VLG_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_tb, nu, nu, nsub, rocprim::plus<uint32_t>(), st));
     }
     const uint64_t n8 = align_up(nsub * 8, 256), n4 = align_up(nsub * 4, 256);
-    const uint64_t bytes = 4 * n8 + 5 * n4 + align_up((nq + 1) * 8, 256) + align_up(std::max(sort_tb, scan_tb), 256) + 1024;
+    const uint64_t bytes = 4 * n8 + 5 * n4 + align_up((nq + 1) * 8, 256) + align_up(std::max(sort_tb, scan_tb), 256) + 1024 + 256;
     VLG_HIP_TRY(hipMalloc((void**)&mem, bytes));
     uint64_t* keys_a = (uint64_t*)mem;
     uint64_t* keys_b = (uint64_t*)(mem + n8);
@@ -1256,10 +1263,12 @@ vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_
     uint32_t* d_did = (uint32_t*)(mem + 4 * n8 + 4 * n4);
     uint64_t* d_qsub = (uint64_t*)(mem + 4 * n8 + 5 * n4);
     void* d_tmp = mem + 4 * n8 + 5 * n4 + align_up((nq + 1) * 8, 256);
+    uint32_t* d_overflow = (uint32_t*)(mem + bytes - 256);
     auto run = [&]() -> vlg_status {
+        VLG_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, st));
         svec<uint64_t> h_qsub(q->qsub.begin(), q->qsub.end());
         VLG_HIP_TRY(hipMemcpyAsync(d_qsub, h_qsub.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(interval_keys_kernel, dim3(grid_for(nq, 2048)), dim3(256), 0, st, d_l, d_r, d_qsub, nq, keys_a, sub_a);
+        hipLaunchKernelGGL(interval_keys_kernel, dim3(grid_for(nq, 2048)), dim3(256), 0, st, d_l, d_r, d_qsub, nq, kbits, keys_a, sub_a, d_overflow);
         rocprim::double_buffer<uint64_t> dk(keys_a, keys_b);
         rocprim::double_buffer<uint32_t> dv(sub_a, sub_b);
         size_t tb = sort_tb;
@@ -1267,14 +1276,16 @@ vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_
         hipLaunchKernelGGL(interval_heads_kernel, dim3(grid_for(nsub, 2048)), dim3(256), 0, st, dk.current(), nsub, d_head);
         tb = scan_tb;
         VLG_HIP_TRY(rocprim::inclusive_scan(d_tmp, tb, d_head, d_gid, nsub, rocprim::plus<uint32_t>(), st));
-        hipLaunchKernelGGL(interval_scatter_kernel, dim3(grid_for(nsub, 2048)), dim3(256), 0, st, dk.current(), dv.current(), d_gid, nsub, d_did,
+        hipLaunchKernelGGL(interval_scatter_kernel, dim3(grid_for(nsub, 2048)), dim3(256), 0, st, dk.current(), dv.current(), d_gid, nsub, kbits, d_did,
                            d_dl, d_docc);
         VLG_HIP_TRY(hipGetLastError());
-        uint32_t nd = 0;
+        uint32_t nd = 0, overflow = 0;
         svec<uint32_t> h_did(nsub);
+        VLG_HIP_TRY(hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, st));
         VLG_HIP_TRY(hipMemcpyAsync(&nd, d_gid + (nsub - 1), 4, hipMemcpyDeviceToHost, st));
         VLG_HIP_TRY(hipMemcpyAsync(h_did.data(), d_did, nsub * 4, hipMemcpyDeviceToHost, st));
         VLG_HIP_TRY(hipStreamSynchronize(st));
+        if (overflow) { *fallback = true; return VLG_OK; }
         pl.dl.resize(nd);
         pl.docc.resize(nd);
         if (nd) {
@@ -1326,10 +1337,13 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         }
         tr.mark("backward search");
         Plan pl;
-        const bool device_plan = ws->dedup && idx->hdr.n <= (1ull << 32) && nsub > 0 && nsub < 0xFFFFFFF0ull;
+        bool device_plan = ws->dedup && idx->hdr.n <= (1ull << 33) && nsub > 0 && nsub < 0xFFFFFFF0ull;
         if (device_plan) {
-            if (vlg_status s = plan_on_device(q, ws, d_l, d_r, pl, res->sum.logical_occurrences)) return s;
-        } else {
+            bool fallback = false;
+            if (vlg_status s = plan_on_device(q, ws, d_l, d_r, idx->hdr.n, pl, res->sum.logical_occurrences, &fallback)) return s;
+            if (fallback) { device_plan = false; pl = Plan(); res->sum.logical_occurrences = 0; }
+        }
+        if (!device_plan) {
         svec<uint64_t> l(nsub), r(nsub);
         if (nsub) {
             VLG_HIP_TRY(hipMemcpyAsync(l.data(), d_l, nsub * 8, hipMemcpyDeviceToHost, st));

@@ -286,6 +286,19 @@ class VlgIndex:
         check(lib().vlg_index_compress(self._h, bv_kind, C.byref(h)))
         return VlgIndex(h)
 
+    def resample(self, text_order=True, dens=32):
+        """A second index over the same BWT with text_order_sa_sampling (or SA-order sampling of another density); same answers."""
+        h = C.c_void_p()
+        check(lib().vlg_index_resample(self._h, 1 if text_order else 0, int(dens), C.byref(h)))
+        return VlgIndex(h)
+
+    def marked(self):
+        """text-order sampling: the marks over the SA indices -> uint8 array of n zeros / ones"""
+        n = self.info()["n"]
+        w = np.zeros((n + 63) // 64, dtype=np.uint64)
+        check(lib().vlg_index_export_marked(self._h, w.ctypes.data))
+        return np.unpackbits(w.view(np.uint8), bitorder="little")[:n]
+
     def export_parts(self):
         sz = capi.IndexParts()
         check(lib().vlg_index_export_parts(self._h, C.byref(sz), None))
