@@ -127,6 +127,7 @@ vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_parts* sizes, 
  * csa_wt<wt_huff<>> format only): an rrr index is always made here, from a plain one.  `src` must be a plain index. */
 #define VLG_BV_PLAIN 0
 #define VLG_BV_RRR63 1
+#define VLG_BV_INT_MATRIX 2          /* integer-alphabet index (vlg_index_build_int): bv_kind of vlg_index_info */
 vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out);
 /* The other SA sampling strategy of the reference, and other densities: a second index over the same BWT whose SA samples are
  *   VLG_SAMPLING_SA_ORDER    SA[0], SA[d], SA[2d], ...                   sa_order_sa_sampling, csa_wt's default
@@ -142,6 +143,19 @@ vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out
 vlg_status vlg_index_resample(const vlg_index* src, int sampling, uint32_t sa_sample_dens, vlg_index** out);
 vlg_status vlg_index_export_marked(const vlg_index* idx, uint64_t* h_words);
 vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* info);
+
+/* FM-index of an INTEGER text -- csa_wt<wt_int<>, dens, ., sa_order_sa_sampling, ., int_alphabet<>>, the csa the reference builds for
+ * vlg_index<int_alphabet_tag> (include/sdsl/vlg_index.hpp:383-384) and its word-level experiments: int_alphabet
+ * (include/sdsl/csa_alphabet_strategy.hpp:394-470), BWT in a level-wise tree (wt_int.hpp; here a wavelet matrix over the compact
+ * symbols: one super-block read per level), LF / csa[i] / backward_search as for bytes.  h_text: n_symbols uint32_t, none of them 0
+ * (VLG_E_ZERO_BYTE: construct.hpp:36-45); n_symbols < 2^32 / 5.  The handle is a vlg_index: vlg_search_batch (with a batch parsed
+ * by vlg_queries_parse_int), vlg_queries_intervals / _occurrences, vlg_backward_search_batch (patterns = little-endian uint32_t
+ * symbols), vlg_sa_batch, vlg_locate_batch, blob export / attach / broadcast take it; the byte-only entry points refuse it. */
+vlg_status vlg_index_build_int(const uint32_t* h_text, uint64_t n_symbols, uint32_t sa_sample_dens, vlg_index** out);
+/* int_alphabet of such an index: *sigma symbols (comp 0 = the sentinel), h_C[sigma + 1], h_comp2char[sigma]; null buffers: sigma only */
+vlg_status vlg_index_export_int_alphabet(const vlg_index* idx, uint64_t* sigma, uint64_t* h_C, uint64_t* h_comp2char);
+/* wt_int::rank(i, c) (include/sdsl/wt_int.hpp:370-395) on its BWT: out[j] = #d_sym[j] in BWT[0, d_i[j]) */
+vlg_status vlg_int_rank_batch(const vlg_index* idx, const uint64_t* d_i, const uint32_t* d_sym, uint64_t* d_out, uint64_t count, void* stream);
 void vlg_index_destroy(vlg_index* idx);
 
 /* Suffix array of text + sentinel on the device (what sdsl::construct_sa computes, include/sdsl/construct_sa.hpp:145-170): d_sa

@@ -1180,3 +1180,122 @@ def test_text_order_sa_sampling(torch_cuda, V, oracle, name, dens):
     assert att.info()["sampling"] == 1
     r2 = att.search(qs)
     assert (r2.counts == ref.counts).all() and r2.summary["checksum"] == ref.summary["checksum"]
+
+
+def _int_texts():
+    rng = np.random.default_rng(31)
+    return {
+        "survey": np.array([5, 6, 7, 5, 6, 7, 1000, 5], dtype=np.uint32),
+        "abra": np.frombuffer(b"abracadabrasimsalabim", dtype=np.uint8).astype(np.uint32),
+        "sparse": rng.choice(np.array([3, 7, 7, 19, 1000, 70000, 2 ** 31 + 5], dtype=np.uint32), 5000),
+        "words": (1 + rng.zipf(1.3, 20000) % 3000).astype(np.uint32),          # word-level text: large alphabet, Zipf frequencies
+        "one": np.array([42], dtype=np.uint32),
+        "run": np.full(300, 9, dtype=np.uint32),
+    }
+
+
+def _int_queries(text, rng, nq, kmax=3, mmax=3, gapmax=40):
+    t = text.tolist()
+    qs = []
+    for _ in range(nq):
+        k = int(rng.integers(1, kmax + 1))
+        subs = [t[s:s + int(rng.integers(1, mmax + 1))] for s in rng.integers(0, max(len(t) - mmax, 1), k)]
+        q = " ".join(map(str, subs[0]))
+        for sp in subs[1:]:
+            a = int(rng.integers(0, 10))
+            q += " .{%d,%d}? %s" % (a, a + int(rng.integers(0, gapmax)), " ".join(map(str, sp)))
+        qs.append(q)
+    return qs
+
+
+@pytest.mark.parametrize("name", ["survey", "abra", "sparse", "words", "one", "run"])
+def test_integer_alphabet_fm_index(torch_cuda, V, oracle, name):
+    """csa_wt<wt_int<>, 32, ., ., ., int_alphabet<>> on the device (vlg_index_build_int) against its restatement in the
+    reference's layout (oracle/vlg_oracle_int.c, pinned by the reference's own wt_int<> / int_alphabet<>): alphabet, wt_int::rank
+    for present and absent symbols, csa[i] for every i, backward_search intervals, and the tuples of the whole path -- which must
+    also equal the paper's index (vlg_wtsa_*) on the same text."""
+    torch = torch_cuda
+    from vlg_matching_amd.index import Queries, WtsaIndex
+    text = _int_texts()[name]
+    o = oracle.IntIndex(text.astype(np.uint64), dens=32)
+    idx = V.VlgIndex.build_int(text)
+    info = idx.info()
+    assert info["n"] == len(text) + 1 and info["bv_kind"] == 2 and info["pos_bytes"] == 4
+    Cc, c2c = idx.int_alphabet()
+    assert Cc.tolist() == o.C().tolist() and c2c.tolist() == o.comp2char().tolist()
+    rng = np.random.default_rng(12)
+    L = V.lib()
+    m = 600
+    syms = np.concatenate([rng.choice(text, m - 6), np.array([1, 2, 4, 123456, 2 ** 32 - 1, int(text[0])], dtype=np.uint32)]).astype(np.uint32)
+    pos = rng.integers(0, o.n + 1, m).astype(np.uint64)
+    d_p, d_s = dev_u64(torch, pos), torch.from_numpy(syms.view(np.int32)).cuda()
+    d_o = torch.zeros(m, dtype=torch.int64, device="cuda")
+    V.capi.check(L.vlg_int_rank_batch(idx._h, d_p.data_ptr(), d_s.data_ptr(), d_o.data_ptr(), m, None))
+    torch.cuda.synchronize()
+    assert host_u64(d_o).tolist() == [o.rank(int(i), int(c)) for i, c in zip(pos, syms)]
+    tz = np.concatenate([text.astype(np.int64), [0]])
+    sa = np.array(sorted(range(len(tz)), key=lambda i: tz[i:].tolist()), dtype=np.uint64) if len(tz) <= 6000 else \
+        np.array([o.sa(i) for i in range(o.n)], dtype=np.uint64)
+    d_i = dev_u64(torch, np.arange(o.n, dtype=np.uint64))
+    d_v = torch.zeros_like(d_i)
+    V.capi.check(L.vlg_sa_batch(idx._h, d_i.data_ptr(), d_v.data_ptr(), o.n, None))
+    torch.cuda.synchronize()
+    assert (host_u64(d_v) == sa).all()
+    qs = _int_queries(text, rng, 120) + ["%d .{0,5}? 999999" % int(text[0]), "999999", "%d" % int(text[-1])]
+    l, r, q = idx.intervals(qs)
+    # sub-pattern intervals in batch order
+    import re
+    pats = []
+    for qq in qs:
+        for part in re.split(r"\.\{\d+,\d+\}\?", qq):
+            pats.append([int(x) for x in part.split()])
+    assert len(pats) == len(l)
+    for p, a, b in zip(pats, l, r):
+        cnt, ol, orr = o.backward_search(p)
+        assert int(b) + 1 - int(a) == cnt, p
+        if cnt:
+            assert (int(a), int(b)) == (ol, orr), p
+    res = idx.search(qs)
+    want = [o.search(qq).tolist() for qq in qs]
+    for i in range(len(qs)):
+        assert res.tuples(i).tolist() == want[i], qs[i]
+    assert res.summary["n_matches"] == sum(len(w) for w in want)
+    wres = WtsaIndex(text).search(qs)
+    for i in range(len(qs)):
+        assert wres.tuples(i).tolist() == want[i], qs[i]
+    # LF-step parity with the restated reference (no interval sharing: every occurrence walks to its own sample)
+    from vlg_matching_amd.index import Workspace
+    ws = Workspace()
+    ws.set_option("dedup", 0)
+    st = np.zeros(4, dtype=np.uint64)
+    for qq in qs:
+        o.search(qq, stats=st)
+    r2 = idx.search(qs, workspace=ws)
+    assert r2.summary["located_occurrences"] == int(st[0]) and r2.summary["lf_steps"] == int(st[1])
+    # the image travels like a byte index's
+    blob = torch.empty(idx.blob_bytes(), dtype=torch.uint8, device="cuda")
+    idx.blob_export(blob.data_ptr(), blob.numel())
+    att = V.VlgIndex.attach_blob(blob.data_ptr(), blob.numel(), keep=blob)
+    r3 = att.search(qs)
+    assert (r3.counts == res.counts).all() and r3.summary["checksum"] == res.summary["checksum"]
+
+
+def test_integer_alphabet_fm_index_known_answers_and_refusals(V):
+    gold = json.load(open(GOLD))
+    for case in gold["int_cases"]:
+        idx = V.VlgIndex.build_int(np.array(case["int_text"], dtype=np.uint32))
+        r = idx.search([case["query"]])
+        assert r.tuples(0).tolist() == case["tuples"], case
+    with pytest.raises(V.VlgError) as e:
+        V.VlgIndex.build_int(np.array([4, 0, 4], dtype=np.uint32))                 # construct.hpp:36-45: a 0 symbol is refused
+    assert e.value.status == V.capi.E_ZERO_BYTE
+    idx = V.VlgIndex.build_int(np.array([5, 6, 7, 5], dtype=np.uint32))
+    from vlg_matching_amd.index import Queries
+    with pytest.raises(V.VlgError):
+        idx.search(Queries(["ab.{0,3}?c"]))                                       # a byte batch on an integer index
+    with pytest.raises(V.VlgError):
+        V.VlgIndex.build(b"abcabc").search(Queries.from_int(["5 6"]))             # and the other way round
+    with pytest.raises(V.VlgError):
+        idx.compress()
+    with pytest.raises(V.VlgError):
+        idx.export_parts()

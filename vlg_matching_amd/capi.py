@@ -72,6 +72,9 @@ SYMBOLS = [
     ("vlg_index_resample", _I, [_P, _I, C.c_uint32, C.POINTER(_P)]),
     ("vlg_index_export_marked", _I, [_P, _P]),
     ("vlg_index_get_info", _I, [_P, C.POINTER(IndexInfo)]),
+    ("vlg_index_build_int", _I, [_P, _U64, C.c_uint32, C.POINTER(_P)]),
+    ("vlg_index_export_int_alphabet", _I, [_P, C.POINTER(_U64), _P, _P]),
+    ("vlg_int_rank_batch", _I, [_P, _P, _P, _P, _U64, _P]),
     ("vlg_index_destroy", None, [_P]),
     ("vlg_sdsl_file_open", _I, [C.c_char_p, C.c_uint32, C.POINTER(_P)]),
     ("vlg_sdsl_file_parts", _I, [_P, C.POINTER(IndexParts)]),

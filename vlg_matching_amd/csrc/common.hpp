@@ -87,6 +87,25 @@ struct IndexView {
     const struct RrrTables* rrr_tables;   // rrr_code.hpp
 };
 
+// ---- FM-index of an integer text (int_index.hpp): its own blob, recognised by its magic -------------------------------------
+constexpr uint64_t kIntBlobMagic = 0x3149474C56ULL;   // "VLGI1"
+struct IntHeader {
+    uint64_t magic, total_bytes;                      // (the first two words as in BlobHeader: what export / attach look at)
+    uint64_t n, sigma, n_samples, nb;                 // nb = super-blocks per level
+    uint32_t levels, dens;
+    uint64_t off_levels, off_Z, off_D, off_C, off_c2c, off_samples;
+};
+struct IntView {
+    const Block* levels;                              // [n_levels][nb] wavelet matrix of the BWT over compact symbols
+    const uint64_t* Z;                                // zeros per level
+    const uint64_t* D;                                // C[c] - first position of c in the last arrangement
+    const uint64_t* C;                                // [sigma + 1]
+    const uint32_t* comp2char;                        // [sigma] ascending
+    const uint32_t* samples;                          // SA[0], SA[dens], ...
+    uint64_t n, nb, sigma, n_samples;
+    uint32_t n_levels, dens;
+};
+
 constexpr uint32_t kBvPlain = 0, kBvRrr63 = 1;
 constexpr uint32_t kSamplingSaOrder = 0, kSamplingTextOrder = 1;
 constexpr uint32_t kRrrBlockBits = 63, kRrrBlocksPerSuper = 32, kRrrSuperBits = 63 * 32;
@@ -173,4 +192,11 @@ struct vlg_index {
     vlg::BlobHeader hdr;
     vlg::IndexView view;
     vlg::HostTree tree;   // host copy (node table, C, ...) for export and planning
+    bool is_int = false;  // integer-alphabet FM-index (int_index.hpp): ihdr / iview are valid, hdr carries the generic fields only
+    vlg::IntHeader ihdr;
+    vlg::IntView iview;
 };
+
+namespace vlg {
+vlg_status attach_int_blob(const void* d_blob, uint64_t bytes, vlg_index* idx);   // int_index.hpp
+}

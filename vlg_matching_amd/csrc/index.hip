@@ -331,6 +331,7 @@ extern "C" vlg_status vlg_index_from_parts(const vlg_index_parts* p, vlg_index**
 extern "C" vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_parts* sizes, vlg_index_parts_out* out)
 {
     if (!idx || !sizes) return fail(VLG_E_INVALID, "null argument");
+    if (idx->is_int) return fail(VLG_E_UNSUPPORTED, "an integer-alphabet index has no byte-alphabet parts (vlg_index_export_int_alphabet gives its alphabet)");
     const BlobHeader& h = idx->hdr;
     if (h.bv_kind != kBvPlain && out && (out->bv_words || out->nodes))
         return fail(VLG_E_UNSUPPORTED, "exporting the bit-vector of an rrr-compressed index is not supported; export the plain index");
@@ -474,6 +475,7 @@ extern "C" vlg_status vlg_index_attach_blob(const void* d_blob, uint64_t bytes, 
     vlg_index* idx = new vlg_index();
     auto run = [&]() -> vlg_status {
         VLG_HIP_TRY(hipMemcpy(&idx->hdr, d_blob, sizeof(BlobHeader), hipMemcpyDeviceToHost));
+        if (idx->hdr.magic == kIntBlobMagic) return attach_int_blob(d_blob, bytes, idx);          // integer-alphabet index (int_index.hpp)
         const BlobHeader& h = idx->hdr;
         if (h.magic != kBlobMagic || h.total_bytes > bytes || h.n_nodes > kMaxNodes || h.sigma > 256)
             return fail(VLG_E_INVALID, "not a VLG index blob");
@@ -600,6 +602,7 @@ extern "C" vlg_status vlg_index_compress(const vlg_index* src, int kind, vlg_ind
     if (!src || !out) return fail(VLG_E_INVALID, "null argument");
     *out = nullptr;
     if (kind != VLG_BV_RRR63) return fail(VLG_E_INVALID, "unknown bit-vector kind");
+    if (src->is_int) return fail(VLG_E_UNSUPPORTED, "integer-alphabet indexes keep plain bit-vectors");
     if (src->hdr.bv_kind != kBvPlain) return fail(VLG_E_INVALID, "source index must use plain bit-vectors");
     if (src->hdr.sampling != kSamplingSaOrder) return fail(VLG_E_INVALID, "compress the SA-order index first, then resample it (vlg_index_resample)");
     vlg_index* idx = new vlg_index();
@@ -779,6 +782,7 @@ extern "C" vlg_status vlg_index_resample(const vlg_index* src, int sampling, uin
     *out = nullptr;
     if (sampling != VLG_SAMPLING_SA_ORDER && sampling != VLG_SAMPLING_TEXT_ORDER) return fail(VLG_E_INVALID, "unknown sampling strategy");
     if (!dens) dens = 32;
+    if (src->is_int) return fail(VLG_E_UNSUPPORTED, "resampling is built for byte-alphabet indexes");
     if (src->hdr.sampling != kSamplingSaOrder) return fail(VLG_E_INVALID, "the source index must be sampled in SA order");
     if (src->hdr.sample_bytes != 4) return fail(VLG_E_UNSUPPORTED, "resampling is built for n <= 2^32 (32-bit SA indices)");
     const uint64_t n = src->hdr.n;

@@ -961,6 +961,15 @@ vlg_status launch_narrow(const uint64_t* d_in, T* d_out, uint64_t count, hipStre
     return VLG_OK;
 }
 template vlg_status launch_narrow<uint32_t>(const uint64_t*, uint32_t*, uint64_t, hipStream_t);
+template <typename T>
+vlg_status launch_widen(const T* d_in, uint64_t* d_out, uint64_t count, hipStream_t stream)
+{
+    if (!count) return VLG_OK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(widen_kernel<T>), dim3(grid_for(count)), dim3(256), 0, stream, d_in, d_out, count);
+    VLG_HIP_TRY(hipGetLastError());
+    return VLG_OK;
+}
+template vlg_status launch_widen<uint32_t>(const uint32_t*, uint64_t*, uint64_t, hipStream_t);
 
 }  // namespace vlg
 
@@ -968,6 +977,7 @@ extern "C" vlg_status vlg_wt_rank_batch(const vlg_index* idx, const uint64_t* d_
                                         void* stream)
 {
     if (!idx || (count && (!d_i || !d_c || !d_out))) return fail(VLG_E_INVALID, "null argument");
+    if (idx->is_int) return fail(VLG_E_INVALID, "integer-alphabet index: use vlg_int_rank_batch");
     if (!count) return VLG_OK;
     if (idx->view.bv_kind == kBvRrr63)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(wt_rank_kernel<RrrBV>), dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream, idx->view, d_i, d_c,
@@ -983,6 +993,8 @@ extern "C" vlg_status vlg_backward_search_batch(const vlg_index* idx, const uint
                                                 uint64_t* d_l, uint64_t* d_r, void* stream)
 {
     if (!idx || (n_patterns && (!d_off || !d_l || !d_r))) return fail(VLG_E_INVALID, "null argument");
+    // (an integer-alphabet index takes patterns of little-endian uint32_t symbols, offsets in bytes)
+    if (idx->is_int) return launch_int_backward_search(idx->iview, d_blob, d_off, n_patterns, d_l, d_r, nullptr, (hipStream_t)stream);
     return launch_backward_search(idx->view, d_blob, d_off, n_patterns, d_l, d_r, nullptr, (hipStream_t)stream);
 }
 
@@ -998,7 +1010,7 @@ extern "C" vlg_status vlg_sa_batch(const vlg_index* idx, const uint64_t* d_i, ui
     uint32_t* tmp = nullptr;
     VLG_HIP_TRY(hipMalloc((void**)&tmp, count * 4));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(narrow_kernel<uint32_t>), dim3(grid_for(count)), dim3(256), 0, st, d_i, tmp, count);
-    vlg_status s2 = launch_locate<uint32_t>(idx->view, tmp, count, nullptr, st);
+    vlg_status s2 = idx->is_int ? launch_int_locate(idx->iview, tmp, count, nullptr, st) : launch_locate<uint32_t>(idx->view, tmp, count, nullptr, st);
     if (!s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(widen_kernel<uint32_t>), dim3(grid_for(count)), dim3(256), 0, st, tmp, d_out, count);
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(tmp);
@@ -1021,7 +1033,7 @@ extern "C" vlg_status vlg_locate_batch(const vlg_index* idx, const uint64_t* d_l
     uint32_t* tmp = nullptr;
     VLG_HIP_TRY(hipMalloc((void**)&tmp, total * 4));
     vlg_status s2 = launch_expand<uint32_t>(d_l, d_out_off, n_patterns, total, tmp, nullptr, st);
-    if (!s2) s2 = launch_locate<uint32_t>(idx->view, tmp, total, nullptr, st);
+    if (!s2) s2 = idx->is_int ? launch_int_locate(idx->iview, tmp, total, nullptr, st) : launch_locate<uint32_t>(idx->view, tmp, total, nullptr, st);
     if (!s2) hipLaunchKernelGGL(HIP_KERNEL_NAME(widen_kernel<uint32_t>), dim3(grid_for(total)), dim3(256), 0, st, tmp, d_out, total);
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(tmp);
@@ -1036,6 +1048,7 @@ extern "C" vlg_status vlg_index_isa_samples(const vlg_index* idx, uint32_t inv_d
     const uint64_t n = idx->hdr.n;
     if (count != (n - 1) / inv_dens + 1) return fail(VLG_E_INVALID, "ISA sample count must be (n-1)/inv_dens + 1");
     if (idx->hdr.sampling != kSamplingSaOrder) return fail(VLG_E_UNSUPPORTED, "ISA samples are computed from an SA-order index");
+    if (idx->is_int) return fail(VLG_E_UNSUPPORTED, "ISA samples of an integer-alphabet index are not built");
     uint64_t* d_out = nullptr;
     VLG_HIP_TRY(hipMalloc((void**)&d_out, count * 8));
     VLG_HIP_TRY(hipMemset(d_out, 0, count * 8));

@@ -32,5 +32,11 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
                                hipStream_t stream, LaunchTimer* timer, uint64_t* trail, uint64_t* rec, uint32_t* trail_gen,
                                const std::function<vlg_status()>* while_first_step = nullptr);
 template <typename T> vlg_status launch_narrow(const uint64_t* d_in, T* d_out, uint64_t count, hipStream_t stream);
+template <typename T> vlg_status launch_widen(const T* d_in, uint64_t* d_out, uint64_t count, hipStream_t stream);
+
+// integer-alphabet FM-index (int_index.hpp): backward_search over uint32_t symbols, csa[i] in place (n <= 2^32)
+vlg_status launch_int_backward_search(const IntView& v, const uint8_t* d_blob, const uint64_t* d_off, uint64_t n_pat, uint64_t* d_l, uint64_t* d_r,
+                                      unsigned long long* d_stat_levels, hipStream_t st);
+vlg_status launch_int_locate(const IntView& v, uint32_t* d_io, uint64_t total, unsigned long long* d_stats, hipStream_t st);
 
 }  // namespace vlg

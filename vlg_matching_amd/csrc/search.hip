@@ -491,7 +491,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     pc_cap = 0;
     ws->fences = nullptr;
     if (!acc) return VLG_OK;
-    const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (wide ? 33 : 32));
+    const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (wide ? 33 : 32)) && !idx->is_int;
     pos_t* Pa = A.take<pos_t>(acc);
     // scratch of the sweep (20 B per element); the sorted lists Pb reuse it once locate is done
     uint8_t* scratch = A.take<uint8_t>(acc * kPhysScratchPerElem<pos_t>());
@@ -539,6 +539,17 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         else s = fail(VLG_E_INTERNAL, "64-bit positions with 32-bit SA indices");
         if (s) return s;
         bt.mark("  physical: sweep");
+    } else if (idx->is_int) {
+        // integer-alphabet index (int_index.hpp): one lane per occurrence on the wavelet matrix of the BWT
+        if (vlg_status s = plan_sort()) return s;
+        if constexpr (sizeof(pos_t) == 4) {
+            {
+                Timed t(ws, KS_EXPAND, 0);
+                if (vlg_status s = launch_expand<uint32_t>(d_lh, d_off64, nd, acc, Pa, nullptr, st)) return s;
+            }
+            Timed t(ws, KS_LOCATE, 0);
+            if (vlg_status s = launch_int_locate(idx->iview, Pa, acc, d_stats, st)) return s;
+        } else return fail(VLG_E_INTERNAL, "integer-alphabet index with 64-bit positions");
     } else if (wide && sizeof(pos_t) == 4) {
         // few occurrences, 33-bit SA indices, 32-bit positions: the in-place kernel walks in 64-bit words of the scratch, then narrows
         if (vlg_status s = plan_sort()) return s;
@@ -1125,10 +1136,10 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
                 VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, np, np, (unsigned)phys, (unsigned)dlist.size(), nu, nu, 0,
                                                                pos_bits, ws->stream));
             }
-            if (ws->sweep && phys >= ws->sweep_min)
+            if (ws->sweep && phys >= ws->sweep_min && !idx->is_int)
                 sort_tmp = std::max(sort_tmp, sweep_temp_bytes(phys, idx->hdr.sigma, ws->stream));
         }
-        const bool will_sweep = ws->sweep && phys >= ws->sweep_min;
+        const bool will_sweep = ws->sweep && phys >= ws->sweep_min && !idx->is_int;
         uint64_t logical_max_query = 0;
         for (uint64_t qi = Q0; qi < Q1; ++qi)
             logical_max_query = std::max(logical_max_query, join_bytes_of(q, qi, [&](uint64_t s) -> uint64_t { return pl.occ[s]; }));
@@ -1308,7 +1319,8 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
 {
     if (!idx || !q || !ws || !out) return fail(VLG_E_INVALID, "null argument");
     *out = nullptr;
-    if (q->sym_bytes != 1) return fail(VLG_E_INVALID, "integer-alphabet query batch: only the vlg_wtsa_* entry points take it");
+    if (!idx->is_int && q->sym_bytes != 1) return fail(VLG_E_INVALID, "integer-alphabet query batch: it takes an integer-alphabet index (vlg_index_build_int) or vlg_wtsa_*");
+    if (idx->is_int && q->sym_bytes != 4 && q->nsub) return fail(VLG_E_INVALID, "an integer-alphabet index takes query batches parsed by vlg_queries_parse_int");
     hipStream_t st = ws->stream;
     vlg_result* res = new vlg_result();
     memset(&res->sum, 0, sizeof res->sum);
@@ -1333,7 +1345,8 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         // ---- K2: every sub-pattern's SA interval ------------------------------------------------------
         {
             Timed t(ws, KS_BSEARCH, 0);
-            if (vlg_status s = launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_l, d_r, d_stats + 3, st)) return s;
+            if (vlg_status s = idx->is_int ? launch_int_backward_search(idx->iview, q->d_blob, q->d_suboff, nsub, d_l, d_r, d_stats + 3, st)
+                                           : launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_l, d_r, d_stats + 3, st)) return s;
         }
         tr.mark("backward search");
         Plan pl;
@@ -1435,13 +1448,14 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
 extern "C" vlg_status vlg_queries_intervals(const vlg_index* idx, const vlg_queries* q, uint64_t* h_l, uint64_t* h_r, void* stream)
 {
     if (!idx || !q || (q->nsub && (!h_l || !h_r))) return fail(VLG_E_INVALID, "null argument");
-    if (q->sym_bytes != 1) return fail(VLG_E_INVALID, "integer-alphabet query batch: only the vlg_wtsa_* entry points take it");
+    if (idx->is_int != (q->sym_bytes == 4) && q->nsub) return fail(VLG_E_INVALID, "query batch and index are of different alphabets");
     const uint64_t nsub = q->nsub;
     if (!nsub) return VLG_OK;
     hipStream_t st = (hipStream_t)stream;
     uint64_t* d_lr = nullptr;
     VLG_HIP_TRY(hipMalloc((void**)&d_lr, 2 * nsub * 8));
-    vlg_status s = launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_lr, d_lr + nsub, nullptr, st);
+    vlg_status s = idx->is_int ? launch_int_backward_search(idx->iview, q->d_blob, q->d_suboff, nsub, d_lr, d_lr + nsub, nullptr, st)
+                               : launch_backward_search(idx->view, q->d_blob, q->d_suboff, nsub, d_lr, d_lr + nsub, nullptr, st);
     hipError_t e = hipSuccess;
     if (!s) e = hipMemcpyAsync(h_l, d_lr, nsub * 8, hipMemcpyDeviceToHost, st);
     if (!s && e == hipSuccess) e = hipMemcpyAsync(h_r, d_lr + nsub, nsub * 8, hipMemcpyDeviceToHost, st);
@@ -1590,3 +1604,4 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
 }
 
 #include "wtsa.hpp"
+#include "int_index.hpp"

@@ -160,6 +160,20 @@ class Queries:
         self.status = np.zeros(self.n, dtype=np.int32)
         return self
 
+    @classmethod
+    def from_int(cls, regexps, strict=True):
+        """Integer-alphabet batch (gapped_pattern_query<int_alphabet_tag>): sub-patterns are whitespace-separated decimals, gaps count
+        symbols -- for an integer-alphabet index (VlgIndex.build_int) or WtsaIndex over an integer text."""
+        raws = [r.encode("latin-1") if isinstance(r, str) else bytes(r) for r in regexps]
+        off = np.zeros(len(raws) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in raws])
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        status = np.zeros(max(len(raws), 1), dtype=np.int32)
+        check(lib().vlg_queries_parse_int(b"".join(raws), off.ctypes.data, len(raws), None if strict else status.ctypes.data, C.byref(h)))
+        self._h, self.n, self.status = h, len(raws), status[: len(raws)]
+        return self
+
     def subpattern_range(self):
         """qsub[nq+1]: query i owns the sub-patterns [qsub[i], qsub[i+1]) of the batch"""
         return np.concatenate([[0], np.cumsum(self.ks.astype(np.int64))])
@@ -220,6 +234,22 @@ class VlgIndex:
         h = C.c_void_p()
         check(lib().vlg_index_build(t.ctypes.data if len(t) else None, len(t), dens, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def build_int(cls, text, dens=32):
+        """FM-index of an integer text (csa_wt<wt_int<>, dens, ..., int_alphabet<>>): symbols uint32, none of them 0."""
+        t = np.ascontiguousarray(text, dtype=np.uint32)
+        h = C.c_void_p()
+        check(lib().vlg_index_build_int(t.ctypes.data if len(t) else None, len(t), dens, C.byref(h)))
+        return cls(h)
+
+    def int_alphabet(self):
+        """(C[sigma + 1], comp2char[sigma]) of an integer-alphabet index"""
+        sg = C.c_uint64()
+        check(lib().vlg_index_export_int_alphabet(self._h, C.byref(sg), None, None))
+        Cc, c2c = np.zeros(sg.value + 1, np.uint64), np.zeros(max(sg.value, 1), np.uint64)
+        check(lib().vlg_index_export_int_alphabet(self._h, C.byref(sg), Cc.ctypes.data, c2c.ctypes.data))
+        return Cc, c2c[: sg.value]
 
     @classmethod
     def build_device(cls, d_text_ptr, n_text, dens=32, stream=None):
@@ -322,9 +352,16 @@ class VlgIndex:
         check(lib().vlg_index_blob_export(self._h, d_ptr, nbytes, stream))
 
     # -- search -----------------------------------------------------------------------------------
+    def _queries(self, queries, dialect=capi.DIALECT_LIBRARY, strict=True):
+        if isinstance(queries, Queries):
+            return queries
+        if self.info()["bv_kind"] == 2:                       # integer-alphabet index: the integer query dialect
+            return Queries.from_int(queries, strict)
+        return Queries(queries, dialect, strict)
+
     def occurrences(self, queries, dialect=capi.DIALECT_LIBRARY):
         """sdsl::count of every sub-pattern of the batch (one backward-search pass) -> uint64[n sub-patterns]"""
-        q = queries if isinstance(queries, Queries) else Queries(queries, dialect)
+        q = self._queries(queries, dialect)
         nsub = int(lib().vlg_queries_subpatterns(q._h))
         occ = np.zeros(max(nsub, 1), dtype=np.uint64)
         check(lib().vlg_queries_occurrences(self._h, q._h, occ.ctypes.data, None))
@@ -332,7 +369,7 @@ class VlgIndex:
 
     def intervals(self, queries, dialect=capi.DIALECT_LIBRARY):
         """SA interval [l, r] of every sub-pattern of the batch (one backward-search pass) -> (l[], r[], Queries)"""
-        q = queries if isinstance(queries, Queries) else Queries(queries, dialect)
+        q = self._queries(queries, dialect)
         nsub = int(lib().vlg_queries_subpatterns(q._h))
         l, r = np.zeros(max(nsub, 1), dtype=np.uint64), np.zeros(max(nsub, 1), dtype=np.uint64)
         check(lib().vlg_queries_intervals(self._h, q._h, l.ctypes.data, r.ctypes.data, None))
@@ -360,7 +397,7 @@ class VlgIndex:
 
     def search(self, queries, dialect=capi.DIALECT_LIBRARY, workspace=None, strict=True):
         """Batched `idx.search(pat)`: queries is a list of regexps or a Queries object."""
-        q = queries if isinstance(queries, Queries) else Queries(queries, dialect, strict)
+        q = self._queries(queries, dialect, strict)
         ws = workspace or self.workspace()
         h = C.c_void_p()
         check(lib().vlg_search_batch(self._h, q._h, ws._h, C.byref(h)))
