@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __rest
                                                              const uint32_t* __restrict__ task_seg, const uint64_t* __restrict__ task_run0,
                                                              uint32_t ntasks, const uint64_t* __restrict__ abits,
                                                              const uint32_t* __restrict__ run_cnt, const uint32_t* __restrict__ run_off,
-                                                             pos_t* __restrict__ Pc)
+                                                             pos_t* __restrict__ Pc, uint64_t pc_cap /* elements Pc can take */)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t r0 = uniform(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kCompactRuns;
@@ -577,6 +577,8 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __rest
         for (int o = 1; o < 32; o <<= 1) { const uint32_t v = __shfl_up(before, o); if ((int)lane >= o) before += v; }
         before -= (uint32_t)__popcll(mine);
         const uint32_t out0 = run_off[run];
+        if ((uint64_t)out0 + run_cnt[run] > pc_cap) continue;                    // (a compaction launched before the counts were known: the host sees
+                                                                                 // the same total and falls back to compacting chunk by chunk)
         if (uniform(run_cnt[run]) < kRun / 2) {
             // sparse run (the usual case: few elements survive the filter): every lane moves the survivors of its own half word, so
             // the loop runs as often as the fullest half word has survivors, not once per word
@@ -621,6 +623,11 @@ struct FilterGroup {                 // outcome of the window filter for the que
     uint32_t* d_runcnt = nullptr;
     uint64_t pc_cap = 0;             // compacted elements one join chunk may hold
     bool any = false;
+    // The survivors of the WHOLE group are compacted right behind the count kernels, before the host has read the counts back (the GPU
+    // would idle through that round trip and the chunk planning otherwise): cpre[c] = where compacted segment c starts inside Pc.
+    // Valid when all survivors of the group fit pc_cap; otherwise the chunks compact their own lists as before.
+    bool speculated = false;
+    std::vector<uint64_t> cpre;      // [ncseg + 1]
 };
 
 inline uint32_t filter_block_shift(uint64_t n) { const unsigned b = bit_width64(n); return b > 31 ? b - 23 : 8; }   // <= 2^23 blocks
@@ -659,7 +666,7 @@ inline uint64_t filter_bytes(const vlg_queries* q, const Plan& pl, const vlg_wor
 template <typename pos_t>
 vlg_status filter_group(uint64_t n_positions /* every list element is smaller */, const vlg_queries* q, vlg_workspace* ws, const Plan& pl,
                         const std::vector<uint32_t>& poff /* per sub-pattern: its list inside P */, const pos_t* P,
-                        Arena& A /* advanced past the state the join chunks still need */, FilterGroup& fg)
+                        Arena& A /* advanced past the state the join chunks still need */, FilterGroup& fg, pos_t* Pc /* survivors go here */)
 {
     hipStream_t st = ws->stream;
     PhaseTrace ft(st);
@@ -819,10 +826,42 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
     VLG_HIP_TRY(hipGetLastError());
     svec<unsigned long long> segcnt(cseg.size());
     VLG_HIP_TRY(hipMemcpyAsync(segcnt.data(), d_segcnt, cseg.size() * 8, hipMemcpyDeviceToHost, st));
+    // compaction of the whole group, launched before the counts are known (the run counts and their scan stay on the device)
+    bool spec_launched = false;
+    const bool spec_on = [] { const char* e = getenv("VLG_NO_SPECULATIVE_COMPACT"); return !(e && e[0] == '1'); }();
+    if (spec_on && Pc && fg.pc_cap && total_runs && total_runs < 0x7FFFFFFFull) {
+        uint32_t* d_off = A.take<uint32_t>(total_runs + 1);
+        size_t scan_tmp = 0;
+        VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tmp, fg.d_runcnt, d_off, 0u, total_runs, rocprim::plus<uint32_t>(), st));
+        void* d_scan = A.take<uint8_t>(scan_tmp + 256);
+        if (!A.failed) {
+            Timed t(ws, KS_FILTER_COMPACT, 0);
+            VLG_HIP_TRY(rocprim::exclusive_scan(d_scan, scan_tmp, fg.d_runcnt, d_off, 0u, total_runs, rocprim::plus<uint32_t>(), st));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_compact_kernel<pos_t>), dim3((uint32_t)(((total_runs + kCompactRuns - 1) / kCompactRuns + 3) / 4)),
+                               dim3(256), 0, st, P, fg.d_segs, fg.d_cseg, fg.d_crun0, fg.ncseg, fg.d_abits, fg.d_runcnt, d_off, Pc, fg.pc_cap);
+            VLG_HIP_TRY(hipGetLastError());
+            spec_launched = true;
+        } else A.failed = false;                                     // no room for the scan: the chunks compact their own lists
+    }
     ft.mark("  filter: launched");
     VLG_HIP_TRY(hipStreamSynchronize(st));
     ft.mark("  filter: counts back");
     for (uint32_t c = 0; c < cseg.size(); ++c) fg.eff[seg_sub[cseg[c]]] = segcnt[c];
+    if (spec_launched) {
+        fg.cpre.assign(cseg.size() + 1, 0);
+        for (uint32_t c = 0; c < cseg.size(); ++c) fg.cpre[c + 1] = fg.cpre[c] + segcnt[c];
+        fg.speculated = fg.cpre.back() <= fg.pc_cap;
+        if (fg.speculated) {
+            ws->stats[KS_FILTER_COMPACT].algorithmic_bytes += 2 * fg.cpre.back() * sizeof(pos_t);
+            // fences of the survivors' lists: whole blocks of [Pc, Pc + total) (Pc starts on a block)
+            if (ws->fences && fg.cpre.back() >= 64) {
+                const uint64_t g0 = (uint64_t)(Pc - P) / 64;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fence_build_kernel<pos_t>), dim3(grid_for(fg.cpre.back() / 64, 8192)), dim3(256), 0, st, P, g0, g0 + fg.cpre.back() / 64,
+                                   static_cast<pos_t*>(ws->fences));
+                VLG_HIP_TRY(hipGetLastError());
+            }
+        }
+    }
     // a query that lost a whole list has no match; one whose survivors do not fit a chunk is joined on its full lists
     for (uint64_t qi = fg.g0; qi < fg.g1; ++qi) {
         const uint64_t s0 = q->qsub[qi] - fg.sub0, k = q->qsub[qi + 1] - q->qsub[qi];
@@ -833,7 +872,7 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
         uint64_t sum = 0;
         for (uint64_t i = 0; i + 1 < k; ++i) { dead |= fg.eff[s0 + i] == 0; if (fg.cidx[s0 + i] != kNone) sum += fg.eff[s0 + i]; }
         if (dead) for (uint64_t i = 0; i < k; ++i) fg.eff[s0 + i] = 0;
-        else if (sum > fg.pc_cap) for (uint64_t i = 0; i < k; ++i) { fg.eff[s0 + i] = pl.occ[fg.sub0 + s0 + i]; fg.cidx[s0 + i] = kNone; }
+        else if (sum > fg.pc_cap && !fg.speculated) for (uint64_t i = 0; i < k; ++i) { fg.eff[s0 + i] = pl.occ[fg.sub0 + s0 + i]; fg.cidx[s0 + i] = kNone; }
     }
     A.used = keep;                                   // bitmaps, counters and task lists are dead
     return VLG_OK;

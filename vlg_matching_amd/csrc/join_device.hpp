@@ -754,15 +754,19 @@ __global__ void chain_walk_kernel(const SegMeta* __restrict__ sm, const QueryMet
     counts[q] = n_match;
 }
 
-// A wave per record: the tile's jump targets are staged in LDS with coalesced loads, one lane hops through them there
-// (an LDS read per match instead of a dependent global load), then the wave writes the matches out together.
+// A wave per record: the matches inside its tile are entry, jump(entry), jump^2(entry), ..., `cnt` of them (the hop count the tile pass
+// left in xh).  The tile's jump targets are staged in LDS as tile-relative 16-bit offsets and the wave builds jump^(2^k) by doubling
+// there; lane r composes the tables selected by the bits of its rank r, so every match is found by <= 10 independent LDS lookups
+// instead of one lane hopping through the whole chain (380 dependent hops per tile on BASELINE config 3).
 __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restrict__ rec_begin, const uint32_t* __restrict__ rec_count,
                                                          const uint2* __restrict__ records, uint32_t total_rec_slots,
                                                          const uint32_t* __restrict__ rec_query, const uint32_t* __restrict__ jump,
-                                                         uint64_t r1 /* end of the slots that have a jump */, uint32_t* __restrict__ mlist)
+                                                         const uint2* __restrict__ xh, uint64_t r1 /* end of the slots that have a jump */,
+                                                         uint32_t* __restrict__ mlist)
 {
-    __shared__ uint32_t s_jump[4][kTile];
-    __shared__ uint32_t s_list[4][kTile];
+    constexpr uint16_t kOut = 0xFFFFu;                               // the chain leaves the tile
+    constexpr uint32_t kPer = kTile / 64;                            // slots (and ranks) per lane
+    __shared__ uint16_t s_t[4][2][kTile];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t r = uniform((uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     if (r >= total_rec_slots) return;
@@ -770,23 +774,42 @@ __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restr
     if (r - rec_begin[q] >= rec_count[q]) return;
     const uint2 rc = records[r];
     const uint64_t tile_base = (uint64_t)(rc.x / kTile) * kTile;
+    const uint32_t cnt = uniform(xh[rc.x].y);                        // chain elements inside the tile, entry included (1 .. kTile)
 #pragma unroll
-    for (uint32_t i = 0; i < kTile / 64; ++i) {
+    for (uint32_t i = 0; i < kPer; ++i) {
         const uint64_t e = tile_base + lane + 64 * i;
-        s_jump[wv][lane + 64 * i] = e < r1 ? jump[e] : kNone;
+        const uint32_t j = e < r1 ? jump[e] : kNone;
+        s_t[wv][0][lane + 64 * i] = (j != kNone && (uint64_t)j < tile_base + kTile) ? (uint16_t)(j - (uint32_t)tile_base) : kOut;
     }
     wave_sync();
-    uint32_t cnt = 0;
-    if (lane == 0) {
-        uint32_t cur = rc.x;
-        while (cur != kNone && (uint64_t)cur < tile_base + kTile) {
-            s_list[wv][cnt++] = cur;
-            cur = s_jump[wv][cur - (uint32_t)tile_base];
+    uint32_t cur[kPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) cur[i] = rc.x - (uint32_t)tile_base;
+    uint32_t buf = 0;
+    for (uint32_t k = 0; (1u << k) < cnt; ++k) {
+        const uint16_t* __restrict__ T = s_t[wv][buf];
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint32_t rank = lane + 64 * i;
+            if (rank < cnt && ((rank >> k) & 1)) cur[i] = T[cur[i]];         // (rank < cnt: the walk stays inside the tile)
+        }
+        if ((2u << k) < cnt) {                                               // jump^(2^(k+1)) for the next round
+            uint16_t* __restrict__ N = s_t[wv][buf ^ 1];
+#pragma unroll
+            for (uint32_t i = 0; i < kPer; ++i) {
+                const uint32_t sl = lane + 64 * i;
+                const uint16_t a = T[sl];
+                N[sl] = a == kOut ? kOut : T[a];
+            }
+            wave_sync();
+            buf ^= 1;
         }
     }
-    wave_sync();
-    cnt = uniform(__shfl(cnt, 0));
-    for (uint32_t i = lane; i < cnt; i += 64) mlist[rc.y + i] = s_list[wv][i];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) {
+        const uint32_t rank = lane + 64 * i;
+        if (rank < cnt) mlist[rc.y + rank] = (uint32_t)tile_base + cur[i];
+    }
 }
 
 // tuples of every match: walk the links from the level-0 element.  One thread per (query, match) slot of list 0.

@@ -687,7 +687,7 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
         Q.k = k; Q.end_len = q->end_len[qi]; Q.out_first = Q.out_tuple = 0; Q.seg0 = kNone;
         if (!(k > 0 && eo(a) > 0)) continue;
         kmax = std::max(kmax, k);
-        if (fg)
+        if (fg && !fg->speculated)
             for (uint32_t i = 0; i < k; ++i) {
                 const uint32_t c = fg->cidx[a + i - fg->sub0];
                 if (c == kNone) continue;
@@ -718,7 +718,7 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
                                (uint32_t)t_seg.size(), fg->d_crun0, fg->d_runcnt, d_cnt);
             VLG_HIP_TRY(rocprim::exclusive_scan(d_scan, scan_tmp, d_cnt, d_off, 0u, runs, rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_compact_kernel<pos_t>), dim3((uint32_t)(((runs + kCompactRuns - 1) / kCompactRuns + 3) / 4)),
-                               dim3(256), 0, st, P, fg->d_segs, d_tseg, d_trun0, (uint32_t)t_seg.size(), fg->d_abits, d_cnt, d_off, Pc);
+                               dim3(256), 0, st, P, fg->d_segs, d_tseg, d_trun0, (uint32_t)t_seg.size(), fg->d_abits, d_cnt, d_off, Pc, ~0ull);
         }
         // fences of the survivors' lists: whole blocks of [Pc, Pc + pc_total) (Pc starts on a block)
         if (ws->fences && pc_total >= 64) {
@@ -761,7 +761,9 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
             SegMeta& m = sm[seg_of_sub[s - s0]];
             m.level = i; m.dist = k - 1 - i;
             m.lo = q->lo[s]; m.hi = q->hi[s];
-            if (filtered(s)) {                                   // private list of the query: the survivors, compacted behind P
+            if (filtered(s) && fg->speculated) {                 // compacted with its whole group: segment c starts at cpre[c]
+                m.pbegin = (uint32_t)((Pc - P) + fg->cpre[fg->cidx[s - fg->sub0]]);
+            } else if (filtered(s)) {                            // private list of the query: the survivors, compacted behind P
                 m.pbegin = (uint32_t)((Pc - P) + pc_used);                 // the order of the compaction tasks
                 pc_used += eo(s);
             } else {
@@ -899,7 +901,7 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
         hipLaunchKernelGGL(chain_walk_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, d_sm, d_qm, nq, d_qstart, xh, d_recb, d_rec, d_recc,
                            d_counts);
         if (n_rec)
-            hipLaunchKernelGGL(chain_emit_kernel, dim3((n_rec + 3) / 4), dim3(256), 0, st, d_recb, d_recc, d_rec, n_rec, d_recq, jump, lvl0_end, mlist);
+            hipLaunchKernelGGL(chain_emit_kernel, dim3((n_rec + 3) / 4), dim3(256), 0, st, d_recb, d_recc, d_rec, n_rec, d_recq, jump, xh, lvl0_end, mlist);
     }
     VLG_HIP_TRY(hipGetLastError());
     // ---- sizes of the result, then gather -------------------------------------------------------------
@@ -1035,7 +1037,7 @@ vlg_status run_joins(uint64_t n_positions, const vlg_queries* q, vlg_workspace* 
         fg.g1 = g1;
         const FilterGroup* fgp = nullptr;
         if (fb) {
-            if (vlg_status s = filter_group<pos_t>(n_positions, q, ws, pl, poff, P, GA, fg)) return s;
+            if (vlg_status s = filter_group<pos_t>(n_positions, q, ws, pl, poff, P, GA, fg, Pc)) return s;
             if (fg.any) fgp = &fg;
             tr.mark("filter group");
         }
@@ -1050,7 +1052,7 @@ vlg_status run_joins(uint64_t n_positions, const vlg_queries* q, vlg_workspace* 
                 const uint64_t e = fgp ? fgp->eff[a + i - fgp->sub0] : pl.occ[a + i];
                 if (i == 0) first = e;
                 if (i + 1 < k || k == 1) t += e;
-                if (fgp && fgp->cidx[a + i - fgp->sub0] != kNone) pc += e;
+                if (fgp && !fgp->speculated && fgp->cidx[a + i - fgp->sub0] != kNone) pc += e;      // (speculated: the survivors are in Pc already)
             }
             bytes = t * kJoinBytesPerSlot + (k ? (uniform_k ? first : t) : 0) * kJoinBytesPerSlot0;
             slots = t + 64ull * k;
