@@ -248,7 +248,9 @@ def main():
     ap.add_argument("--bv", choices=["plain", "rrr"], default=None, help="wavelet-tree bit-vectors (default: rrr for C5, else plain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling region")
-    ap.add_argument("--strong-sharding", choices=["affinity", "work"], default="affinity")
+    ap.add_argument("--strong-sharding", choices=["lists", "affinity", "work"], default="lists",
+                    help="strong-scaling region: 'lists' = collective search (distinct lists sharded for locate + sort, sorted lists "
+                         "all-gathered, queries sharded for the joins); 'affinity' / 'work' = only the query loop is sharded")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (parse + H2D + search + D2H) region")
     ap.add_argument("--tuples", action="store_true", help="also materialise every sub-pattern position of every match (sdsl::locate output)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -449,7 +451,46 @@ def main():
 
     # ---- strong scaling: THE batch (rank 0's) cut by work, every rank searches its slice ------------------------------------
     strong = None
-    if dist is not None and not args.no_strong:
+    if dist is not None and not args.no_strong and args.strong_sharding == "lists":
+        # collective search: every rank gets THE batch (rank 0's), locates + sorts its share of the distinct lists, receives the other
+        # shares (RCCL all-gather of the sorted lists; gloo rehearsals move them through the host), joins its piece of the queries
+        box = [queries if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        qs = Queries(box[0])
+        comm_x = None
+        if args.backend == "nccl":
+            comm_x = vdist.Comm.from_torch_dist(dist)
+            ws.set_comm(comm_x)
+        else:
+            ws.set_exchange(world, rank, vdist.host_exchange(dist))
+        idx.search(qs, workspace=ws)                           # warm-up
+        ws.profile(True)
+        dt_s, my_dt_s, r_s = timed(lambda: idx.search(qs, workspace=ws), args.steps)
+        x_stats = ws.kernel_stats()
+        ws.profile(False)
+        ss = r_s.summary
+        tq_all = ss["n_queries"]
+        owned = r_s.owned_queries()
+        n_own = sum(b - a for a, b in owned) if owned else tq_all
+        tq, tocc, tm = reduce_sum([n_own, ss["located_occurrences"], ss["n_matches"]])
+        chk = vdist.reduce_checksum(ss["checksum"], dist, dev)
+        pr = gather_per_rank([my_dt_s / args.steps * 1e3, n_own, ss["located_occurrences"], x_stats["exchange"]["total_ms"] / args.steps,
+                              x_stats["exchange"]["algorithmic_bytes"] / args.steps])
+        strong = {"scaling": "strong", "value": tq * args.steps / dt_s, "unit": "queries/s", "ms_per_step": dt_s / args.steps * 1e3,
+                  "queries": tq, "matches": tm, "checksum": chk, "located_occ_per_step_all_ranks": tocc,
+                  "per_rank": [{"ms_per_step": p[0], "queries": int(p[1]), "located_occ": int(p[2]), "exchange_ms": p[3],
+                                "exchange_bytes_received": int(p[4])} for p in pr],
+                  "sharding": "lists",
+                  "exchange": "vlg_comm_allgatherv (RCCL)" if comm_x is not None else "host (gloo rehearsal)",
+                  "note": "the 1-GPU batch answered by all ranks together: every distinct occurrence list is located and sorted by exactly one "
+                          "rank (located_occ summed over ranks = the 1-GPU figure), the sorted lists are all-gathered, every rank filters and "
+                          "joins a contiguous piece of the queries of equal join work"}
+        ws.set_comm(None)
+        if comm_x is not None:
+            comm_x.close()
+        if rank == 0:
+            assert tq == s["n_queries"] and tm == s["n_matches"] and chk == s["checksum"] and tocc == s["located_occurrences"], (tq, tm, chk, tocc, s)
+    elif dist is not None and not args.no_strong:
         if rank == 0:
             if args.strong_sharding == "affinity":             # queries that share their longest list stay together
                 l_, r_, q_all = idx.intervals(queries)

@@ -446,6 +446,25 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
 vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* name, int64_t value);
 vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n);
 
+/* ------------------------------------------------------------------------------------------
+ * Collective search (one process per GPU): ONE batch answered by all ranks of a communicator.
+ * Every rank passes the same index image and the same query batch to vlg_search_batch, with a workspace of the same cap.  A batch
+ * is cheap on one GPU because equal SA intervals are located once (vlg_result_summary.located_occurrences << logical_occurrences);
+ * sharding only the query loop of gm_search.cpp:91-121 makes every rank locate the frequent lists again.  Here the DISTINCT LISTS are
+ * sharded for locate + sort (a contiguous share of the lists in SA order per rank, equal occurrences), the sorted lists are exchanged
+ * (one in-place all-gather of positions: the exchange step of this path), and the QUERIES are sharded for filter + join (contiguous
+ * pieces of equal join work).  The result holds this rank's queries (vlg_result_owned_queries; counts of the others are 0); counts,
+ * checksums and located occurrences are summed over the ranks by the caller (vlg_comm_allreduce_sum_u64).
+ * vlg_workspace_set_comm: exchange by RCCL (vlg_comm_allgatherv); NULL = back to single-GPU searches.
+ * vlg_workspace_set_exchange: the caller moves the bytes -- `fn` must all-gather IN PLACE: d_buf holds this rank's piece at the offset
+ * of the pieces before it (h_counts[r] elements of elem_bytes per rank r), afterwards every piece; work it enqueues must be ordered
+ * with `stream`.  (Hosts without RCCL between their ranks; rehearsals with several ranks on one device.) */
+typedef int (*vlg_exchange_fn)(void* ctx, void* d_buf, const uint64_t* h_counts, uint32_t elem_bytes, int n_ranks, int rank, void* stream);
+vlg_status vlg_workspace_set_comm(vlg_workspace* ws, void* nccl_comm);
+vlg_status vlg_workspace_set_exchange(vlg_workspace* ws, int n_ranks, int rank, vlg_exchange_fn fn, void* ctx);
+/* [begin, end) pairs of the queries this rank joined in a collective search (n_ranges = 0: a single-GPU search, all of them) */
+vlg_status vlg_result_owned_queries(const vlg_result* r, uint64_t* h_ranges, uint32_t cap_ranges, uint32_t* n_ranges);
+
 #ifdef __cplusplus
 }
 #endif

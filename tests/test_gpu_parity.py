@@ -1075,11 +1075,19 @@ def _nccl_one_rank_worker(port, text, queries, out_q):
     comm.allgatherv(send.data_ptr(), [1000], 4, recv.data_ptr())
     torch.cuda.synchronize()
     r2 = vdist.replicate_index(idx0, dist, dev, src=0, comm=comm).search(queries)
+    # collective search over the (one-rank) communicator: list-sharded locate, exchange through vlg_comm_allgatherv, query-sharded joins
+    from vlg_matching_amd.index import Workspace
+    wsx = Workspace()
+    wsx.set_comm(comm)
+    r3 = idx0.search(queries, workspace=wsx)
+    owned = r3.owned_queries()
+    wsx.set_comm(None)
     lib_path = comm.library()
     comm.close()
     out_q.put({"counts": [int(c) for c in r.counts], "tot": [int(x) for x in tot.tolist()], "max": float(t.item()), "chk": chk,
                "gathered": float(outl[0].item()), "comm": (n_ranks, rank), "same": same is idx0, "sums": sums,
                "recv_ok": bool((recv == send).all().item()), "counts2": [int(c) for c in r2.counts], "rccl": lib_path,
+               "counts3": [int(c) for c in r3.counts], "owned": owned, "chk3": int(r3.summary["checksum"]),
                "summary": {k: int(v) for k, v in r.summary.items()}})
     dist.barrier()
     dist.destroy_process_group()
@@ -1112,6 +1120,7 @@ def test_rccl_branch_runs_with_one_rank(V, oracle):
     assert got["chk"] == one.summary["checksum"] and got["max"] == 1.5 and got["gathered"] == 1.5
     assert got["comm"] == (1, 0) and got["same"] and got["recv_ok"]
     assert got["sums"] == [one.summary["n_matches"], (1 << 64) - 1, 7]
+    assert got["counts3"] == got["counts"] and got["owned"] == [] and got["chk3"] == one.summary["checksum"]
     assert "rccl" in got["rccl"].lower()
     o = oracle.Index.from_text(text)
     for i in (0, 17, 60, 119):
@@ -1299,3 +1308,79 @@ def test_integer_alphabet_fm_index_known_answers_and_refusals(V):
         idx.compress()
     with pytest.raises(V.VlgError):
         idx.export_parts()
+
+
+def _collective_worker(rank, world, port, text, queries, opts, out_q):
+    import torch
+    import torch.distributed as dist
+    import vlg_matching_amd as V
+    from vlg_matching_amd import dist as vdist
+    from vlg_matching_amd.index import Workspace
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx = vdist.replicate_index(V.VlgIndex.build(text) if rank == 0 else None, dist, torch.device("cuda", 0), src=0)
+    ws = Workspace()
+    for k_, v_ in opts.items():
+        ws.set_option(k_, v_)
+    ws.set_exchange(world, rank, vdist.host_exchange(dist))
+    r = idx.search(queries, workspace=ws)
+    owned = r.owned_queries()
+    counts = [int(c) for c in r.counts]
+    tuples = {}
+    for a, b in owned:
+        for i in range(a, b):
+            tuples[i] = r.tuples(i).tolist()
+    st = ws.kernel_stats()
+    out_q.put((rank, owned, counts, tuples, {k: int(v) for k, v in r.summary.items()}, st["exchange"]["launches"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,opts", [(2, {}), (3, {"sweep_min": 1, "sweep_tail": 64, "filter_min": 0, "filter_stream_min": 0}),
+                                        (2, {"list_sort": 0, "global_sort_min": 1 << 40})])
+def test_collective_search_shards_lists_and_queries(V, oracle, world, opts):
+    """The exchange step (SURVEY.md 8e strong scaling): `world` ranks on ONE device, the pieces moved through gloo on the host
+    (vlg_workspace_set_exchange) -- every rank locates + sorts only its share of the distinct lists (the shares add up to the 1-GPU
+    figure: nothing is located twice), receives the others' sorted lists, joins its piece of the queries; pieces are disjoint and
+    cover the batch, tuples equal the single-process run and the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    text = skewed_text(60000, 41).tobytes()
+    rng = np.random.default_rng(43)
+    queries = random_queries(text, rng, 400, kmax=4, mmax=3)
+    one = V.VlgIndex.build(text).search(queries)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    procs = [ctx.Process(target=_collective_worker, args=(r, world, port, text, queries, opts, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(out_q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    covered = []
+    for rank, owned, counts, tuples, summ, xl in got:
+        assert len(owned) == 1 and xl >= 1
+        a, b = owned[0]
+        covered.append((a, b))
+        assert all(c == 0 for i, c in enumerate(counts) if not (a <= i < b))
+        for i in range(a, b):
+            assert counts[i] == int(one.counts[i]) and tuples[i] == one.tuples(i).tolist(), (rank, i, queries[i])
+    covered.sort()
+    assert covered[0][0] == 0 and covered[-1][1] == len(queries)
+    for (a0, b0), (a1, b1) in zip(covered, covered[1:]):
+        assert b0 == a1
+    assert sum(g[4]["n_matches"] for g in got) == one.summary["n_matches"]
+    assert sum(g[4]["checksum"] for g in got) % (1 << 64) == one.summary["checksum"]
+    located = [g[4]["located_occurrences"] for g in got]
+    assert sum(located) == one.summary["located_occurrences"]                 # every distinct list located exactly once
+    assert max(located) <= one.summary["located_occurrences"] / world * 2 + 20000     # shares are cut between lists: balanced up to one list
+    o = oracle.Index.from_text(text)
+    for i in (0, 99, 250, 399):
+        assert one.tuples(i).tolist() == o.search(queries[i]).tolist()

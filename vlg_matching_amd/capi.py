@@ -57,6 +57,8 @@ class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_uint64)]
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_int, C.c_int, C.c_void_p)
+
 # every symbol include/vlg_hip.h declares: (name, restype, argtypes)
 _P, _U64, _I = C.c_void_p, C.c_uint64, C.c_int
 SYMBOLS = [
@@ -135,6 +137,9 @@ SYMBOLS = [
     ("vlg_workspace_profile", _I, [_P, _I]),
     ("vlg_workspace_set_option", _I, [_P, C.c_char_p, C.c_int64]),
     ("vlg_workspace_kernel_stats", _I, [_P, C.POINTER(KernelStat), C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("vlg_workspace_set_comm", _I, [_P, _P]),
+    ("vlg_workspace_set_exchange", _I, [_P, _I, _I, _P, _P]),
+    ("vlg_result_owned_queries", _I, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
 ]
 
 

@@ -826,6 +826,8 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
     VLG_HIP_TRY(hipGetLastError());
     svec<unsigned long long> segcnt(cseg.size());
     VLG_HIP_TRY(hipMemcpyAsync(segcnt.data(), d_segcnt, cseg.size() * 8, hipMemcpyDeviceToHost, st));
+    hipEvent_t counts_ready = ws_event(ws);                          // the host waits for the counts, not for what is enqueued behind them
+    if (counts_ready) VLG_HIP_TRY(hipEventRecord(counts_ready, st));
     // compaction of the whole group, launched before the counts are known (the run counts and their scan stay on the device)
     bool spec_launched = false;
     const bool spec_on = [] { const char* e = getenv("VLG_NO_SPECULATIVE_COMPACT"); return !(e && e[0] == '1'); }();
@@ -844,7 +846,11 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
         } else A.failed = false;                                     // no room for the scan: the chunks compact their own lists
     }
     ft.mark("  filter: launched");
-    VLG_HIP_TRY(hipStreamSynchronize(st));
+    if (counts_ready) {
+        const hipError_t e = hipEventSynchronize(counts_ready);
+        ws->free_events.push_back(counts_ready);
+        VLG_HIP_TRY(e);
+    } else VLG_HIP_TRY(hipStreamSynchronize(st));
     ft.mark("  filter: counts back");
     for (uint32_t c = 0; c < cseg.size(); ++c) fg.eff[seg_sub[cseg[c]]] = segcnt[c];
     if (spec_launched) {

@@ -36,9 +36,9 @@ using namespace vlg;
 // Workspace
 // =============================================================================================
 enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_LOCATE_PART, KS_LOCATE_RESOLVE, KS_SORT, KS_FILTER_PIVOT, KS_FILTER_PASS, KS_FILTER_COMPACT,
-       KS_JOIN_INIT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_COUNT };
+       KS_JOIN_INIT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_EXCHANGE, KS_COUNT };
 static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "locate_partition", "locate_resolve", "sort", "filter_pivot",
-                                             "filter_pass", "filter_compact", "join_init", "join_link", "join_scan", "join_chain", "gather"};
+                                             "filter_pass", "filter_compact", "join_init", "join_link", "join_scan", "join_chain", "gather", "exchange"};
 
 struct vlg_workspace {
     hipStream_t stream = nullptr;
@@ -69,6 +69,12 @@ struct vlg_workspace {
     // trail table of the sorted sweep: it lives at the head of the arena and carries generation stamps, so it is cleared once, not per batch
     uint32_t trail_gen = 0;             // generation of the last sweep that wrote it; 0 = content unknown
     uint64_t trail_n = 0;               // text length it was last used for
+    // one process per GPU: a collective search shards the DISTINCT LISTS of a batch over the ranks for locate + sort,
+    // exchanges the sorted lists (all-gather) and shards the QUERIES for filter + join
+    int x_ranks = 1, x_rank = 0;
+    vlg_exchange_fn x_fn = nullptr;     // in-place all-gather of device pieces; null with x_comm set = vlg_comm_allgatherv
+    void* x_ctx = nullptr;
+    void* x_comm = nullptr;
     vlg_kernel_stat stats[KS_COUNT];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KS_COUNT];
     std::vector<hipEvent_t> free_events;
@@ -228,6 +234,24 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     return fail(VLG_E_INVALID, std::string("unknown workspace option ") + name);
 }
 
+extern "C" vlg_status vlg_workspace_set_comm(vlg_workspace* ws, void* nccl_comm)
+{
+    if (!ws) return fail(VLG_E_INVALID, "null argument");
+    ws->x_comm = nullptr; ws->x_fn = nullptr; ws->x_ctx = nullptr; ws->x_ranks = 1; ws->x_rank = 0;
+    if (!nccl_comm) return VLG_OK;
+    int n = 0, r = 0;
+    if (vlg_status s = vlg_comm_info(nccl_comm, &n, &r)) return s;
+    ws->x_comm = nccl_comm; ws->x_ranks = n; ws->x_rank = r;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_workspace_set_exchange(vlg_workspace* ws, int n_ranks, int rank, vlg_exchange_fn fn, void* ctx)
+{
+    if (!ws || n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !fn)) return fail(VLG_E_INVALID, "bad exchange arguments");
+    ws->x_comm = nullptr; ws->x_fn = n_ranks > 1 ? fn : nullptr; ws->x_ctx = ctx; ws->x_ranks = n_ranks; ws->x_rank = rank;
+    return VLG_OK;
+}
+
 extern "C" vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, uint32_t cap, uint32_t* n)
 {
     if (!ws || !n) return fail(VLG_E_INVALID, "null argument");
@@ -253,6 +277,7 @@ struct vlg_result {
     std::vector<uint64_t> counts;          // host: per query
     std::vector<uint32_t> k;               // host: sub-patterns per query
     std::vector<ResultPiece> pieces;
+    std::vector<uint64_t> owned;           // collective search: [begin, end) pairs of the queries this rank joined (empty: all of them)
 };
 
 // Result buffers are large and batches come one after the other: freed buffers are parked (up to kResultCacheBytes) and
@@ -332,6 +357,14 @@ extern "C" vlg_status vlg_result_summary_get(const vlg_result* r, vlg_result_sum
 {
     if (!r || !s) return fail(VLG_E_INVALID, "null argument");
     *s = r->sum;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_result_owned_queries(const vlg_result* r, uint64_t* h_ranges, uint32_t cap_ranges, uint32_t* n_ranges)
+{
+    if (!r || !n_ranges) return fail(VLG_E_INVALID, "null argument");
+    *n_ranges = (uint32_t)(r->owned.size() / 2);
+    for (uint32_t i = 0; i < *n_ranges && i < cap_ranges && h_ranges; ++i) { h_ranges[2 * i] = r->owned[2 * i]; h_ranges[2 * i + 1] = r->owned[2 * i + 1]; }
     return VLG_OK;
 }
 
@@ -475,26 +508,50 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
 {
     hipStream_t st = ws->stream;
     PhaseTrace bt(st);
-    const uint32_t nd = (uint32_t)dlist.size();
-    svec<uint64_t> off64(nd + 1), lh(nd);
-    svec<uint32_t> off32(nd + 1);
-    uint64_t acc = 0;
-    for (uint32_t i = 0; i < nd; ++i) {
-        off64[i] = acc; off32[i] = (uint32_t)acc; lh[i] = pl.dl[dlist[i]];
-        poff[dlist[i]] = (uint32_t)acc;
-        acc += pl.docc[dlist[i]];
+    // all lists of the super-chunk ("g": global), laid out one after the other in SA order of their intervals
+    const uint32_t gnd = (uint32_t)dlist.size();
+    svec<uint64_t> goff64(gnd + 1);
+    uint64_t gacc = 0;
+    for (uint32_t i = 0; i < gnd; ++i) {
+        goff64[i] = gacc;
+        poff[dlist[i]] = (uint32_t)gacc;
+        gacc += pl.docc[dlist[i]];
     }
-    off64[nd] = acc; off32[nd] = (uint32_t)acc;
-    Tphys = acc;
+    goff64[gnd] = gacc;
+    Tphys = gacc;
     P_out = nullptr;
     Pc_out = nullptr;
     pc_cap = 0;
     ws->fences = nullptr;
-    if (!acc) return VLG_OK;
+    if (!gacc) return VLG_OK;
+    // Collective search: this rank locates and sorts a contiguous share [sl, sh) of the lists -- cut so that every rank gets the
+    // same number of occurrences, identically on every rank -- and the ranks exchange their sorted pieces afterwards.
+    uint32_t sl = 0, sh = gnd;
+    std::vector<uint64_t> xcounts;
+    if (ws->x_ranks > 1) {
+        std::vector<uint32_t> cut(ws->x_ranks + 1, gnd);
+        cut[0] = 0;
+        for (int r = 1; r < ws->x_ranks; ++r) {
+            const uint64_t target = gacc / (uint64_t)ws->x_ranks * (uint64_t)r;
+            const uint32_t c = (uint32_t)(std::lower_bound(goff64.begin(), goff64.end(), target) - goff64.begin());
+            cut[r] = std::max(cut[r - 1], std::min(c, gnd));
+        }
+        xcounts.resize(ws->x_ranks);
+        for (int r = 0; r < ws->x_ranks; ++r) xcounts[r] = goff64[cut[r + 1]] - goff64[cut[r]];
+        sl = cut[ws->x_rank]; sh = cut[ws->x_rank + 1];
+    }
+    const uint32_t nd = sh - sl;                                       // from here to the sort: this rank's share
+    svec<uint64_t> off64(nd + 1), lh(std::max<uint32_t>(nd, 1));
+    svec<uint32_t> off32(nd + 1);
+    for (uint32_t i = 0; i <= nd; ++i) { off64[i] = goff64[sl + i] - goff64[sl]; off32[i] = (uint32_t)off64[i]; }
+    for (uint32_t i = 0; i < nd; ++i) lh[i] = pl.dl[dlist[sl + i]];
+    const uint64_t acc = off64[nd];
     const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (wide ? 33 : 32)) && !idx->is_int;
-    pos_t* Pa = A.take<pos_t>(acc);
+    pos_t* Pg = A.take<pos_t>(gacc);
     // scratch of the sweep (20 B per element); the sorted lists Pb reuse it once locate is done
-    uint8_t* scratch = A.take<uint8_t>(acc * kPhysScratchPerElem<pos_t>());
+    uint8_t* scratch = A.take<uint8_t>(gacc * kPhysScratchPerElem<pos_t>());
+    pos_t* Pa = Pg ? Pg + goff64[sl] : nullptr;
+    uint64_t* d_goff64 = (ws->x_ranks > 1) ? A.take<uint64_t>(gnd + 1) : nullptr;
     uint64_t* d_off64 = A.take<uint64_t>(nd + 1);
     uint32_t* d_off32 = A.take<uint32_t>(nd + 1);
     uint64_t* d_lh = A.take<uint64_t>(nd);
@@ -504,7 +561,8 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     pos_t* Pb = reinterpret_cast<pos_t*>(scratch);
     VLG_HIP_TRY(hipMemcpyAsync(d_off64, off64.data(), (nd + 1) * 8, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(d_off32, off32.data(), (nd + 1) * 4, hipMemcpyHostToDevice, st));
-    VLG_HIP_TRY(hipMemcpyAsync(d_lh, lh.data(), nd * 8, hipMemcpyHostToDevice, st));
+    if (nd) VLG_HIP_TRY(hipMemcpyAsync(d_lh, lh.data(), nd * 8, hipMemcpyHostToDevice, st));
+    if (d_goff64) VLG_HIP_TRY(hipMemcpyAsync(d_goff64, goff64.data(), (gnd + 1) * 8, hipMemcpyHostToDevice, st));
     uint64_t* rec = nullptr;
     if (use_sweep && trail) {                                                     // (trails are shared inside one sweep)
         rec = A.take<uint64_t>(acc);
@@ -521,7 +579,9 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         if (ls != VLG_OK) A.used = sort_mark;
         return VLG_OK;
     };
-    if (use_sweep) {
+    if (!acc) {
+        // (a rank without a share: nothing to locate or sort, the exchange below still takes place)
+    } else if (use_sweep) {
         const uint64_t cap = std::min<uint64_t>(acc, wide ? sweep_batch_max<true>() : sweep_batch_max<false>());
         uint64_t* val_a = reinterpret_cast<uint64_t*>(scratch);
         uint64_t* val_b = val_a + cap;
@@ -579,14 +639,16 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     const bool global_sort = acc >= ws->global_sort_min && bits + list_bits <= 64;
     uint64_t dead_bytes = 0;                              // free bytes behind the sorted lists (the survivors of the window filter go there)
     bool sorted = false;
-    if (lsp.ready) {
+    if (!acc) {
+        sorted = true;
+        P_out = Pa;
+    } else if (lsp.ready) {
         // 32-bit positions: sorted inside every list (list_sort.hpp) -- 4 passes of 8 B per element instead of 6 of 16 B
         Timed t(ws, KS_SORT, 2ull * acc * sizeof(pos_t));
         if (vlg_status ls = list_sort_enqueue(lsp, reinterpret_cast<uint32_t*>(Pa), reinterpret_cast<uint32_t*>(scratch), d_off64, bits, st)) return ls;
         A.used = sort_mark;                               // its tables are dead once its kernels have run (stream order)
         sorted = true;
         P_out = Pa;
-        dead_bytes = (uint64_t)(scratch - reinterpret_cast<uint8_t*>(Pa)) + acc * kPhysScratchPerElem<pos_t>() - acc * sizeof(pos_t);
     }
     if (sorted) {
     } else if (global_sort) {
@@ -601,14 +663,32 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_narrow_kernel<pos_t>), dim3(grid_for(acc, 32768)), dim3(256), 0, st, keys.current(), acc, bits, Pa);
         VLG_HIP_TRY(hipGetLastError());
         P_out = Pa;
-        dead_bytes = (uint64_t)(scratch - reinterpret_cast<uint8_t*>(Pa)) + acc * kPhysScratchPerElem<pos_t>() - acc * sizeof(pos_t);
     } else {
         Timed t(ws, KS_SORT, 2ull * acc * sizeof(pos_t));
         size_t tb = sort_tmp;
         VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(d_tmp, tb, Pa, Pb, (unsigned)acc, nd, d_off32, d_off32 + 1, 0, bits, st));
         P_out = Pb;
-        dead_bytes = acc * kPhysScratchPerElem<pos_t>() - acc * sizeof(pos_t);
+        if (ws->x_ranks > 1) {                                // the pieces of all ranks meet in ONE array: back to the share's place
+            VLG_HIP_TRY(hipMemcpyAsync(Pa, Pb, acc * sizeof(pos_t), hipMemcpyDeviceToDevice, st));
+            P_out = Pa;
+        }
     }
+    // ---- the exchange step: every rank contributes the sorted lists of its share, all ranks end up with all lists -----------------------
+    const uint64_t* d_check_off = d_off64;
+    uint64_t check_nd = nd, check_acc = acc;
+    if (ws->x_ranks > 1) {
+        Timed t(ws, KS_EXCHANGE, (gacc - acc) * sizeof(pos_t));
+        int rc = 0;
+        if (ws->x_fn) rc = ws->x_fn(ws->x_ctx, Pg, xcounts.data(), (uint32_t)sizeof(pos_t), ws->x_ranks, ws->x_rank, st);
+        else if (ws->x_comm) rc = (int)vlg_comm_allgatherv(ws->x_comm, Pa, xcounts.data(), (uint32_t)sizeof(pos_t), Pg, st);
+        else return fail(VLG_E_INTERNAL, "collective search without a communicator");
+        if (rc) return ws->x_fn ? fail(VLG_E_INTERNAL, "the exchange callback failed with code " + std::to_string(rc)) : (vlg_status)rc;
+        P_out = Pg;
+        d_check_off = d_goff64; check_nd = gnd; check_acc = gacc;
+    }
+    if (P_out == Pb) dead_bytes = gacc * kPhysScratchPerElem<pos_t>() - gacc * sizeof(pos_t);
+    else dead_bytes = (uint64_t)(scratch - reinterpret_cast<uint8_t*>(Pg)) + gacc * kPhysScratchPerElem<pos_t>() - gacc * sizeof(pos_t);
+    if (ws->x_ranks == 1 && P_out == Pa) P_out = Pg;          // (the same place: the one share starts at the beginning)
     // VLG_CHECK_SORT=1 (set by the tests): every list is verified ascending on the device after the sort -- list_sort.hpp leans on
     // the key order of rocPRIM's block_radix_rank, which a library upgrade could change silently
     if (check_sort_enabled() && P_out) {
@@ -616,7 +696,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         if (!d_flags) return fail(VLG_E_INTERNAL, "arena carve failed (sort check)");
         unsigned long long flags[2] = {0, 0};
         VLG_HIP_TRY(hipMemsetAsync(d_flags, 0, 16, st));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lists_check_kernel<pos_t>), dim3(grid_for((acc + 7) / 8, 8192)), dim3(256), 0, st, P_out, d_off64, (uint64_t)nd, acc, d_flags);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lists_check_kernel<pos_t>), dim3(grid_for((check_acc + 7) / 8, 8192)), dim3(256), 0, st, P_out, d_check_off, check_nd, check_acc, d_flags);
         VLG_HIP_TRY(hipGetLastError());
         VLG_HIP_TRY(hipMemcpyAsync(flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         VLG_HIP_TRY(hipStreamSynchronize(st));
@@ -625,21 +705,21 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     // no wait here: the staging vectors live in the workspace's pinned pool until the batch ends, so the caller plans the
     // window filter while the sort runs
     {
-        const uint64_t pc_first = align_up(acc, 64);
-        if (dead_bytes > (pc_first - acc + 64) * sizeof(pos_t) && pc_first < 0xFFFFFF00ull) {
+        const uint64_t pc_first = align_up(gacc, 64);
+        if (dead_bytes > (pc_first - gacc + 64) * sizeof(pos_t) && pc_first < 0xFFFFFF00ull) {
             Pc_out = P_out + pc_first;
-            pc_cap = std::min<uint64_t>(dead_bytes / sizeof(pos_t) - (pc_first - acc) - 64, 0xFFFFFF00ull - pc_first);
+            pc_cap = std::min<uint64_t>(dead_bytes / sizeof(pos_t) - (pc_first - gacc) - 64, 0xFFFFFF00ull - pc_first);
         }
     }
     // fences of the sorted lists (and room for those of the survivors' lists behind them)
     ws->fences = nullptr;
     if (P_out) {
-        const uint64_t cover = Pc_out ? (uint64_t)(Pc_out - P_out) + pc_cap : acc;
+        const uint64_t cover = Pc_out ? (uint64_t)(Pc_out - P_out) + pc_cap : gacc;
         const uint64_t entries = cover / 64 + 2;
         if (!A.failed && A.size - A.used > entries * sizeof(pos_t) + 4096) {
             pos_t* F = A.take<pos_t>(entries);
-            if (acc >= 64)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fence_build_kernel<pos_t>), dim3(grid_for(acc / 64, 8192)), dim3(256), 0, st, P_out, (uint64_t)0, acc / 64, F);
+            if (gacc >= 64)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fence_build_kernel<pos_t>), dim3(grid_for(gacc / 64, 8192)), dim3(256), 0, st, P_out, (uint64_t)0, gacc / 64, F);
             VLG_HIP_TRY(hipGetLastError());
             ws->fences = F;
         }
@@ -1170,9 +1250,27 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         const uint64_t meta_upper = (q->qsub[Q1] - q->qsub[Q0] + 4) * (sizeof(SegMeta) + 48) + (Q1 - Q0 + 4) * (sizeof(QueryMeta) + 96) +
                                     (budget / 8192 + (Q1 - Q0) + 8) * 48 + (1ull << 20);
         const bool launch_first = ws->arena_bytes >= budget + meta_upper + 2 * fixed;
+        // collective search: the queries of the super-chunk are cut into one contiguous piece per rank of equal join work (slots of the
+        // non-final lists, from the list lengths every rank knows); this rank filters and joins its piece [qa, qb) only
+        uint64_t qa = Q0, qb = Q1;
+        if (ws->x_ranks > 1) {
+            std::vector<uint64_t> cum(Q1 - Q0 + 1, 0);
+            for (uint64_t qi = Q0; qi < Q1; ++qi)
+                cum[qi - Q0 + 1] = cum[qi - Q0] + 1 + (pl.occ[q->qsub[qi]] ? join_slots_of(q, qi, [&](uint64_t sidx) -> uint64_t { return pl.occ[sidx]; }) : 0);
+            auto cut_at = [&](int r) -> uint64_t {
+                if (r <= 0) return Q0;
+                if (r >= ws->x_ranks) return Q1;
+                const uint64_t target = cum.back() / (uint64_t)ws->x_ranks * (uint64_t)r;
+                return Q0 + (uint64_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+            };
+            qa = std::min(cut_at(ws->x_rank), Q1);
+            qb = std::max(qa, std::min(cut_at(ws->x_rank + 1), Q1));
+            res->owned.push_back(qa);
+            res->owned.push_back(qb);
+        }
         JoinPlan jp;
         if (!launch_first) {
-            if (vlg_status s = plan_joins(q, pl, ws, Q0, Q1, join_budget, idx->hdr.n, jp)) return s;
+            if (vlg_status s = plan_joins(q, pl, ws, qa, qb, join_budget, idx->hdr.n, jp)) return s;
             if (vlg_status s = ws_reserve(ws, phys_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
         }
         Arena A{ws->arena, ws->arena_bytes};
@@ -1190,10 +1288,10 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         uint64_t pc_cap = 0;
         if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, trail, wide)) return s;
         if (launch_first)
-            if (vlg_status s = plan_joins(q, pl, ws, Q0, Q1, join_budget, idx->hdr.n, jp)) return s;
+            if (vlg_status s = plan_joins(q, pl, ws, qa, qb, join_budget, idx->hdr.n, jp)) return s;
         tr.mark("locate + sort");
         for (uint64_t s = q->qsub[Q0]; s < q->qsub[Q1]; ++s) poff_sub[s] = pl.occ[s] ? poff[pl.did[s]] : 0;
-        if (vlg_status s = run_joins<pos_t>(idx->hdr.n, q, ws, res, pl, poff_sub, P, A, Pc, pc_cap, Q0, Q1, jp, d_stats, tr)) return s;
+        if (vlg_status s = run_joins<pos_t>(idx->hdr.n, q, ws, res, pl, poff_sub, P, A, Pc, pc_cap, qa, qb, jp, d_stats, tr)) return s;
         Q0 = Q1;
     }
     return VLG_OK;

@@ -147,6 +147,37 @@ class Comm:
             pass
 
 
+def host_exchange(dist):
+    """An exchange callback for Workspace.set_exchange that moves the pieces through torch.distributed on the HOST (D2H, all_gather
+    of padded uint8 tensors, H2D): for rehearsals of the collective search with several gloo ranks on one device, and for hosts
+    whose ranks have no RCCL between them.  The production path is Workspace.set_comm (RCCL over xGMI)."""
+    import ctypes as C
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def exchange(d_buf, counts, elem_bytes, n_ranks, rank, stream):
+        if hip.hipStreamSynchronize(stream):
+            return 2
+        sizes = [c * elem_bytes for c in counts]
+        offs = [0]
+        for b in sizes:
+            offs.append(offs[-1] + b)
+        mx = max(max(sizes), 1)
+        mine = torch.zeros(mx, dtype=torch.uint8)
+        if sizes[rank] and hip.hipMemcpy(mine.data_ptr(), d_buf + offs[rank], sizes[rank], 2):      # device -> host
+            return 3
+        parts = [torch.zeros(mx, dtype=torch.uint8) for _ in range(n_ranks)]
+        dist.all_gather(parts, mine)
+        for r in range(n_ranks):
+            if r != rank and sizes[r] and hip.hipMemcpy(d_buf + offs[r], parts[r].data_ptr(), sizes[r], 1):   # host -> device
+                return 4
+        return 0
+    return exchange
+
+
 def replicate_index(idx, dist, device, src=0, comm=None):
     """Broadcast the index image from rank `src` to every rank's HBM and attach to it.  `idx` is None elsewhere.
     With a Comm (RCCL through the C-ABI) this is vlg_index_broadcast: one ncclBroadcast straight out of / into the index's own

@@ -42,6 +42,14 @@ class SearchResult:
         except Exception:
             pass
 
+    def owned_queries(self):
+        """[(begin, end), ...] of the queries this rank joined in a collective search; [] after a single-GPU search (all of them)"""
+        n = C.c_uint32()
+        check(lib().vlg_result_owned_queries(self._h, None, 0, C.byref(n)))
+        r = np.zeros(2 * max(n.value, 1), dtype=np.uint64)
+        check(lib().vlg_result_owned_queries(self._h, r.ctypes.data, n.value, C.byref(n)))
+        return [(int(r[2 * i]), int(r[2 * i + 1])) for i in range(n.value)]
+
     def fetch(self):
         if self._fetched is None:
             nq = self.summary["n_queries"]
@@ -112,6 +120,25 @@ class Workspace:
 
     def set_option(self, name, value):
         check(lib().vlg_workspace_set_option(self._h, name.encode(), int(value)))
+
+    def set_comm(self, comm):
+        """Collective searches over the ranks of an RCCL communicator (vlg_matching_amd.dist.Comm): the distinct lists of a batch are
+        sharded for locate + sort and all-gathered, the queries are sharded for the joins.  None: single-GPU searches again."""
+        check(lib().vlg_workspace_set_comm(self._h, comm._h if comm is not None else None))
+        self._comm = comm
+
+    def set_exchange(self, n_ranks, rank, callback):
+        """The same with the caller moving the bytes: callback(d_buf, counts, elem_bytes, n_ranks, rank, stream) -> 0, an in-place
+        all-gather of device pieces (vlg_workspace_set_exchange)."""
+        def trampoline(ctx, d_buf, counts_ptr, elem_bytes, n, r, stream):
+            try:
+                return int(callback(d_buf, [int(counts_ptr[i]) for i in range(n)], int(elem_bytes), int(n), int(r), stream) or 0)
+            except Exception as e:                                   # an exception must not cross the C frame
+                import sys
+                print("exchange callback failed: %r" % (e,), file=sys.stderr)
+                return 1
+        self._exchange_cb = capi.EXCHANGE_FN(trampoline)
+        check(lib().vlg_workspace_set_exchange(self._h, int(n_ranks), int(rank), self._exchange_cb, None))
 
     def profile(self, enable=True):
         check(lib().vlg_workspace_profile(self._h, 1 if enable else 0))
