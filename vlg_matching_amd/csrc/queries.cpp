@@ -2,7 +2,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 #include "common.hpp"
 #include "search_types.hpp"
@@ -141,26 +143,62 @@ extern "C" vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_of
     q->nq = n_queries;
     q->qsub.assign(1, 0);
     q->suboff.assign(1, 0);
+    // The batch is parsed by slices on host threads (a query is a small state machine over its own characters; 10^5 of them take
+    // 25 ms on one core) and the slices' pieces are stitched together in batch order.
+    struct Slice {
+        std::vector<uint8_t> blob;
+        std::vector<uint64_t> sublen, lo, hi, end_len;
+        std::vector<uint32_t> k;
+        vlg_status first_err = VLG_OK;
+        std::string first_why;
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint64_t n_slices = n_queries >= 8192 ? std::min<uint64_t>(std::min<unsigned>(hw, 16u), n_queries / 2048) : 1;
+    std::vector<Slice> slices(std::max<uint64_t>(n_slices, 1));
+    auto work = [&](uint64_t si) {
+        Slice& sl = slices[si];
+        const uint64_t b = n_queries * si / slices.size(), e = n_queries * (si + 1) / slices.size();
+        sl.k.reserve(e - b); sl.end_len.reserve(e - b);
+        for (uint64_t i = b; i < e; ++i) {
+            Parsed p;
+            std::string why;
+            const char* re = h_text + h_off[i];
+            vlg_status st = parse_one(re, h_off[i + 1] - h_off[i], dialect, p, why);
+            if (h_status) h_status[i] = st;
+            if (st) {
+                if (!sl.first_err) { sl.first_err = st; sl.first_why = "query " + std::to_string(i) + ": " + why; }
+            } else {
+                for (size_t s = 0; s < p.sub.size(); ++s) {
+                    sl.blob.insert(sl.blob.end(), re + p.sub[s].first, re + p.sub[s].first + p.sub[s].second);
+                    sl.sublen.push_back(p.sub[s].second);
+                    sl.lo.push_back(p.lo[s]);
+                    sl.hi.push_back(p.hi[s]);
+                }
+            }
+            sl.k.push_back(st ? 0u : (uint32_t)p.sub.size());      // a failed query keeps zero sub-patterns
+            sl.end_len.push_back(st ? 0 : p.end_len);
+        }
+    };
+    if (slices.size() == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (uint64_t si = 0; si < slices.size(); ++si) th.emplace_back(work, si);
+        for (auto& t : th) t.join();
+    }
     vlg_status first_err = VLG_OK;
     std::string first_why;
-    for (uint64_t i = 0; i < n_queries; ++i) {
-        Parsed p;
-        std::string why;
-        const char* re = h_text + h_off[i];
-        vlg_status st = parse_one(re, h_off[i + 1] - h_off[i], dialect, p, why);
-        if (h_status) h_status[i] = st;
-        if (st) {
-            if (!first_err) { first_err = st; first_why = "query " + std::to_string(i) + ": " + why; }
-        } else {
-            for (size_t s = 0; s < p.sub.size(); ++s) {
-                q->blob.insert(q->blob.end(), re + p.sub[s].first, re + p.sub[s].first + p.sub[s].second);
-                q->suboff.push_back(q->blob.size());
-                q->lo.push_back(p.lo[s]);
-                q->hi.push_back(p.hi[s]);
-            }
-        }
-        q->qsub.push_back(q->suboff.size() - 1);     // a failed query keeps zero sub-patterns
-        q->end_len.push_back(st ? 0 : p.end_len);
+    uint64_t tot_blob = 0, tot_sub = 0;
+    for (const Slice& sl : slices) { tot_blob += sl.blob.size(); tot_sub += sl.sublen.size(); }
+    q->blob.reserve(tot_blob + 16); q->suboff.reserve(tot_sub + 1); q->lo.reserve(tot_sub); q->hi.reserve(tot_sub);
+    q->qsub.reserve(n_queries + 1); q->end_len.reserve(n_queries);
+    for (const Slice& sl : slices) {
+        if (sl.first_err && !first_err) { first_err = sl.first_err; first_why = sl.first_why; }
+        q->blob.insert(q->blob.end(), sl.blob.begin(), sl.blob.end());
+        for (uint64_t len : sl.sublen) q->suboff.push_back(q->suboff.back() + len);
+        q->lo.insert(q->lo.end(), sl.lo.begin(), sl.lo.end());
+        q->hi.insert(q->hi.end(), sl.hi.begin(), sl.hi.end());
+        for (uint32_t k : sl.k) q->qsub.push_back(q->qsub.back() + k);
+        q->end_len.insert(q->end_len.end(), sl.end_len.begin(), sl.end_len.end());
     }
     q->nsub = q->suboff.size() - 1;
     if (first_err && !h_status) { delete q; return fail(first_err, first_why); }
