@@ -123,8 +123,9 @@ vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_parts* sizes, 
  * (BASELINE config 5; include/sdsl/rrr_vector.hpp).  Every search entry point accepts it and returns identical results.
  * Blocks of 63 bits are stored as a 6-bit class and an offset of ceil(log2 C(63,k)) bits -- the sizes of rrr_vector<63>; the
  * offset numbers the blocks of a class by halves (csrc/rrr_code.hpp) instead of bit by bit, so that a rank decodes in a fixed
- * short sequence of table lookups.  The image is this library's own (blob magic "VGLB2"; vlg_index_load_sdsl reads the plain
- * csa_wt<wt_huff<>> format only): an rrr index is always made here, from a plain one.  `src` must be a plain index. */
+ * short sequence of table lookups.  The device image is this library's own (blob magic "VGLB2"); a stock
+ * csa_wt<wt_huff<rrr_vector<63>>> file is read by vlg_index_load_sdsl_kind, which decodes its blocks and ends here.  `src` must be
+ * a plain index. */
 #define VLG_BV_PLAIN 0
 #define VLG_BV_RRR63 1
 #define VLG_BV_INT_MATRIX 2          /* integer-alphabet index (vlg_index_build_int): bv_kind of vlg_index_info */
@@ -179,6 +180,13 @@ vlg_status vlg_sdsl_file_open(const char* path, uint32_t sa_sample_dens, vlg_sds
 vlg_status vlg_sdsl_file_parts(const vlg_sdsl_file* f, vlg_index_parts* parts);   /* pointers stay valid until close */
 void vlg_sdsl_file_close(vlg_sdsl_file* f);
 vlg_status vlg_index_load_sdsl(const char* path, uint32_t sa_sample_dens, vlg_index** out);
+/* The same for the file of csa_wt<wt_huff<rrr_vector<63>>, t_dens, t_inv_dens> (bv_kind = VLG_BV_RRR63; the index type of
+ * benchmark/indexing_count/index.config:10 and BASELINE config 5): the wavelet tree's bit-vector is an rrr_vector<63>
+ * (include/sdsl/rrr_vector.hpp:349-372: size, block classes, offsets, pointer and rank samples, inversion bits; its rank / select
+ * supports store nothing).  Every block is decoded on the host (rrr_helper.hpp:304-375) and the index is kept rrr-coded on the
+ * device in this library's block numbering (vlg_index_compress): same sizes, same answers.  VLG_BV_PLAIN = vlg_index_load_sdsl. */
+vlg_status vlg_sdsl_file_open_kind(const char* path, uint32_t sa_sample_dens, int bv_kind, vlg_sdsl_file** out);
+vlg_status vlg_index_load_sdsl_kind(const char* path, uint32_t sa_sample_dens, int bv_kind, vlg_index** out);
 
 /* One contiguous device image of the read-only index, for replication across the GPUs of a node
  * (SURVEY.md 8e): the owner exports it into caller-provided HBM, the caller moves it with RCCL

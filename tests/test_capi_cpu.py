@@ -173,3 +173,31 @@ print("done", ok, bad)
     assert r.returncode == 0 and r.stdout.startswith("done"), (r.returncode, r.stdout[-300:], r.stderr[-600:])
     ok, bad = (int(x) for x in r.stdout.split()[1:3])
     assert bad > 200                                          # most damage is detected; a flipped payload bit can still parse
+
+
+def test_sdsl_file_reader_on_reference_written_rrr_image(V, refmod, tmp_path):
+    """A csa_wt<wt_huff<rrr_vector<63>>> image whose wavelet tree was built and serialised by the reference's OWN rrr_vector<63>
+    (oracle/_ref, variant 2: include/sdsl/rrr_vector.hpp:145-237, 349-372) parses -- every block decoded from its class and offset,
+    inverted super-blocks included -- into exactly the plain bit-vector, tree, samples and alphabet of the plain index."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import bwt_from_sa, dna_text, skewed_text
+    O = refmod
+    rng = np.random.default_rng(7)
+    dense = bytes(rng.choice(np.frombuffer(b"aaaaaaaaaaaaaaab", dtype=np.uint8), 40000).tolist())   # long runs: inverted super-blocks
+    for name, text in [("abra", b"abracadabrasimsalabim"), ("dna", dna_text(20000, 3).tobytes()), ("zipf", skewed_text(30000, 4).tobytes()),
+                       ("dense", dense), ("one", b"a"), ("63", b"ab" * 63), ("allsym", bytes(range(1, 256)) * 3)]:
+        tz = np.frombuffer(text + b"\0", dtype=np.uint8)
+        sa = O.suffix_array(tz)
+        R = O.RefIndex(bwt_from_sa(tz, sa), sa, 2)
+        path = tmp_path / (name + ".rrr.sdsl")
+        R.write_csa_image(path, sa)
+        got = V.index.read_sdsl_file(path, rrr=True)
+        want = O.Index.from_text(text).parts()
+        assert got["n"] == want["n"] and got["sigma"] == want["sigma"] and got["bv_bits"] == want["bv_bits"], name
+        assert (got["bv_words"] == want["bv_words"]).all(), name
+        assert (got["char2comp"] == want["char2comp"]).all() and (got["C"] == want["C"]).all() and (got["samples"] == want["samples"]).all()
+        for f in ("bv_pos", "parent", "child"):
+            assert (got["nodes"][f] == want["nodes"][f]).all(), f
+    with pytest.raises(V.VlgError):
+        V.index.read_sdsl_file(tmp_path / "dna.rrr.sdsl", rrr=False)        # an rrr image is not a plain one

@@ -750,6 +750,28 @@ def test_load_index_stored_by_stock_sdsl(V, refmod, tmp_path):
         assert res.tuples(i).tolist() == o.search(q).tolist(), q
 
 
+def test_load_rrr_index_stored_by_stock_sdsl(V, refmod, tmp_path):
+    """BASELINE config 5's index type from a stock file: csa_wt<wt_huff<rrr_vector<63>>> serialised by the reference's own code
+    (oracle/_ref) -> vlg_index_load_sdsl_kind(VLG_BV_RRR63) -> an rrr index on the device with the plain index's answers."""
+    O = refmod
+    from util import bwt_from_sa
+    text = skewed_text(60000, 12).tobytes()
+    tz = np.frombuffer(text + bytes(1), dtype=np.uint8)
+    sa = O.suffix_array(tz)
+    path = tmp_path / "idx.rrr.sdsl"
+    O.RefIndex(bwt_from_sa(tz, sa), sa, 2).write_csa_image(path, sa)
+    idx = V.VlgIndex.load_sdsl(path, rrr=True)
+    assert idx.info()["bv_kind"] == 1
+    built = V.VlgIndex.build(text)
+    qs = random_queries(text, np.random.default_rng(2), 150, kmax=3, mmax=3)
+    a, b = idx.search(qs), built.search(qs)
+    for x, y in zip(a.fetch(), b.fetch()):
+        assert (x == y).all()
+    o = O.Index.from_text(text)
+    for i in (0, 33, 149):
+        assert a.tuples(i).tolist() == o.search(qs[i]).tolist()
+
+
 @pytest.mark.parametrize("name", ["abracadabra", "one_byte", "100a", "all_symbols", "dna_50k", "zipf40"])
 def test_suffix_array_device(torch_cuda, V, oracle, name):
     """The device suffix sorter on its own (what construct_sa computes): SA of text + sentinel."""

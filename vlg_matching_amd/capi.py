@@ -82,6 +82,8 @@ SYMBOLS = [
     ("vlg_sdsl_file_parts", _I, [_P, C.POINTER(IndexParts)]),
     ("vlg_sdsl_file_close", None, [_P]),
     ("vlg_index_load_sdsl", _I, [C.c_char_p, C.c_uint32, C.POINTER(_P)]),
+    ("vlg_sdsl_file_open_kind", _I, [C.c_char_p, C.c_uint32, _I, C.POINTER(_P)]),
+    ("vlg_index_load_sdsl_kind", _I, [C.c_char_p, C.c_uint32, _I, C.POINTER(_P)]),
     ("vlg_index_save_sdsl", _I, [_P, C.c_char_p]),
     ("vlg_suffix_array_device", _I, [_P, _U64, _P, _P]),
     ("vlg_index_isa_samples", _I, [_P, C.c_uint32, _P, _U64]),

@@ -7,6 +7,8 @@
 //   select_support_mcl     include/sdsl/select_support_mcl.hpp:424-494
 //   _byte_tree / _node     include/sdsl/wt_helper.hpp:112-131,275-301      22 bytes per node
 //   byte_alphabet          lib/csa_alphabet_strategy.cpp:103-121
+//   rrr_vector<63>         include/sdsl/rrr_vector.hpp:349-372 (csa_wt<wt_huff<rrr_vector<63>>>, BASELINE config 5: the stock image is
+//                          decoded block by block on the host and re-coded on the device, vlg_index_load_sdsl_kind)
 // Host-only: nothing here touches the GPU.
 #include <cstdio>
 #include <cstring>
@@ -65,7 +67,67 @@ uint64_t read_packed(const uint8_t* words, uint64_t idx, uint8_t width)
 
 }  // namespace
 
-static vlg_status sdsl_file_open_impl(const char* path, uint32_t sa_sample_dens, vlg_sdsl_file** out)
+// rrr_vector<63> (include/sdsl/rrr_vector.hpp:349-372: size, bt, btnr, btnrp, rank samples, invert) back to plain bits.  Block i
+// holds k ones, k = the stored class, or 63 - it where its super-block of 32 blocks is inverted (:186-201, 469-471); its offset of
+// space_for_bt(k) bits (rrr_helper.hpp:282-284) numbers it among the blocks of that class (bin_to_nr, :304-320): bit b is set iff
+// nr >= C(62 - b, k) for the k still to place (decode_bit, :323-375, walked over the whole block).
+static bool rrr63_to_plain(Cursor& c, uint64_t& bits_out, std::vector<uint64_t>& plain)
+{
+    const uint64_t size = c.get<uint64_t>();
+    uint64_t bt_bits, btnr_bits, b3;
+    uint8_t bt_w, w1, w3;
+    const uint8_t* bt = c.int_vector(0, bt_bits, bt_w);
+    const uint8_t* btnr = c.int_vector(1, btnr_bits, w1);
+    c.skip_int_vector(0);                                      // btnrp (pointer samples: recomputed by walking)
+    c.skip_int_vector(0);                                      // rank samples
+    const uint8_t* inv = c.int_vector(1, b3, w3);
+    if (!c.ok || bt_w != 6) return false;                      // bits::hi(63) + 1
+    const uint64_t n_blocks = bt_bits / 6;
+    if (n_blocks != (size + 63) / 63 || b3 != (n_blocks + 31) / 32) return false;
+    static uint64_t binom[64][64];
+    static uint8_t space[64];
+    static bool ready = false;
+    if (!ready) {
+        for (int nn = 0; nn < 64; ++nn) for (int k = 0; k < 64; ++k) binom[nn][k] = k == 0 ? 1 : (nn == 0 ? 0 : (k > nn ? 0 : binom[nn - 1][k - 1] + binom[nn - 1][k]));
+        for (int k = 0; k < 64; ++k) space[k] = binom[63][k] == 1 ? 0 : (uint8_t)(64 - __builtin_clzll(binom[63][k]));
+        ready = true;
+    }
+    bits_out = size;
+    plain.assign((size + 63) / 64 + 1, 0);
+    uint64_t pos = 0;                                          // bit position in btnr
+    for (uint64_t i = 0; i < n_blocks; ++i) {
+        const uint32_t stored = (uint32_t)read_packed(bt, i, 6);
+        const bool inverted = (inv[(i / 32) >> 3] >> ((i / 32) & 7)) & 1;
+        uint32_t k = inverted ? 63 - stored : stored;
+        const uint32_t len = space[stored];
+        if (pos + len > btnr_bits) return false;
+        uint64_t nr = 0;
+        if (len) {
+            const uint64_t wq = pos >> 6, o = pos & 63;
+            uint64_t lo, hi = 0;
+            memcpy(&lo, btnr + 8 * wq, 8);
+            nr = lo >> o;
+            if (o + len > 64) { memcpy(&hi, btnr + 8 * (wq + 1), 8); nr |= hi << (64 - o); }
+            if (len < 64) nr &= (1ull << len) - 1;
+        }
+        pos += len;
+        uint64_t bin = 0;
+        if (k == 63) bin = (1ull << 63) - 1;
+        else for (uint32_t b = 0, nn = 63; b < 63 && k; ++b, --nn) {
+            const uint64_t cc = binom[nn - 1][k];
+            if (nr >= cc) { nr -= cc; --k; bin |= 1ull << b; }
+        }
+        const uint64_t at = i * 63;
+        if (at >= size) break;
+        const uint64_t take = size - at < 63 ? size - at : 63;
+        if (take < 63) bin &= (1ull << take) - 1;
+        plain[at >> 6] |= bin << (at & 63);
+        if ((at & 63) + take > 64) plain[(at >> 6) + 1] |= bin >> (64 - (at & 63));
+    }
+    return c.ok;
+}
+
+static vlg_status sdsl_file_open_impl(const char* path, uint32_t sa_sample_dens, int bv_kind, vlg_sdsl_file** out)
 {
     using namespace vlg;
     FILE* fp = fopen(path, "rb");
@@ -85,14 +147,20 @@ static vlg_status sdsl_file_open_impl(const char* path, uint32_t sa_sample_dens,
     // ---- wavelet tree (wt_pc.hpp:638-652) -----------------------------------------------------------
     f->n = c.get<uint64_t>();
     f->wt_sigma = c.get<uint64_t>();
-    uint8_t w;
-    const uint8_t* bvw = c.int_vector(1, f->bv_bits, w);
-    if (!c.ok || f->wt_sigma == 0 || f->wt_sigma > 256) return bad("wavelet tree header");
-    f->bv.assign((f->bv_bits + 63) / 64 + 1, 0);
-    if (f->bv_bits) memcpy(f->bv.data(), bvw, ((f->bv_bits + 63) / 64) * 8);
-    c.skip_int_vector(64);                                    // rank_support_v basic blocks (rebuilt on the device as counts)
-    c.skip_select_mcl();                                      // select_1
-    c.skip_select_mcl();                                      // select_0
+    if (bv_kind == VLG_BV_RRR63) {
+        // wt_huff<rrr_vector<63>>: the bit-vector is an rrr_vector, its rank / select supports store nothing (rrr_vector.hpp:511-522)
+        if (!c.ok || f->wt_sigma == 0 || f->wt_sigma > 256) return bad("wavelet tree header");
+        if (!rrr63_to_plain(c, f->bv_bits, f->bv)) return bad("rrr_vector<63>");
+    } else {
+        uint8_t w;
+        const uint8_t* bvw = c.int_vector(1, f->bv_bits, w);
+        if (!c.ok || f->wt_sigma == 0 || f->wt_sigma > 256) return bad("wavelet tree header");
+        f->bv.assign((f->bv_bits + 63) / 64 + 1, 0);
+        if (f->bv_bits) memcpy(f->bv.data(), bvw, ((f->bv_bits + 63) / 64) * 8);
+        c.skip_int_vector(64);                                    // rank_support_v basic blocks (rebuilt on the device as counts)
+        c.skip_select_mcl();                                      // select_1
+        c.skip_select_mcl();                                      // select_0
+    }
     uint64_t n_nodes = c.get<uint64_t>();
     if (!c.ok || n_nodes != 2 * f->wt_sigma - 1) return bad("tree size");
     f->nodes.resize(n_nodes);
@@ -137,14 +205,20 @@ static vlg_status sdsl_file_open_impl(const char* path, uint32_t sa_sample_dens,
 }
 
 // No exception may cross the C boundary: a damaged file that asks for absurd sizes ends as a status, not std::terminate.
-extern "C" vlg_status vlg_sdsl_file_open(const char* path, uint32_t sa_sample_dens, vlg_sdsl_file** out)
+extern "C" vlg_status vlg_sdsl_file_open_kind(const char* path, uint32_t sa_sample_dens, int bv_kind, vlg_sdsl_file** out)
 {
     using namespace vlg;
     if (!path || !out) return fail(VLG_E_INVALID, "null argument");
     *out = nullptr;
-    try { return sdsl_file_open_impl(path, sa_sample_dens, out); }
+    if (bv_kind != VLG_BV_PLAIN && bv_kind != VLG_BV_RRR63) return fail(VLG_E_INVALID, "unknown bit-vector kind");
+    try { return sdsl_file_open_impl(path, sa_sample_dens, bv_kind, out); }
     catch (const std::bad_alloc&) { return fail(VLG_E_OOM, "out of host memory while reading the index file"); }
     catch (const std::exception& e) { return fail(VLG_E_INVALID, std::string("not a csa_wt<wt_huff<>> file (") + e.what() + ")"); }
+}
+
+extern "C" vlg_status vlg_sdsl_file_open(const char* path, uint32_t sa_sample_dens, vlg_sdsl_file** out)
+{
+    return vlg_sdsl_file_open_kind(path, sa_sample_dens, VLG_BV_PLAIN, out);
 }
 
 extern "C" vlg_status vlg_sdsl_file_parts(const vlg_sdsl_file* f, vlg_index_parts* p)
@@ -161,17 +235,27 @@ extern "C" vlg_status vlg_sdsl_file_parts(const vlg_sdsl_file* f, vlg_index_part
 
 extern "C" void vlg_sdsl_file_close(vlg_sdsl_file* f) { delete f; }
 
-extern "C" vlg_status vlg_index_load_sdsl(const char* path, uint32_t sa_sample_dens, vlg_index** out)
+extern "C" vlg_status vlg_index_load_sdsl_kind(const char* path, uint32_t sa_sample_dens, int bv_kind, vlg_index** out)
 {
     if (!out) return vlg::fail(VLG_E_INVALID, "null argument");
     *out = nullptr;
     vlg_sdsl_file* f = nullptr;
-    if (vlg_status st = vlg_sdsl_file_open(path, sa_sample_dens, &f)) return st;
+    if (vlg_status st = vlg_sdsl_file_open_kind(path, sa_sample_dens, bv_kind, &f)) return st;
     vlg_index_parts p;
     vlg_sdsl_file_parts(f, &p);
-    vlg_status st = vlg_index_from_parts(&p, out);
+    vlg_index* plain = nullptr;
+    vlg_status st = vlg_index_from_parts(&p, &plain);
     vlg_sdsl_file_close(f);
+    if (st || bv_kind == VLG_BV_PLAIN) { *out = plain; return st; }
+    // a stock rrr image: its blocks were decoded on the host; the device index keeps them rrr-coded in its own block numbering
+    st = vlg_index_compress(plain, VLG_BV_RRR63, out);
+    vlg_index_destroy(plain);
     return st;
+}
+
+extern "C" vlg_status vlg_index_load_sdsl(const char* path, uint32_t sa_sample_dens, vlg_index** out)
+{
+    return vlg_index_load_sdsl_kind(path, sa_sample_dens, VLG_BV_PLAIN, out);
 }
 
 // =============================================================================================

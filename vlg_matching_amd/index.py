@@ -85,10 +85,11 @@ class SearchResult:
         return tup[toff[q]: toff[q + 1]].reshape(-1, max(k, 1)) if k else np.zeros((0, 0), np.uint64)
 
 
-def read_sdsl_file(path, dens=32):
-    """Host-only parse of a stock sdsl csa_wt<wt_huff<>> file -> parts dict (same keys as VlgIndex.export_parts())."""
+def read_sdsl_file(path, dens=32, rrr=False):
+    """Host-only parse of a stock sdsl csa_wt<wt_huff<>> file (rrr: csa_wt<wt_huff<rrr_vector<63>>>, its blocks decoded back to
+    plain bits) -> parts dict (same keys as VlgIndex.export_parts())."""
     f = C.c_void_p()
-    check(lib().vlg_sdsl_file_open(str(path).encode(), dens, C.byref(f)))
+    check(lib().vlg_sdsl_file_open_kind(str(path).encode(), dens, 1 if rrr else 0, C.byref(f)))
     try:
         p = capi.IndexParts()
         check(lib().vlg_sdsl_file_parts(f, C.byref(p)))
@@ -300,10 +301,10 @@ class VlgIndex:
         return cls(h)
 
     @classmethod
-    def load_sdsl(cls, path, dens=32):
-        """An index stored by stock sdsl (csa_wt<wt_huff<>> file)."""
+    def load_sdsl(cls, path, dens=32, rrr=False):
+        """An index stored by stock sdsl: a csa_wt<wt_huff<>> file, or (rrr) a csa_wt<wt_huff<rrr_vector<63>>> file."""
         h = C.c_void_p()
-        check(lib().vlg_index_load_sdsl(str(path).encode(), dens, C.byref(h)))
+        check(lib().vlg_index_load_sdsl_kind(str(path).encode(), dens, 1 if rrr else 0, C.byref(h)))
         return cls(h)
 
     def save_sdsl(self, path):
