@@ -84,18 +84,34 @@ def main():
         ws = Workspace(int(rng.choice([0, 64 << 20])))
         for k_, v_ in opts.items():
             ws.set_option(k_, v_)
+        os.environ["VLG_FORCE_POS64"] = "0"
         other = idx.compress() if rng.random() < 0.3 else idx        # the rrr-63 variant of the index must answer the same
+        mode = str(rng.choice(["0", "0", "0", "1", "2"]))              # 64-bit positions / wide SA indices with 32-bit positions on small texts
+        variant = "plain"
+        if mode != "0":
+            os.environ["VLG_FORCE_POS64"] = mode
+            other = V.VlgIndex.build(text)
+            variant = "pos64=" + mode
+        elif rng.random() < 0.3:                                     # text_order_sa_sampling on top (plain or rrr)
+            other = other.resample(text_order=True, dens=int(rng.choice([1, 4, 32, 64])))
+            variant = "text-order"
+        os.environ["VLG_NO_SPECULATIVE_COMPACT"] = str(rng.choice(["0", "0", "1"]))
+        opts["variant"] = variant
         try:
             b = other.search(qs, workspace=ws, strict=False)
         except V.capi.VlgError as e:
             if "workspace" in str(e):
                 continue
             raise
+        finally:
+            os.environ["VLG_FORCE_POS64"] = "0"
         for k_ in ("n_matches", "checksum", "n_tuple_values", "logical_occurrences"):
             assert a.summary[k_] == b.summary[k_], (seed, rounds, k_, opts, other is not idx)
         for x, y in zip(a.fetch(), b.fetch()):
             assert (x == y).all(), (seed, rounds, opts, other is not idx)
         rounds += 1
+    os.environ["VLG_NO_SPECULATIVE_COMPACT"] = "0"
+    os.environ["VLG_FORCE_POS64"] = "0"
     print("fuzz ok: %d batches, seed %d" % (rounds, seed))
 
 

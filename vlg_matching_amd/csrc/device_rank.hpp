@@ -103,32 +103,21 @@ struct RrrBV {
         uint64_t ptr = (uint64_t)h0.y << 6;
         uint64_t c0 = (uint64_t)h0.z | ((uint64_t)h0.w << 32), c1 = (uint64_t)h1.x | ((uint64_t)h1.y << 32),
                  c2 = (uint64_t)h1.z | ((uint64_t)h1.w << 32);
-        // classes in front of the block (rrr_vector.hpp:463-467).  Every class sits at a FIXED place of the 192 bits, so the sum over
-        // the first blk of them is unrolled with compile-time shifts and a predicate: 31 independent width lookups, no chain of
-        // 192-bit shifts whose length is the slowest lane's blk anyway.
+        // classes in front of the block (rrr_vector.hpp:463-467): the 192 bits of classes are shifted past one class per step
+        // (measured in round 3: unrolling the sum over the 31 fixed places with a predicate is SLOWER -- C5 locate 33.3 vs 28.8 ms)
         uint32_t bits = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < kRrrBlocksPerSuper - 1; ++j) {
-            const uint32_t b = 6 * j, w = b >> 6, o = b & 63;
-            const uint64_t lo = w == 0 ? c0 : (w == 1 ? c1 : c2);
-            uint64_t v = lo >> o;
-            if (o > 58) v |= (w == 0 ? c1 : c2) << (64 - o);
-            const uint32_t k = (uint32_t)v & 63u;
-            const bool in = j < blk;
-            rank += in ? k : 0u;
-            bits += in ? (uint32_t)s.t.space[k] : 0u;
+        for (uint32_t j = 0; j < blk; ++j) {
+            const uint32_t k = (uint32_t)c0 & 63u;
+            rank += k;
+            bits += s.t.space[k];
+            c0 = (c0 >> 6) | (c1 << 58);
+            c1 = (c1 >> 6) | (c2 << 58);
+            c2 >>= 6;
         }
         ptr += bits;
         bit = 0;
         if (kBit || off) {
-            uint32_t k;
-            {                                                     // the block's own class: a run-time place
-                const uint32_t b = 6 * blk, w = b >> 6, o = b & 63;
-                const uint64_t lo = w == 0 ? c0 : (w == 1 ? c1 : c2);
-                uint64_t v = lo >> o;
-                if (o > 58) v |= (w == 0 ? c1 : c2) << (64 - o);
-                k = (uint32_t)v & 63u;
-            }
+            const uint32_t k = (uint32_t)c0 & 63u;
             const uint32_t len = s.t.space[k];
             uint64_t o = 0;
             if (len) {
