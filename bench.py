@@ -113,6 +113,7 @@ CLASSES = {
     "join_chain": ("join_jump + chain_tiles/walk/emit", ["join_jump_kernel", "chain_tiles_kernel", "chain_walk_kernel", "chain_emit_kernel"],
                    "8 B per slot of every first list"),
     "gather": ("join_gather_kernel", ["join_gather_kernel"], "8 B per match (and per tuple value) written"),
+    "exchange": ("vlg_comm_allgatherv (RCCL broadcasts of the ranks' sorted lists)", [], "4 B per occurrence located by another rank (received)"),
     "join": ("vlg_join_batch", [], ""),
 }
 
@@ -573,7 +574,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32" if info["pos_bytes"] == 4 else "u64",
+            # text positions are 32-bit inside the kernels up to n = 2^32 + 1 (C4: 33-bit SA indices, 32-bit positions); u64 at the boundary
+            "dtype": "u32" if info["n"] <= (1 << 32) + 1 and os.environ.get("VLG_FORCE_POS64", "0") != "1" else "u64",
             "data": "synthetic",
             "config": {"workload": "%s%s: %s text n=%d (seed %d), %d queries/GPU x k=%d, m=%d, gap .{%d,%d}?, t_dens=32"
                                    % (args.config, "" if args.scale == 1.0 else " x%g" % args.scale, cfg["kind"], cfg["n"],

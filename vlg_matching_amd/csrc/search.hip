@@ -71,6 +71,10 @@ struct vlg_workspace {
     uint64_t trail_n = 0;               // text length it was last used for
     // one process per GPU: a collective search shards the DISTINCT LISTS of a batch over the ranks for locate + sort,
     // exchanges the sorted lists (all-gather) and shards the QUERIES for filter + join
+    // device memory of a batch's first steps (SA intervals, the interval plan's arrays, counters): kept from batch to batch -- a
+    // hipMalloc / hipFree pair per batch cost more than the kernels between them
+    uint8_t* head = nullptr;
+    uint64_t head_bytes = 0;
     int x_ranks = 1, x_rank = 0;
     vlg_exchange_fn x_fn = nullptr;     // in-place all-gather of device pieces; null with x_comm set = vlg_comm_allgatherv
     void* x_ctx = nullptr;
@@ -161,6 +165,18 @@ void ws_reset_stats(vlg_workspace* ws)
 
 void drain_result_cache();
 
+vlg_status ws_head(vlg_workspace* ws, uint64_t bytes, uint8_t** out)
+{
+    if (bytes > ws->head_bytes) {
+        if (ws->head) { (void)hipFree(ws->head); ws->head = nullptr; ws->head_bytes = 0; }
+        const uint64_t want = align_up(bytes + bytes / 4, 1 << 20);
+        VLG_HIP_TRY(hipMalloc((void**)&ws->head, want));
+        ws->head_bytes = want;
+    }
+    *out = ws->head;
+    return VLG_OK;
+}
+
 vlg_status ws_reserve(vlg_workspace* ws, uint64_t bytes)
 {
     if (bytes <= ws->arena_bytes) return VLG_OK;
@@ -198,6 +214,7 @@ extern "C" void vlg_workspace_destroy(vlg_workspace* ws)
     ws_collect(ws);
     for (hipEvent_t e : ws->free_events) (void)hipEventDestroy(e);
     if (ws->arena) (void)hipFree(ws->arena);
+    if (ws->head) (void)hipFree(ws->head);
     ws->host.release();
     delete ws;
 }
@@ -1341,8 +1358,23 @@ __global__ void interval_scatter_kernel(const uint64_t* __restrict__ keys, const
 // Identical SA intervals are the same occurrence list: each distinct one is located + sorted once per super-chunk and shared.
 // The distinct intervals are numbered in ascending SA order, so the sweep that locates them starts globally sorted.
 // *fallback is set (and nothing planned) when an interval does not fit its key field: the caller then plans on the host.
+// device scratch plan_on_device needs for nsub sub-patterns of nq queries
+uint64_t plan_device_bytes(uint64_t nsub, uint64_t nq, hipStream_t st, size_t* sort_tb_out = nullptr, size_t* scan_tb_out = nullptr)
+{
+    size_t sort_tb = 0, scan_tb = 0;
+    rocprim::double_buffer<uint64_t> nk(nullptr, nullptr);
+    rocprim::double_buffer<uint32_t> nv(nullptr, nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, sort_tb, nk, nv, nsub, 0, 64, st);
+    uint32_t* nu = nullptr;
+    (void)rocprim::inclusive_scan(nullptr, scan_tb, nu, nu, nsub, rocprim::plus<uint32_t>(), st);
+    if (sort_tb_out) *sort_tb_out = sort_tb;
+    if (scan_tb_out) *scan_tb_out = scan_tb;
+    const uint64_t n8 = align_up(nsub * 8, 256), n4 = align_up(nsub * 4, 256);
+    return 4 * n8 + 5 * n4 + align_up((nq + 1) * 8, 256) + align_up(std::max(sort_tb, scan_tb), 256) + 1024 + 256;
+}
+
 vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_t* d_l, const uint64_t* d_r, uint64_t n, Plan& pl, uint64_t& logical,
-                          bool* fallback)
+                          bool* fallback, uint8_t* mem /* plan_device_bytes() of device scratch */, uint64_t mem_bytes)
 {
     *fallback = false;
     const uint32_t kbits = 64 - std::max(32u, bit_width64(n - 1));
@@ -1351,18 +1383,10 @@ vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_
     pl.occ.assign(nsub, 0);
     pl.did.assign(nsub, 0);
     if (!nsub) return VLG_OK;
-    uint8_t* mem = nullptr;
     size_t sort_tb = 0, scan_tb = 0;
-    {
-        rocprim::double_buffer<uint64_t> nk(nullptr, nullptr);
-        rocprim::double_buffer<uint32_t> nv(nullptr, nullptr);
-        VLG_HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_tb, nk, nv, nsub, 0, 64, st));
-        uint32_t* nu = nullptr;
-        VLG_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_tb, nu, nu, nsub, rocprim::plus<uint32_t>(), st));
-    }
     const uint64_t n8 = align_up(nsub * 8, 256), n4 = align_up(nsub * 4, 256);
-    const uint64_t bytes = 4 * n8 + 5 * n4 + align_up((nq + 1) * 8, 256) + align_up(std::max(sort_tb, scan_tb), 256) + 1024 + 256;
-    VLG_HIP_TRY(hipMalloc((void**)&mem, bytes));
+    const uint64_t bytes = plan_device_bytes(nsub, nq, st, &sort_tb, &scan_tb);
+    if (!mem || mem_bytes < bytes) return fail(VLG_E_INTERNAL, "interval plan: scratch too small");
     uint64_t* keys_a = (uint64_t*)mem;
     uint64_t* keys_b = (uint64_t*)(mem + n8);
     uint64_t* d_dl = (uint64_t*)(mem + 2 * n8);
@@ -1408,9 +1432,7 @@ vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_
             if (h_did[s] != 0xFFFFFFFFu) { pl.did[s] = h_did[s]; pl.occ[s] = pl.docc[h_did[s]]; logical += pl.occ[s]; }
         return VLG_OK;
     };
-    const vlg_status stt = run();
-    (void)hipFree(mem);
-    return stt;
+    return run();
 }
 
 }  // namespace
@@ -1438,9 +1460,16 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - last_end).count());
     auto run = [&]() -> vlg_status {
         const uint64_t nsub = q->nsub;
-        VLG_HIP_TRY(hipMalloc((void**)&d_l, (nsub + 1) * 8));
-        VLG_HIP_TRY(hipMalloc((void**)&d_r, (nsub + 1) * 8));
-        VLG_HIP_TRY(hipMalloc((void**)&d_stats, kStatsWords * 8));
+        // SA intervals, counters and the interval plan's arrays live in the workspace's head buffer (no allocation per batch)
+        const bool may_plan_on_device = ws->dedup && idx->hdr.n <= (1ull << 33) && nsub > 0 && nsub < 0xFFFFFFF0ull;
+        const uint64_t lr_bytes = align_up((nsub + 1) * 8, 256), st_bytes = align_up(kStatsWords * 8, 256);
+        const uint64_t plan_bytes = may_plan_on_device ? plan_device_bytes(nsub, q->nq, st) : 0;
+        uint8_t* head = nullptr;
+        if (vlg_status hs = ws_head(ws, 2 * lr_bytes + st_bytes + plan_bytes, &head)) return hs;
+        d_l = (uint64_t*)head;
+        d_r = (uint64_t*)(head + lr_bytes);
+        d_stats = (unsigned long long*)(head + 2 * lr_bytes);
+        uint8_t* plan_mem = head + 2 * lr_bytes + st_bytes;
         VLG_HIP_TRY(hipMemsetAsync(d_stats, 0, kStatsWords * 8, st));
         // ---- K2: every sub-pattern's SA interval ------------------------------------------------------
         {
@@ -1450,10 +1479,10 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         }
         tr.mark("backward search");
         Plan pl;
-        bool device_plan = ws->dedup && idx->hdr.n <= (1ull << 33) && nsub > 0 && nsub < 0xFFFFFFF0ull;
+        bool device_plan = may_plan_on_device;
         if (device_plan) {
             bool fallback = false;
-            if (vlg_status s = plan_on_device(q, ws, d_l, d_r, idx->hdr.n, pl, res->sum.logical_occurrences, &fallback)) return s;
+            if (vlg_status s = plan_on_device(q, ws, d_l, d_r, idx->hdr.n, pl, res->sum.logical_occurrences, &fallback, plan_mem, plan_bytes)) return s;
             if (fallback) { device_plan = false; pl = Plan(); res->sum.logical_occurrences = 0; }
         }
         if (!device_plan) {
@@ -1532,9 +1561,6 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         catch (const std::bad_alloc&) { stt = fail(VLG_E_OOM, "out of host memory while planning the batch (pinned staging)"); }
     }
     tr.mark("statistics");
-    if (d_l) (void)hipFree(d_l);
-    if (d_r) (void)hipFree(d_r);
-    if (d_stats) (void)hipFree(d_stats);
     tr.mark("free");
     last_end = std::chrono::steady_clock::now();
     if (stt) { vlg_result_destroy(res); return stt; }
