@@ -217,6 +217,8 @@ def ref():
         R.vrefi_inverse_select.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         R.vrefi_inverse_select.restype = C.c_uint64
         R.vrefi_tree_bits.argtypes = [C.c_void_p, C.c_void_p]
+        R.vrefw_vlg_iterate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        R.vrefw_vlg_iterate.restype = C.c_uint64
         R.vref_int_alphabet.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         R.vref_int_alphabet.restype = C.c_uint64
         _REF = R
@@ -556,6 +558,22 @@ class RefWtInt:
         ref().vrefw_tree_bits(self.h, w.ctypes.data)
         bits = np.unpackbits(w.view(np.uint8), bitorder="little")[:nb]
         return bits.reshape(self.levels, self.n)
+
+    def vlg_iterate(self, ranges, lo, hi, last_len):
+        """vlg_iterator's loops (vlg_index.hpp:227-291) restated over the reference's own wt_range_walker on this tree: ranges = SA ranges
+        [(sp, ep)] of the sub-patterns, lo / hi = the start-to-start gap bounds as gapped_pattern_query stores them -> tuples [m, k]"""
+        k = len(ranges)
+        sp = np.array([r[0] for r in ranges], dtype=np.uint64)
+        ep = np.array([r[1] for r in ranges], dtype=np.uint64)
+        glo = np.array(list(lo) + [0], dtype=np.uint64)
+        ghi = np.array(list(hi) + [0], dtype=np.uint64)
+        cap = 1 << 12
+        while True:
+            out = np.zeros(cap * k, dtype=np.uint64)
+            m = int(ref().vrefw_vlg_iterate(self.h, k, sp.ctypes.data, ep.ctypes.data, glo.ctypes.data, ghi.ctypes.data, int(last_len), out.ctypes.data, cap))
+            if m <= cap:
+                return out[: m * k].reshape(m, k)
+            cap = m
 
     def count_less(self, l, length, x):
         return int(ref().vrefw_count_less(self.h, int(l), int(length), int(x)))

@@ -399,6 +399,75 @@ uint64_t vrefw_quantile(void* h, uint64_t l, uint64_t len, uint64_t q)
     return wt.sym(v);
 }
 
+// ---- vlg_iterator over the reference's OWN wt_range_walker -----------------------------------------------------------------------
+// vlg_index.hpp itself cannot be included (it pulls suffix_arrays.hpp -> construct_sa.hpp -> divsufsort.h), but everything its iterator
+// stands on can: wt_int, wt_node_cache and wt_range_walker (wt_helper.hpp:691-785) are the reference's code, compiled above.  The
+// three loops of vlg_iterator -- relax (vlg_index.hpp:227-249), pull_forward (:254-266), next (:269-291) -- and its constructor /
+// operator++ (:303-321, 345-352) are RESTATED here line by line over those real walkers; the suffix-array ranges come from the caller
+// (forward_search needs the text and the same unbuildable header).  What this pins: the tuples the paper's algorithm yields on the
+// reference's tree -- an implementation of the VLG semantics that shares no code with the merge join of oracle/vlg_oracle.c.
+// gaps[i] = (lo, hi) as gapped_pattern_query stores them (start-to-start distances, vlg_index.hpp:95).
+uint64_t vrefw_vlg_iterate(void* h, uint32_t k, const uint64_t* sp, const uint64_t* ep, const uint64_t* gap_lo, const uint64_t* gap_hi,
+                           uint64_t last_subpattern_size, uint64_t* out_tuples, uint64_t cap)
+{
+    typedef wt_range_walker<wtsa_ref_type> walker;
+    const wtsa_ref_type& wt = *(wtsa_ref_type*)h;
+    std::vector<walker> lex_ranges;
+    auto root_node = wt_node_cache<wtsa_ref_type>(wt.root(), wt);
+    for (uint32_t i = 0; i < k; ++i) {
+        lex_ranges.emplace_back(wt, range_type({sp[i], ep[i]}), root_node);
+        if (sp[i] > ep[i]) return 0;                                 // :315-316 shortcut on empty range
+    }
+    auto size = [&]() { return lex_ranges.size(); };
+    auto relax = [&]() -> bool {                                     // :227-249
+        bool redo = true;
+        while (redo) {
+            redo = false;
+            for (size_t i = 1; i < size(); ++i) {
+                if (lex_ranges[i - 1].current_node().range_end + gap_hi[i - 1] < lex_ranges[i].current_node().range_begin) {
+                    lex_ranges[i - 1].next_right();
+                    redo = true;
+                    if (!lex_ranges[i - 1].has_more()) return false;
+                }
+                if (lex_ranges[i - 1].current_node().range_begin + gap_lo[i - 1] > lex_ranges[i].current_node().range_end) {
+                    lex_ranges[i].next_right();
+                    redo = true;
+                    if (!lex_ranges[i].has_more()) return false;
+                }
+            }
+        }
+        return true;
+    };
+    auto pull_forward = [&]() -> bool {                              // :254-266
+        auto last_pos = lex_ranges[lex_ranges.size() - 1].current_node().range_begin;
+        while (lex_ranges[0].has_more() && lex_ranges[0].current_node().range_end <= last_pos) lex_ranges[0].next_right();
+        while (lex_ranges[0].next_leaf() && lex_ranges[0].current_node().range_begin < last_pos + last_subpattern_size) ;
+        return lex_ranges[0].has_more();
+    };
+    bool finished = false;
+    auto next = [&]() {                                              // :269-291
+        while (relax()) {
+            size_t r = 1, j = 0;
+            bool found = false;
+            for (size_t i = 0; i < size(); ++i) {
+                auto lr = lex_ranges[i].current_node().node.size;
+                if (lr > r) { r = lr; j = i; found = true; }
+            }
+            if (found) lex_ranges[j].next_down();
+            else return;
+        }
+        finished = true;
+    };
+    next();
+    uint64_t m = 0;
+    while (!finished) {
+        if (m < cap && out_tuples) for (uint32_t i = 0; i < k; ++i) out_tuples[m * k + i] = lex_ranges[i].current_node().range_begin;   // operator[] :337-340
+        ++m;
+        if (pull_forward()) next(); else finished = true;            // operator++ :345-352
+    }
+    return m;
+}
+
 // ---- wt_int<> (bit_vector + rank_support_v), the BWT container of csa_wt<wt_int<>> for integer alphabets ----------------------------
 typedef wt_int<> wt_int_plain;
 void* vrefi_create(const uint64_t* vals, uint64_t n)
