@@ -384,7 +384,9 @@ void vlg_result_destroy(vlg_result* r);
  * On the device the tree is level-contiguous: level l is one rank-enabled bit-vector of 256-bit super-blocks (as K1), nodes are
  * intervals of it (wt_int, include/sdsl/wt_int.hpp:215-255).  Results equal sdsl::locate(vlg_index, query) -- the same tuples as
  * vlg_search_batch on the FM-index -- cut after max_matches_per_query matches of each query when that is not 0 (what a caller
- * that stops iterating early sees, include/sdsl/vlg_index.hpp:357-363).
+ * that stops iterating early sees, include/sdsl/vlg_index.hpp:357-363).  One corner is defined away: for a query of one
+ * sub-pattern of one symbol the reference's iterator drops an occurrence at 2j + 1 that directly follows a match at 2j
+ * (vlg_index.hpp:254-266 with wt_helper.hpp:776-779); like the benchmark's merge join this library reports both.
  * ---------------------------------------------------------------------------------------- */
 typedef struct vlg_wtsa vlg_wtsa;
 typedef struct {

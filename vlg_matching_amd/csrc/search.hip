@@ -75,6 +75,8 @@ struct vlg_workspace {
     // hipMalloc / hipFree pair per batch cost more than the kernels between them
     uint8_t* head = nullptr;
     uint64_t head_bytes = 0;
+    uint64_t tmp_key[6] = {0, 0, 0, 0, 0, 0};   // what the cached temporary-storage size of the sorts was asked for
+    size_t tmp_bytes = 0;
     int x_ranks = 1, x_rank = 0;
     vlg_exchange_fn x_fn = nullptr;     // in-place all-gather of device pieces; null with x_comm set = vlg_comm_allgatherv
     void* x_ctx = nullptr;
@@ -1196,6 +1198,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
     while (Q0 < q->nq) {
         // ---- choose the super-chunk ----------------------------------------------------------------
         std::vector<uint32_t> dlist;
+        dlist.reserve(pl.dl.size());
         uint64_t phys = 0, Q1 = Q0;
         while (Q1 < q->nq) {
             uint64_t add = 0;
@@ -1224,7 +1227,11 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         }
         // ---- arena: physical lists first, filter state and join scratch behind them ---------------------
         size_t sort_tmp = 0;
-        if (phys) {
+        // (the library's size queries are not free -- a few hundred microseconds each -- and batches repeat: the last answer is kept)
+        const uint64_t tmp_key[6] = {phys, dlist.size(), idx->hdr.n, ((uint64_t)idx->hdr.sigma << 8) | ((uint64_t)ws->sweep << 1) | (uint64_t)idx->is_int | (sizeof(pos_t) << 4),
+                                     ws->global_sort_min, ws->sweep_min};
+        if (phys && !memcmp(tmp_key, ws->tmp_key, sizeof tmp_key)) sort_tmp = ws->tmp_bytes;
+        else if (phys) {
             // the sort build_physical will choose (same condition there): one radix sort of (list, position) keys, or a segmented one
             const unsigned pos_bits = std::max(1u, bit_width64(idx->hdr.n >= 2 ? idx->hdr.n - 2 : 0));
             if (phys >= ws->global_sort_min && pos_bits + bit_width64(dlist.size()) <= 64) {
@@ -1237,6 +1244,8 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             }
             if (ws->sweep && phys >= ws->sweep_min && !idx->is_int)
                 sort_tmp = std::max(sort_tmp, sweep_temp_bytes(phys, idx->hdr.sigma, ws->stream));
+            memcpy(ws->tmp_key, tmp_key, sizeof tmp_key);
+            ws->tmp_bytes = sort_tmp;
         }
         const bool will_sweep = ws->sweep && phys >= ws->sweep_min && !idx->is_int;
         uint64_t logical_max_query = 0;
