@@ -20,3 +20,9 @@ print("span %.1f ms, idle %.1f ms in %d gaps" % (span, idle, len(gaps)))
 for g in sorted(gaps, reverse=True)[:60]:
     if g[0] >= min_gap:
         print("%10.1f us  after %-60s before %s" % (g[0], g[1], g[2]))
+
+# per-launch durations of the kernels whose name contains argv[3] (e.g. sweep_step_kernel), in launch order
+if len(sys.argv) > 3:
+    for pat in sys.argv[3:]:
+        d = [(s, (e - s) / 1e3) for s, e, n in ev if pat in n]
+        print("%s: %d launches, us each: %s" % (pat, len(d), " ".join("%.0f" % x[1] for x in d)))
