@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(256) sa_expand_kernel(IndexView iv, uint32_t* 
                     uint64_t r1;
                     BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
                     pos = bit ? r1 : pos - r1;
-                    const uint32_t ch = nd.child[bit];
+                    const uint32_t ch = bit ? nd.child[1] : nd.child[0];      // (a select, not an indexed read: the node stays in registers)
                     if (ch & kLeafFlag) { c = ch & ~kLeafFlag; break; }
                     node = ch;
                 }

@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(256) int_locate_kernel(IntView v, uint32_t* __
                 uint32_t blk, o;
                 split224(i, blk, o);
                 const BlockRegs r = load_block(v.levels, (uint32_t)(lvl * v.nb) + blk);
-                const uint32_t bit = block_bit(r, o);
-                const uint64_t r1 = block_rank(r, o);
+                uint32_t bit;
+                const uint64_t r1 = block_rank_bit(r, o, bit);
                 ++n_lv;
                 i = bit ? sZ[lvl] + r1 : i - r1;
                 c = (c << 1) | bit;

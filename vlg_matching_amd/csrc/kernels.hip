@@ -348,7 +348,7 @@ __device__ __forceinline__ uint64_t wt_rank_dev(const IndexView& iv, const WalkL
         uint64_t r1 = BV::rank(iv, s.sh, s.nodes[v].base, res);
         ++levels;
         res = bit ? r1 : res - r1;
-        v = s.nodes[v].child[bit] & ~kLeafFlag;
+        { const DNode nd = s.nodes[v]; v = (bit ? nd.child[1] : nd.child[0]) & ~kLeafFlag; }
     }
     return res;
 }
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
                 BV::rank_bit(iv, s.sh, nd.base, i, r1, bit);
                 ++n_lv;
                 uint64_t ni = bit ? r1 : i - r1;
-                uint32_t ch = nd.child[bit];
+                uint32_t ch = bit ? nd.child[1] : nd.child[0];      // (a select, not an indexed read: the node stays in registers)
                 if (ch & kLeafFlag) {                      // reached the symbol: LF = C[c] + rank
                     i = s.C[ch & ~kLeafFlag] + ni;
                     v = 0;
@@ -655,15 +655,16 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
         } else {
             if (kTrail) trail[i] = gen | ((slot0 + (v64 >> kShift) + 1) << 16) | step;
             uint32_t v = 0, c;
-            uint64_t pos = i;
+            using walk_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;      // node-relative positions: < n
+            walk_t pos = (walk_t)i;
             for (;;) {                                       // inverse_select: wt_pc.hpp:385-402
                 const DNode nd = s.nodes[v];
                 uint32_t bit;
-                uint64_t r1;
+                walk_t r1;
                 BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
                 ++n_lv;
                 pos = bit ? r1 : pos - r1;
-                uint32_t ch = nd.child[bit];
+                uint32_t ch = bit ? nd.child[1] : nd.child[0];      // (a select, not an indexed read: the node stays in registers)
                 if (ch & kLeafFlag) { c = ch & ~kLeafFlag; break; }
                 v = ch;
             }
@@ -687,6 +688,12 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
 // the next round.  Records are single 64-bit words, so a reader sees a valid state of the element it follows whatever that
 // one's own thread is doing; chains collapse as the elements ahead finish (measured on C3: 2 + 2 hops per round over four
 // rounds 24.5 ms, to the end in one round + one checking round 18.6 ms).
+// Round 3 measured three ways around that wall, none of which paid (C3, per batch): (1) not looking at the owner's record when an
+// element stops in the first rounds, where the owner is all but certainly still walking: the sweep gains 1 ms, this kernel loses 2.5
+// -- the looks are nearly free inside the sweep, which is not request-bound; (2) taking the hops in the order the sweep left the
+// stopped elements in (the per-round tails of its buffers, last round first, then first to last): 35.5 instead of 17.7 ms --
+// neighbours in SA order are not neighbours in slot order; (3) following the chains on a second stream beside the sweep's late rounds:
+// this kernel 18.0 -> 13.3 ms, but the rounds and their partitions slow down by 7 ms: the requests are conserved, not hidden.
 constexpr uint32_t kResolveHops = 64;
 template <typename pos_t, bool kWide>
 __global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict__ rec, uint64_t count, pos_t* __restrict__ out,
@@ -736,7 +743,7 @@ __global__ void __launch_bounds__(256) isa_samples_kernel(IndexView iv, uint32_t
                 uint64_t r1;
                 BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
                 pos = bit ? r1 : pos - r1;
-                const uint32_t ch = nd.child[bit];
+                const uint32_t ch = bit ? nd.child[1] : nd.child[0];      // (a select, not an indexed read: the node stays in registers)
                 if (ch & kLeafFlag) { c = ch & ~kLeafFlag; break; }
                 node = ch;
             }

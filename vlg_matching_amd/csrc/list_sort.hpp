@@ -6,7 +6,7 @@
 // (list, position) keys with one device-wide radix sort moves 16 bytes per element and pass and spends its upper passes on list
 // bits that are in order already (C3: 30 + 18 bits = 6 passes of 8 bits).  Here only the position bits are sorted, as 32-bit keys,
 // INSIDE every list:
-//   lists of up to kSortBig elements   one workgroup sorts the list in LDS (rocPRIM block_radix_sort), one read + one write;
+//   lists of up to kSortTile elements  one workgroup sorts the list in LDS (rocPRIM block_radix_sort), one read + one write;
 //   longer lists                       LSD radix passes of <= 8 bits over tiles of kSortTile elements that never straddle two
 //                                      lists: per tile a digit histogram, per list an exclusive scan of the histograms (by chunks
 //                                      of kSortChunk tiles, so that a list of 2000 tiles is not one serial loop), then every tile
@@ -16,8 +16,8 @@
 #pragma once
 namespace {
 
-constexpr uint32_t kSortTile = 4096;          // elements per tile: 256 threads x 16
-constexpr uint32_t kSortBig = 16384;          // the longest list one workgroup (1024 threads x 16, 64 KiB of LDS) sorts in one pass
+constexpr uint32_t kSortTile = 4096;          // elements per tile: 256 threads x 16 (measured in round 3: a further class of lists up to 16384
+                                              // elements sorted by one workgroup of 1024 threads in 64 KiB of LDS made the sort slower, 12.3 vs 11.4 ms)
 constexpr uint32_t kSortChunk = 32;           // tiles per chunk of the histogram scan
 
 // ---- short lists: whole list in one workgroup ------------------------------------------------------------------------------------
@@ -189,8 +189,8 @@ inline uint64_t list_sort_scratch_bytes(uint64_t n_long, uint64_t n_tiles, uint6
 // the caller takes the device-wide sort), list_sort_enqueue launches the kernels.
 struct ListSortPlan {
     bool ready = false;
-    uint32_t n_small[4] = {0, 0, 0, 0};
-    uint32_t* d_small[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t n_small[3] = {0, 0, 0};
+    uint32_t* d_small[3] = {nullptr, nullptr, nullptr};
     uint32_t n_long = 0, n_tiles = 0, n_chunks = 0;
     SortList* d_longs = nullptr;
     uint32_t *d_tile_list = nullptr, *d_chunk_list = nullptr, *d_tot = nullptr, *d_pref = nullptr;
@@ -199,7 +199,7 @@ struct ListSortPlan {
 
 inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Arena& A, hipStream_t st, ListSortPlan& lp)
 {
-    svec<uint32_t> small[4];                                       // <= 256, <= 1024, <= kSortTile, <= kSortBig elements
+    svec<uint32_t> small[3];                                       // <= 256, <= 1024, <= kSortTile elements
     svec<SortList> longs;
     svec<uint32_t> tile_list, chunk_list;
     for (uint32_t l = 0; l < nd; ++l) {
@@ -208,7 +208,6 @@ inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Ar
         if (len <= 256) small[0].push_back(l);
         else if (len <= 1024) small[1].push_back(l);
         else if (len <= kSortTile) small[2].push_back(l);
-        else if (len <= kSortBig) small[3].push_back(l);
         else {
             if (len > 0xFFFFFFFFull) return fail(VLG_E_INTERNAL, "list sort: list too long");
             const uint32_t tiles = (uint32_t)((len + kSortTile - 1) / kSortTile), chunks = (tiles + kSortChunk - 1) / kSortChunk;
@@ -220,11 +219,11 @@ inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Ar
     }
     {   // room for everything, or nothing is carved
         uint64_t need = 4096;
-        for (int c = 0; c < 4; ++c) need += align_up(small[c].size() * 4, 256);
+        for (int c = 0; c < 3; ++c) need += align_up(small[c].size() * 4, 256);
         if (!longs.empty()) need += list_sort_scratch_bytes(longs.size(), tile_list.size(), chunk_list.size());
         if (A.failed || A.size - A.used < need) return fail(VLG_E_WORKSPACE, "list sort: no room for its tables");
     }
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 3; ++c) {
         lp.n_small[c] = (uint32_t)small[c].size();
         if (small[c].empty()) continue;
         lp.d_small[c] = A.take<uint32_t>(small[c].size());
@@ -254,7 +253,6 @@ inline vlg_status list_sort_enqueue(const ListSortPlan& lp, uint32_t* P, uint32_
     if (lp.n_small[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<64, 4>), dim3(lp.n_small[0]), dim3(64), 0, st, P, d_off64, lp.d_small[0], lp.n_small[0], bits);
     if (lp.n_small[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<256, 4>), dim3(lp.n_small[1]), dim3(256), 0, st, P, d_off64, lp.d_small[1], lp.n_small[1], bits);
     if (lp.n_small[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<256, 16>), dim3(lp.n_small[2]), dim3(256), 0, st, P, d_off64, lp.d_small[2], lp.n_small[2], bits);
-    if (lp.n_small[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<1024, 16>), dim3(lp.n_small[3]), dim3(1024), 0, st, P, d_off64, lp.d_small[3], lp.n_small[3], bits);
     VLG_HIP_TRY(hipGetLastError());
     if (!lp.n_long) return VLG_OK;
     const unsigned passes = bits <= 16 ? 2 : 4;                    // even: the lists come back to P
