@@ -373,6 +373,11 @@ vlg_status vlg_result_summary_get(const vlg_result* r, vlg_result_summary* s);
  * query-major, k(q) values per match.  Any pointer may be NULL. */
 vlg_status vlg_result_fetch(const vlg_result* r, uint64_t* h_counts, uint64_t* h_offsets,
                             uint64_t* h_first_positions, uint64_t* h_tuples);
+/* The same positions as 32-bit values, for callers that keep them that way: results of a text whose positions fit 32 bits
+ * (vlg_index_info.n <= 2^32 + 1) are held 4 bytes wide in HBM and cross PCIe that way -- vlg_result_fetch widens them on the
+ * host (threads, pinned staging blocks), this entry point copies them as they are.  VLG_E_INVALID when the result's positions
+ * are 64 bits wide (larger texts, VLG_FORCE_POS64=1, vlg_wtsa_* results).  Either pointer may be NULL. */
+vlg_status vlg_result_fetch32(const vlg_result* r, uint32_t* h_first_positions, uint32_t* h_tuples);
 void vlg_result_destroy(vlg_result* r);
 
 /* ------------------------------------------------------------------------------------------

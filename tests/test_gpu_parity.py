@@ -541,6 +541,7 @@ def test_window_filter_equals_unfiltered_join_and_oracle(V, oracle, name, seed, 
     ws_f.set_option("filter_min", 0)
     ws_f.set_option("filter_stream_min", 0)
     ws_f.set_option("filter_pivot", pivot)
+    ws_f.set_option("pivot_rungs", 2 if seed % 2 else 0)                 # index ranges through the ladder / by bisection
     ws_f.set_option("global_sort_min", 1 if pivot else 1 << 40)      # all lists sorted at once / one sort per list ...
     ws_f.set_option("list_sort", seed % 2)                           # ... when the sort inside every list is off
     if seed in (62, 65):
@@ -597,6 +598,7 @@ def test_window_filter_extreme_gaps(V, oracle, pivot):
     ws_f.set_option("filter_min", 0)
     ws_f.set_option("filter_stream_min", 0)
     ws_f.set_option("filter_pivot", pivot)
+    ws_f.set_option("pivot_rungs", 2)
     ra, rb = idx.search(qs, workspace=ws_n), idx.search(qs, workspace=ws_f)
     assert ws_f.kernel_stats()["filter_compact"]["launches"] > 0
     for i, q in enumerate(qs):
@@ -847,7 +849,7 @@ def test_64bit_position_kernels(torch_cuda, V, oracle, monkeypatch, force):
     want = [o.search(q).tolist() for q in qs]
     for pivot in (1, 0):
         ws = Workspace()
-        for k_, v_ in (("sweep_min", 1), ("sweep_tail", 16), ("global_sort_min", 1), ("filter_min", 0), ("filter_stream_min", 0), ("filter_pivot", pivot)):
+        for k_, v_ in (("sweep_min", 1), ("sweep_tail", 16), ("global_sort_min", 1), ("filter_min", 0), ("filter_stream_min", 0), ("filter_pivot", pivot), ("pivot_rungs", 2)):
             ws.set_option(k_, v_)
         res = idx.search(qs, workspace=ws)
         assert ws.kernel_stats()["filter_compact"]["launches"] > 0 and ws.kernel_stats()["locate_resolve"]["launches"] > 0
@@ -1406,3 +1408,83 @@ def test_collective_search_shards_lists_and_queries(V, oracle, world, opts):
     o = oracle.Index.from_text(text)
     for i in (0, 99, 250, 399):
         assert one.tuples(i).tolist() == o.search(queries[i]).tolist()
+
+
+def test_narrow_results_widen_on_fetch(torch_cuda, V, oracle, monkeypatch):
+    """Positions that fit 32 bits are held 4 bytes wide in HBM: vlg_result_fetch hands out the 64-bit values of
+    gapped_search_result::positions (utils.hpp:73-80) -- widened by host threads from pinned staging blocks, many blocks per thread
+    on a result of a few million matches -- and vlg_result_fetch32 the same values as they are stored; results with 64-bit
+    positions (VLG_FORCE_POS64=1, the wtsa index) refuse the narrow fetch."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    text = rng.choice(np.frombuffer(b"ab", np.uint8), 30_000_000, p=[0.7, 0.3]).tobytes()
+    idx = V.VlgIndex.build(text)
+    qs = ["ab.{0,3}?a", "a", "ba.{1,2}?b.{0,2}?a", "bbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbb", "b.{0,0}?b"]
+    res = idx.search(qs)
+    counts, off, first, tup = res.fetch()
+    assert res.summary["n_matches"] > 8 * (8 << 20) // 4                  # more than one staging block for each of the fetch threads
+    t = np.frombuffer(text, np.uint8)
+    a_at = np.flatnonzero(t == ord("a")).astype(np.uint64)
+    assert (res.positions(1) == a_at).all()                                # every 'a' of the text, in order
+    bb = np.flatnonzero((t[:-1] == ord("b")) & (t[1:] == ord("b")))
+    keep, last = [], -2
+    for p in bb.tolist():                                                  # non-overlapping, left to right
+        if p > last + 1:
+            keep.append(p); last = p
+    assert res.positions(4).tolist() == keep
+    assert int(first.sum(dtype=np.uint64)) == res.summary["checksum"] and counts[3] == 0
+    f32, t32 = res.fetch32()
+    assert f32.dtype == np.uint32 and (f32 == first).all() and (t32 == tup).all()
+    small = idx.search(qs[:1] + qs[2:4])                                   # and a result far smaller than a staging block
+    o = oracle.Index.from_text(text[:200_000])
+    sidx = V.VlgIndex.build(text[:200_000])
+    r2 = sidx.search(qs)
+    for i, q in enumerate(qs):
+        assert r2.tuples(i).tolist() == o.search(q).tolist(), q
+    assert (r2.fetch32()[0] == r2.fetch()[2]).all() and small.summary["n_matches"] == int(counts[0] + counts[2])
+    monkeypatch.setenv("VLG_FORCE_POS64", "1")
+    wide = V.VlgIndex.build(text[:200_000]).search(qs)
+    for x, y in zip(wide.fetch(), r2.fetch()):
+        assert (x == y).all()
+    with pytest.raises(V.VlgError):
+        wide.fetch32()
+
+
+@pytest.mark.parametrize("force", ["0", "1"])
+def test_pivot_filter_through_the_ladder(torch_cuda, V, monkeypatch, force):
+    """The pivot filter finds its index ranges by descending the 4-ary ladder over the sorted lists (one 16-byte load per level)
+    or, with workspace option pivot_rungs = 0, by bracket searches and bisection: lists of a few elements up to millions, at every
+    alignment inside the shared array, 32- and 64-bit positions -- same survivors' joins, same matches as the unfiltered join."""
+    from vlg_matching_amd.index import Workspace
+    monkeypatch.setenv("VLG_FORCE_POS64", force)
+    rng = np.random.default_rng(31)
+    n = 3_000_000
+    text = bytearray(rng.choice(np.frombuffer(b"abc", np.uint8), n, p=[0.86, 0.12, 0.02]).tobytes())
+    for p in rng.integers(0, n - 8, 40):
+        text[p:p + 3] = b"xyz"                                             # a rare sub-pattern: pivot lists of a few elements
+    text = bytes(text)
+    idx = V.VlgIndex.build(text)
+    qs = []
+    subs = ["a", "b", "c", "ab", "ba", "aa", "cb", "bc", "xyz", "abc", "aab", "cc", "bbb", "ca", "aaaa", "acb"]
+    for _ in range(300):
+        k = int(rng.integers(2, 5))
+        parts = [subs[int(rng.integers(0, len(subs)))] for _ in range(k)]
+        q = parts[0]
+        for s in parts[1:]:
+            lo = int(rng.integers(0, 30))
+            q += ".{%d,%d}?%s" % (lo, lo + int(rng.choice([0, 4, 60, 900, 20000])), s)
+        qs.append(q)
+    res = {}
+    for name, opts in (("plain", {"filter": 0}), ("bisect", {"pivot_rungs": 0}), ("ladder", {"pivot_rungs": 2})):
+        ws = Workspace()
+        for k_, v_ in {"filter_min": 0, "filter_stream_min": 0, "filter_pivot": 1, "filter_pivot_ratio": 2, **opts}.items():
+            ws.set_option(k_, v_)
+        res[name] = idx.search(qs, workspace=ws)
+        if name != "plain":
+            assert ws.kernel_stats()["filter_pivot"]["launches"] > 0 and ws.kernel_stats()["filter_compact"]["launches"] > 0
+    assert res["ladder"].summary["join_slots"] == res["bisect"].summary["join_slots"] < res["plain"].summary["join_slots"]
+    for name in ("bisect", "ladder"):
+        for k_ in ("n_matches", "checksum", "n_tuple_values", "logical_occurrences"):
+            assert res[name].summary[k_] == res["plain"].summary[k_], (name, k_)
+        for x, y in zip(res[name].fetch(), res["plain"].fetch()):
+            assert (x == y).all(), name

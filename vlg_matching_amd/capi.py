@@ -126,6 +126,7 @@ SYMBOLS = [
     ("vlg_join_batch", _I, [_P, _P, _U64, _P, _P, _P, _P, _U64, _P, C.POINTER(_P)]),
     ("vlg_result_summary_get", _I, [_P, C.POINTER(ResultSummary)]),
     ("vlg_result_fetch", _I, [_P, _P, _P, _P, _P]),
+    ("vlg_result_fetch32", _I, [_P, _P, _P]),
     ("vlg_result_destroy", None, [_P]),
     ("vlg_wtsa_build", _I, [_P, _U64, C.c_uint32, C.POINTER(_P)]),
     ("vlg_wtsa_get_info", _I, [_P, C.POINTER(WtsaInfo)]),

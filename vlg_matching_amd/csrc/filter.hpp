@@ -400,6 +400,89 @@ __device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, const 
     }
 }
 
+// The same ranges through the ladder of join_device.hpp (rungs): every lane descends for its a and for its b + 1 from the level
+// whose group of kRungFan entries covers the whole list, all 2 x kPivotGroups descents in lockstep (one aligned load of a group each
+// per level).  The upper levels are the same address in every lane; no bracket searches, no bisection.
+template <typename pos_t>
+__device__ __forceinline__ void pivot_ranges_rungs(const pos_t* __restrict__ P, const pos_t* __restrict__ R, const uint64_t* __restrict__ roff,
+                                                   uint32_t pbegin, uint32_t pend, const uint64_t (&a)[kPivotGroups], const uint64_t (&b)[kPivotGroups],
+                                                   bool (&on)[kPivotGroups], uint32_t (&i0)[kPivotGroups], uint32_t (&i1)[kPivotGroups])
+{
+    constexpr uint32_t G = kPivotGroups, F = kRungFan, S = kRungShift;
+    constexpr pos_t kMax = (pos_t)~(pos_t)0;
+    using Quad = RungQuad<pos_t>;
+    // keys as positions: nothing in a list reaches kMax, so a >= kMax finds the end and b >= kMax - 1 takes everything
+    pos_t ka[G], kb[G];
+#pragma unroll
+    for (uint32_t g = 0; g < G; ++g) {
+        ka[g] = a[g] >= (uint64_t)kMax ? kMax : (pos_t)a[g];
+        kb[g] = b[g] >= (uint64_t)kMax - 1 ? (pos_t)(kMax - 1) : (pos_t)b[g];
+    }
+    const uint32_t diff = pbegin ^ (pend - 1);                                  // (the list is not empty)
+    const uint32_t jt = diff ? (31u - (uint32_t)__builtin_clz(diff)) / S : 0;   // its indices agree above bit S (jt + 1) - 1
+    uint32_t ga[G], gb[G];
+#pragma unroll
+    for (uint32_t g = 0; g < G; ++g) ga[g] = gb[g] = S * (jt + 1) < 32 ? pbegin >> (S * (jt + 1)) : 0;
+    for (int j = (int)jt; j >= 0; --j) {
+        const pos_t* __restrict__ L = j ? R + roff[j] : P;
+        const uint32_t A = pbegin >> (S * j), B = pend >> (S * j);              // entries [A, B) of this level are elements of the list
+        Quad ea[G][F / 4], eb[G][F / 4];
+        bool edge = false;
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            if (on[g]) {
+#pragma unroll
+                for (uint32_t c = 0; c < F / 4; ++c) {
+                    ea[g][c] = *reinterpret_cast<const Quad*>(L + F * (uint64_t)ga[g] + 4 * c);
+                    eb[g][c] = *reinterpret_cast<const Quad*>(L + F * (uint64_t)gb[g] + 4 * c);
+                }
+                edge |= F * ga[g] < A || F * ga[g] + F > B || F * gb[g] < A || F * gb[g] + F > B;
+            }
+        }
+        if (__any(edge)) {                                                       // a group reaches over a border of the list
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g) {
+                if (on[g]) {
+#pragma unroll
+                    for (uint32_t t = 0; t < F; ++t) {
+                        const uint32_t ia = F * ga[g] + t, ib = F * gb[g] + t;
+                        pos_t& xa = ea[g][t / 4].v[t % 4];
+                        pos_t& xb = eb[g][t / 4].v[t % 4];
+                        xa = ia < A ? (pos_t)0 : (ia >= B ? kMax : xa);
+                        xb = ib < A ? (pos_t)0 : (ib >= B ? kMax : xb);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            if (on[g]) {
+                uint32_t ca = 0, cb = 0;
+#pragma unroll
+                for (uint32_t t = 0; t + 1 < F; ++t) {
+                    ca += (uint32_t)(ea[g][t / 4].v[t % 4] < ka[g]);
+                    cb += (uint32_t)(eb[g][t / 4].v[t % 4] <= kb[g]);
+                }
+                if (j == 0) {                                                    // (above: the last block is where larger keys go)
+                    ca += (uint32_t)(ea[g][F / 4 - 1].v[3] < ka[g]);
+                    cb += (uint32_t)(eb[g][F / 4 - 1].v[3] <= kb[g]);
+                }
+                ga[g] = F * ga[g] + ca;
+                gb[g] = F * gb[g] + cb;
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t g = 0; g < G; ++g) {
+        uint32_t l0 = ga[g] < pbegin ? pbegin : (ga[g] > pend ? pend : ga[g]);
+        uint32_t l1 = gb[g] < pbegin ? pbegin : (gb[g] > pend ? pend : gb[g]);
+        if (!on[g]) l0 = l1 = pbegin;
+        i0[g] = l0 - pbegin;
+        i1[g] = l1 - pbegin;
+        on[g] = on[g] && l0 < l1;
+    }
+}
+
 // Pivot mode: when one list of the query is much shorter than the others, the survivors are found from its elements
 // outwards instead of streaming the long lists.  A lane takes one element of the pivot list (kPivotGroups of them, one per
 // 64-element group of the wave's run) and follows it level by level: the elements of the neighbouring list inside its gap
@@ -408,8 +491,9 @@ __device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, const 
 struct PTask { uint32_t seg0, k, p, pad; };          // first segment of the query, sub-patterns, pivot level
 constexpr uint32_t kPivotRun = 64 * kPivotGroups;     // pivot elements per wave
 
-template <typename pos_t>
+template <typename pos_t, bool kRungs>
 __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restrict__ P, const pos_t* __restrict__ F /* fences of P, or null */,
+                                                           const pos_t* __restrict__ R, const uint64_t* __restrict__ roff /* kRungs: the ladder over P */,
                                                            const RSeg* __restrict__ segs,
                                                            const PTask* __restrict__ tasks, const uint64_t* __restrict__ task_run0,
                                                            uint32_t ntasks, uint64_t* __restrict__ abits)
@@ -440,7 +524,8 @@ __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restri
     auto follow = [&](const RSeg& sg, const uint64_t (&a)[G], const uint64_t (&b)[G], bool (&on)[G], uint64_t (&lo_pos)[G], uint64_t (&hi_pos)[G],
                       bool more_levels) {
         uint32_t i0[G], i1[G];
-        pivot_ranges(P, F, sg.pbegin, sg.pend, a, b, on, i0, i1);
+        if (kRungs) pivot_ranges_rungs(P, R, roff, sg.pbegin, sg.pend, a, b, on, i0, i1);
+        else pivot_ranges(P, F, sg.pbegin, sg.pend, a, b, on, i0, i1);
         MarkRun mr;
         mr.bm = abits + (sg.abit >> 6);
 #pragma unroll
@@ -769,8 +854,14 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
         uint64_t probes = 0;                                      // (pivot element, level) pairs: two lower bounds of 8 bytes each
         for (const PTask& pt : ptasks) probes += (uint64_t)(segs[pt.seg0 + pt.p].pend - segs[pt.seg0 + pt.p].pbegin) * (pt.k >= 2 ? pt.k - 2 + (pt.p + 1 == pt.k ? 1 : 0) : 0);
         Timed t(ws, KS_FILTER_PIVOT, 16 * probes);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t>), dim3((uint32_t)((prun0.back() + 3) / 4)), dim3(256), 0, st, P, static_cast<const pos_t*>(ws->fences), fg.d_segs,
-                           d_ptasks, d_prun0, (uint32_t)ptasks.size(), fg.d_abits);
+        if (ws->rungs && ws->pivot_rungs)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t, true>), dim3((uint32_t)((prun0.back() + 3) / 4)), dim3(256), 0, st, P,
+                               static_cast<const pos_t*>(ws->fences), static_cast<const pos_t*>(ws->rungs), ws->rung_off, fg.d_segs, d_ptasks, d_prun0,
+                               (uint32_t)ptasks.size(), fg.d_abits);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t, false>), dim3((uint32_t)((prun0.back() + 3) / 4)), dim3(256), 0, st, P,
+                               static_cast<const pos_t*>(ws->fences), (const pos_t*)nullptr, (const uint64_t*)nullptr, fg.d_segs, d_ptasks, d_prun0,
+                               (uint32_t)ptasks.size(), fg.d_abits);
         VLG_HIP_TRY(hipGetLastError());
     }
     auto clear_buf = [&](uint32_t buf) -> vlg_status {

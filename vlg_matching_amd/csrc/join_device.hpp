@@ -75,6 +75,46 @@ __global__ void fence_build_kernel(const pos_t* __restrict__ P, uint64_t g0, uin
     for (uint64_t g = g0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += (uint64_t)gridDim.x * blockDim.x) F[g] = P[64 * g + 63];
 }
 
+// ---- rungs: a search ladder over the sorted lists -----------------------------------------------------------------------------
+// R_j[i] = P[f^j (i + 1) - 1], j = 1 .. levels, f = kRungFan: the last element of every whole block of f^j elements.  A lower bound
+// descends from the level whose one group of f entries covers the list: ONE aligned load of f entries per level picks one of f
+// blocks, so a search touches log_f(length) lines instead of the log2(length) of a bisection -- the pivot filter, whose loads go to
+// a different line in almost every lane, is bound by exactly those line requests (L1 misses on their way to L2), not by bytes.
+// Entry i of level j lies inside the list P[a,b) iff a >> (s j) <= i < b >> (s j), s = log2 f, whatever the list's borders, so the
+// lists share one ladder; entries before the list count as smaller than any key, entries behind it as larger.
+#ifndef VLG_RUNG_SHIFT
+#define VLG_RUNG_SHIFT 2
+#endif
+constexpr uint32_t kRungShift = VLG_RUNG_SHIFT, kRungFan = 1u << kRungShift;
+constexpr uint32_t kMaxRungs = 32 / kRungShift;         // f^kMaxRungs elements: more than any index here (32-bit)
+struct RungLayout { uint64_t off[kMaxRungs + 1]; uint32_t levels; uint64_t entries; };
+inline RungLayout rung_layout(uint64_t total)
+{
+    RungLayout L{};
+    L.levels = 0;
+    while (L.levels < kMaxRungs && (total >> (kRungShift * (L.levels + 1))) != 0) ++L.levels;   // the block of level `levels + 1` covers every index
+    uint64_t at = 0;
+    for (uint32_t j = 1; j <= L.levels; ++j) {                                                  // whole groups, and one to spare
+        L.off[j] = at;
+        at += (((total >> (kRungShift * j)) + kRungFan - 1) & ~(uint64_t)(kRungFan - 1)) + kRungFan;
+    }
+    L.entries = at;
+    return L;
+}
+
+template <typename pos_t>
+__global__ void rung_build_kernel(const pos_t* __restrict__ P, uint64_t total, pos_t* __restrict__ R, const uint64_t* __restrict__ off, uint32_t levels)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total >> kRungShift); i += (uint64_t)gridDim.x * blockDim.x) {
+        const pos_t v = P[kRungFan * i + kRungFan - 1];
+        R[off[1] + i] = v;
+        uint64_t k = i;
+        for (uint32_t j = 2; j <= levels && (k & (kRungFan - 1)) == kRungFan - 1; ++j) { k >>= kRungShift; R[off[j] + k] = v; }
+    }
+}
+
+template <typename pos_t> struct alignas(4 * sizeof(pos_t)) RungQuad { pos_t v[4]; };
+
 // Keys the windows did not reach (the list is much denser than the keys): two-level search.  Lane t reads the LAST element of
 // block t behind the fence `wb` -- one round trip covers 64 blocks -- every lane ranks its key among these 64 fences through
 // cross-lane reads and then bisects the one block that holds its answer (6 probes inside 256 bytes).  A galloping search
@@ -95,12 +135,11 @@ __device__ __forceinline__ void wave_far_lower_bound(const pos_t* __restrict__ P
         else { const uint64_t fi = (uint64_t)wb + 64 * lane + 63; f = fi < b ? P[fi] : kInf; }
         const pos_t flast = __shfl(f, 63);
         const bool can = need && key <= flast;
-        uint32_t lo = 0, hi = 63;                                    // first block whose last element is >= key
+        uint32_t lo = 0;                                             // first block whose last element is >= key
 #pragma unroll
-        for (uint32_t st = 0; st < 6; ++st) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const pos_t v = __shfl(f, (int)mid);
-            if (v < key) lo = mid + 1; else hi = mid;
+        for (uint32_t step = 32; step; step >>= 1) {
+            const pos_t v = __shfl(f, (int)(lo + step - 1));
+            lo += v < key ? step : 0u;
         }
         if (can) {
             uint64_t w0 = F ? ((uint64_t)(g0 + lo) << 6) : (uint64_t)wb + 64 * lo;   // the answer is in [w0, w0+63] (or b, in a clipped block)
@@ -146,12 +185,11 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P
         const pos_t w = idx < b ? P[idx] : kInf;                     // +inf behind the list
         const pos_t wlast = __shfl(w, 63);
         const bool can = need && key <= wlast;
-        uint32_t lo = 0, hi = 63;                                    // for `can` lanes w[63] >= key, so the answer is in [0,63]
+        uint32_t lo = 0;                                             // for `can` lanes w[63] >= key, so the answer is in [0,63]
 #pragma unroll
-        for (uint32_t st = 0; st < 6; ++st) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const pos_t v = __shfl(w, (int)mid);
-            if (v < key) lo = mid + 1; else hi = mid;
+        for (uint32_t step = 32; step; step >>= 1) {                 // lo = elements of w[0,63) below the key
+            const pos_t v = __shfl(w, (int)(lo + step - 1));
+            lo += v < key ? step : 0u;
         }
         const pos_t at = __shfl(w, (int)lo);
         if (can) { res = wb + lo; val = at; need = false; }
@@ -177,13 +215,12 @@ __device__ __forceinline__ void wave_lower_bound2(const pos_t* __restrict__ P, c
         const pos_t w = idx < b ? P[idx] : kInf;
         const pos_t wlast = __shfl(w, 63);
         const bool can0 = need0 && key0 <= wlast, can1 = need1 && key1 <= wlast;
-        uint32_t lo0 = 0, hi0 = 63, lo1 = 0, hi1 = 63;
+        uint32_t lo0 = 0, lo1 = 0;
 #pragma unroll
-        for (uint32_t st = 0; st < 6; ++st) {
-            const uint32_t mid0 = (lo0 + hi0) >> 1, mid1 = (lo1 + hi1) >> 1;
-            const pos_t a0 = __shfl(w, (int)mid0), a1 = __shfl(w, (int)mid1);
-            if (a0 < key0) lo0 = mid0 + 1; else hi0 = mid0;
-            if (a1 < key1) lo1 = mid1 + 1; else hi1 = mid1;
+        for (uint32_t step = 32; step; step >>= 1) {                 // lo = elements of w[0,63) below the key (w[63] >= key for `can` lanes)
+            const pos_t a0 = __shfl(w, (int)(lo0 + step - 1)), a1 = __shfl(w, (int)(lo1 + step - 1));
+            lo0 += a0 < key0 ? step : 0u;
+            lo1 += a1 < key1 ? step : 0u;
         }
         const pos_t at0 = __shfl(w, (int)lo0), at1 = __shfl(w, (int)lo1);
         if (can0) { j0 = wb + lo0; v0 = at0; need0 = false; }
@@ -813,12 +850,13 @@ __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restr
 }
 
 // tuples of every match: walk the links from the level-0 element.  One thread per (query, match) slot of list 0.
+// Results are written as wide as the positions are (ResultPiece::width); vlg_result_fetch widens them on the way to the host.
 template <typename pos_t>
 __global__ void __launch_bounds__(256) join_gather_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
                                                           const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint64_t r0,
                                                           uint64_t r1, const uint32_t* __restrict__ link, const uint32_t* __restrict__ mlist,
-                                                          const unsigned long long* __restrict__ counts, uint64_t* __restrict__ out_first,
-                                                          uint64_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
+                                                          const unsigned long long* __restrict__ counts, pos_t* __restrict__ out_first,
+                                                          pos_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -837,11 +875,11 @@ __global__ void __launch_bounds__(256) join_gather_kernel(const pos_t* __restric
             if (m.level == 0 && t < counts[m.query]) {
                 const QueryMeta Q = qm[m.query];
                 uint32_t el = mlist[e];                                // logical element of level 0
-                uint64_t first = P[phys_of(m, el)];
+                const pos_t first = P[phys_of(m, el)];
                 out_first[Q.out_first + t] = first;
                 local += first;
                 if (out_tuples) {                                      // null: first positions only (workspace option "tuples" = 0)
-                    uint64_t* tp = out_tuples + Q.out_tuple + t * Q.k;
+                    pos_t* tp = out_tuples + Q.out_tuple + t * Q.k;
                     tp[0] = first;
                     uint32_t cur = Q.k > 1 ? link[el] : 0;
                     uint32_t sg = m.next;

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -62,6 +63,10 @@ struct vlg_workspace {
     uint64_t filter_pivot_ratio = 6;    // ... i.e. when all lists together are at least this many times longer (C3, ms per batch: 24 -> 262,
                                         // 12 -> 251, 6 -> 246.6, 4 -> 246.4, <= 3 -> 248: the probes win wherever a list is clearly the shortest)
     void* fences = nullptr;     // F[g] = P[64 g + 63] over the lists of the super-chunk in work (join_device.hpp), or null
+    void* rungs = nullptr;      // the 4-ary ladder over the same lists (join_device.hpp), or null
+    uint64_t* rung_off = nullptr;   // device: first entry of every level
+    uint32_t pivot_rungs = 1;   // the pivot filter searches through the ladder: 0 never (fences + bisection), 1 when it pays, 2 always
+    bool want_rungs = false;    // ... and the super-chunk in work has enough pivot searches to pay for building it
     bool list_sort = true;      // 32-bit positions: every list sorted inside itself (list_sort.hpp); off: the two rocPRIM paths below
     uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
@@ -243,6 +248,7 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "filter_min")) { ws->filter_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_pivot")) { ws->filter_pivot = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter_pivot_ratio")) { ws->filter_pivot_ratio = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "pivot_rungs")) { ws->pivot_rungs = value <= 0 ? 0u : (value == 1 ? 1u : 2u); return VLG_OK; }
     if (!strcmp(name, "filter_stream_min")) { ws->filter_stream_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_group_bytes")) { ws->filter_group_bytes = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "reserve")) {                           // allocate the scratch now (+ the per-chunk metadata a batch adds on top of its budget)
@@ -286,8 +292,9 @@ extern "C" vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_s
 struct ResultPiece {
     uint64_t q0 = 0, q1 = 0;       // query range of the chunk
     uint64_t matches = 0, tuple_vals = 0;
-    uint64_t* d_first = nullptr;   // [matches]
-    uint64_t* d_tuples = nullptr;  // [tuple_vals]
+    void* d_first = nullptr;       // [matches] positions of `width` bytes
+    void* d_tuples = nullptr;      // [tuple_vals]
+    uint32_t width = 8;            // 4 when the text's positions fit 32 bits (vlg_result_fetch widens on the way to the host)
     uint64_t first_bytes = 0, tuple_bytes = 0;   // sizes of the allocations (a parked buffer may be larger than needed)
 };
 
@@ -344,14 +351,14 @@ struct ResultCache {
 ResultCache& result_cache() { static ResultCache* c = new ResultCache(); return *c; }     // never destroyed: no HIP calls at exit
 void drain_result_cache() { result_cache().drain(); }
 
-hipError_t result_alloc(uint64_t** out, uint64_t bytes, uint64_t* got)
+hipError_t result_alloc(void** out, uint64_t bytes, uint64_t* got)
 {
-    if (void* p = result_cache().take(bytes, got)) { *out = (uint64_t*)p; return hipSuccess; }
-    hipError_t e = hipMalloc((void**)out, bytes);
+    if (void* p = result_cache().take(bytes, got)) { *out = p; return hipSuccess; }
+    hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess) {                                   // memory may be parked in the cache: release it and retry once
         (void)hipGetLastError();
         result_cache().drain();
-        e = hipMalloc((void**)out, bytes);
+        e = hipMalloc(out, bytes);
     }
     *got = bytes;
     return e;
@@ -387,6 +394,93 @@ extern "C" vlg_status vlg_result_owned_queries(const vlg_result* r, uint64_t* h_
     return VLG_OK;
 }
 
+// ---- narrow results on their way to the host ----------------------------------------------------------------------------------
+// Pieces travel as they are stored: 4 bytes per position when the text's positions fit 32 bits (half the PCIe time of the
+// 8-byte values the caller receives).  A few host threads each take a slice of the piece, copy it block by block into their own
+// two pinned staging blocks on their own stream and widen block i into the caller's array while block i + 1 is in flight.
+namespace {
+constexpr uint32_t kFetchThreads = 8;
+constexpr uint64_t kFetchBlock = 8ull << 20;                 // bytes per staging block
+struct FetchLane { void* blk[2] = {nullptr, nullptr}; hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; int device = -1; };
+struct FetchStage {
+    std::mutex mu;                                           // one narrow fetch at a time uses the staging blocks
+    FetchLane lane[kFetchThreads];
+    hipError_t ready(FetchLane& l, int dev)
+    {
+        hipError_t e = hipSuccess;
+        for (int b = 0; b < 2 && e == hipSuccess; ++b)
+            if (!l.blk[b]) e = hipHostMalloc(&l.blk[b], kFetchBlock, hipHostMallocPortable);
+        if (e == hipSuccess && l.device != dev) {            // streams and events belong to a device
+            if (l.st) { (void)hipStreamDestroy(l.st); (void)hipEventDestroy(l.ev[0]); (void)hipEventDestroy(l.ev[1]); l.st = nullptr; }
+            e = hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking);
+            for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&l.ev[b], hipEventDisableTiming);
+            if (e == hipSuccess) l.device = dev;
+        }
+        return e;
+    }
+};
+FetchStage& fetch_stage() { static FetchStage* s = new FetchStage; return *s; }
+
+inline void widen_block(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) __builtin_nontemporal_store((uint64_t)in[i], out + i);     // the caller's array is written once: keep it out of the caches
+}
+
+// elements [a, b) of a narrow device array into h[a, b)
+hipError_t fetch_slice_widened(FetchLane& l, const uint32_t* d, uint64_t a, uint64_t b, uint64_t* h)
+{
+    const uint64_t per = kFetchBlock / 4;
+    uint64_t at = a;
+    uint64_t pend_at[2] = {0, 0}, pend_n[2] = {0, 0};
+    int slot = 0;
+    hipError_t e = hipSuccess;
+    auto drain = [&](int sl) -> hipError_t {
+        if (!pend_n[sl]) return hipSuccess;
+        hipError_t w = hipEventSynchronize(l.ev[sl]);
+        if (w == hipSuccess) widen_block(static_cast<const uint32_t*>(l.blk[sl]), h + pend_at[sl], pend_n[sl]);
+        pend_n[sl] = 0;
+        return w;
+    };
+    while (at < b && e == hipSuccess) {
+        const uint64_t n = std::min(per, b - at);
+        e = drain(slot);                                         // the block this copy lands in must have been widened
+        if (e != hipSuccess) break;
+        e = hipMemcpyAsync(l.blk[slot], d + at, n * 4, hipMemcpyDeviceToHost, l.st);
+        if (e == hipSuccess) e = hipEventRecord(l.ev[slot], l.st);
+        pend_at[slot] = at; pend_n[slot] = e == hipSuccess ? n : 0;
+        at += n;
+        slot ^= 1;
+        if (e == hipSuccess) e = drain(slot);                    // widen the older block while this one is in flight
+    }
+    for (int sl = 0; sl < 2; ++sl) { hipError_t w = drain(sl); if (e == hipSuccess) e = w; }
+    return e;
+}
+
+hipError_t fetch_widened(const void* d_narrow, uint64_t count, uint64_t* h)
+{
+    if (!count) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    FetchStage& fs = fetch_stage();
+    std::lock_guard<std::mutex> g(fs.mu);
+    const uint32_t nt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(kFetchThreads, count / (1u << 20)));
+    for (uint32_t t = 0; t < nt; ++t) if ((e = fs.ready(fs.lane[t], dev)) != hipSuccess) return e;
+    const uint32_t* d = static_cast<const uint32_t*>(d_narrow);
+    if (nt == 1) return fetch_slice_widened(fs.lane[0], d, 0, count, h);
+    std::vector<hipError_t> err(nt, hipSuccess);
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            err[t] = hipSetDevice(dev);                          // the current device is a per-thread setting
+            if (err[t] == hipSuccess) err[t] = fetch_slice_widened(fs.lane[t], d, count * t / nt, count * (t + 1) / nt, h);
+        });
+    for (auto& x : th) x.join();
+    for (uint32_t t = 0; t < nt; ++t) if (err[t] != hipSuccess) return err[t];
+    return hipSuccess;
+}
+}  // namespace
+
 extern "C" vlg_status vlg_result_fetch(const vlg_result* r, uint64_t* h_counts, uint64_t* h_offsets, uint64_t* h_first, uint64_t* h_tuples)
 {
     if (!r) return fail(VLG_E_INVALID, "null argument");
@@ -401,8 +495,30 @@ extern "C" vlg_status vlg_result_fetch(const vlg_result* r, uint64_t* h_counts, 
         return fail(VLG_E_INVALID, "tuples were not materialised (workspace option \"tuples\" is 0)");
     uint64_t fo = 0, to = 0;
     for (const auto& p : r->pieces) {
-        if (h_first && p.matches) VLG_HIP_TRY(hipMemcpy(h_first + fo, p.d_first, p.matches * 8, hipMemcpyDeviceToHost));
-        if (h_tuples && p.tuple_vals) VLG_HIP_TRY(hipMemcpy(h_tuples + to, p.d_tuples, p.tuple_vals * 8, hipMemcpyDeviceToHost));
+        if (p.width == 4) {
+            if (h_first && p.matches) VLG_HIP_TRY(fetch_widened(p.d_first, p.matches, h_first + fo));
+            if (h_tuples && p.tuple_vals) VLG_HIP_TRY(fetch_widened(p.d_tuples, p.tuple_vals, h_tuples + to));
+        } else {
+            if (h_first && p.matches) VLG_HIP_TRY(hipMemcpy(h_first + fo, p.d_first, p.matches * 8, hipMemcpyDeviceToHost));
+            if (h_tuples && p.tuple_vals) VLG_HIP_TRY(hipMemcpy(h_tuples + to, p.d_tuples, p.tuple_vals * 8, hipMemcpyDeviceToHost));
+        }
+        fo += p.matches;
+        to += p.tuple_vals;
+    }
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_result_fetch32(const vlg_result* r, uint32_t* h_first, uint32_t* h_tuples)
+{
+    if (!r) return fail(VLG_E_INVALID, "null argument");
+    if (h_tuples && r->sum.n_matches && !r->sum.n_tuple_values)
+        return fail(VLG_E_INVALID, "tuples were not materialised (workspace option \"tuples\" is 0)");
+    for (const auto& p : r->pieces)
+        if (p.matches && p.width != 4) return fail(VLG_E_INVALID, "the positions of this result are 64 bits wide (vlg_result_fetch)");
+    uint64_t fo = 0, to = 0;
+    for (const auto& p : r->pieces) {
+        if (h_first && p.matches) VLG_HIP_TRY(hipMemcpy(h_first + fo, p.d_first, p.matches * 4, hipMemcpyDeviceToHost));
+        if (h_tuples && p.tuple_vals) VLG_HIP_TRY(hipMemcpy(h_tuples + to, p.d_tuples, p.tuple_vals * 4, hipMemcpyDeviceToHost));
         fo += p.matches;
         to += p.tuple_vals;
     }
@@ -542,6 +658,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     Pc_out = nullptr;
     pc_cap = 0;
     ws->fences = nullptr;
+    ws->rungs = nullptr;
     if (!gacc) return VLG_OK;
     // Collective search: this rank locates and sorts a contiguous share [sl, sh) of the lists -- cut so that every rank gets the
     // same number of occurrences, identically on every rank -- and the ranks exchange their sorted pieces afterwards.
@@ -732,6 +849,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     }
     // fences of the sorted lists (and room for those of the survivors' lists behind them)
     ws->fences = nullptr;
+    ws->rungs = nullptr;
     if (P_out) {
         const uint64_t cover = Pc_out ? (uint64_t)(Pc_out - P_out) + pc_cap : gacc;
         const uint64_t entries = cover / 64 + 2;
@@ -741,6 +859,20 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(fence_build_kernel<pos_t>), dim3(grid_for(gacc / 64, 8192)), dim3(256), 0, st, P_out, (uint64_t)0, gacc / 64, F);
             VLG_HIP_TRY(hipGetLastError());
             ws->fences = F;
+        }
+        // the ladder for the pivot filter (a third of the lists' size): only when the window filter will run on these lists
+        if (ws->fences && ws->want_rungs && gacc >= 64) {
+            const RungLayout rl = rung_layout(gacc);
+            if (A.size - A.used > rl.entries * sizeof(pos_t) + 8192) {
+                pos_t* R = A.take<pos_t>(rl.entries);
+                uint64_t* d_off = A.take<uint64_t>(kMaxRungs + 1);
+                svec<uint64_t> h_off(rl.off, rl.off + kMaxRungs + 1);
+                VLG_HIP_TRY(hipMemcpyAsync(d_off, h_off.data(), (kMaxRungs + 1) * 8, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(rung_build_kernel<pos_t>), dim3(grid_for(gacc / 4, 16384)), dim3(256), 0, st, P_out, gacc, R, d_off, rl.levels);
+                VLG_HIP_TRY(hipGetLastError());
+                ws->rungs = R;
+                ws->rung_off = d_off;
+            }
         }
     }
     res->sum.located_occurrences += acc;
@@ -1016,14 +1148,16 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
     }
     piece.matches = M; piece.tuple_vals = TV;
     if (M) {
-        VLG_HIP_TRY(result_alloc(&piece.d_first, M * 8, &piece.first_bytes));
-        if (TV) VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * 8, &piece.tuple_bytes));
+        piece.width = sizeof(pos_t);
+        VLG_HIP_TRY(result_alloc(&piece.d_first, M * sizeof(pos_t), &piece.first_bytes));
+        if (TV) VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * sizeof(pos_t), &piece.tuple_bytes));
         res->pieces.push_back(piece);
         jt.mark("  chunk: result malloc");
         VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
-        Timed t(ws, KS_GATHER, 8ull * (M + TV));
+        Timed t(ws, KS_GATHER, sizeof(pos_t) * (M + TV));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(runs_grid(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, d_segb, nlive,
-                           d_sm, d_qm, lvl0_begin, lvl0_end, link, mlist, d_counts, piece.d_first, piece.d_tuples, d_stats + kStatsChecksum);
+                           d_sm, d_qm, lvl0_begin, lvl0_end, link, mlist, d_counts, static_cast<pos_t*>(piece.d_first),
+                           static_cast<pos_t*>(piece.d_tuples), d_stats + kStatsChecksum);
         VLG_HIP_TRY(hipGetLastError());
     } else {
         res->pieces.push_back(piece);
@@ -1253,7 +1387,17 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             logical_max_query = std::max(logical_max_query, join_bytes_of(q, qi, [&](uint64_t s) -> uint64_t { return pl.occ[s]; }));
         // the trail table (8 B per text position) and the records (8 B per occurrence) must leave room for the joins
         uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup ? (idx->hdr.n + phys) * 8 + 512 : 0;
-        const uint64_t phys_plain = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20) + phys;    // (+ fences: < 1 B per element)
+        // (+ fences: < 1 B per element; + the pivot filter's ladder, a third of the lists, when its searches outweigh building it:
+        // one pass over the lists against two descents per pivot element)
+        uint64_t pivot_elems = 0;
+        if (ws->filter && ws->filter_pivot && ws->pivot_rungs)
+            for (uint64_t qi = Q0; qi < Q1; ++qi) {
+                uint32_t pv = 0;
+                if (filter_mode(q, pl, ws, qi, &pv) == 2) pivot_elems += pl.occ[q->qsub[qi] + pv];
+            }
+        ws->want_rungs = pivot_elems && (ws->pivot_rungs == 2 || (pivot_elems >= phys / 16 && pivot_elems >= 4096));
+        const uint64_t rung_bytes = ws->want_rungs ? rung_layout(phys).entries * sizeof(pos_t) + 8192 : 0;
+        const uint64_t phys_plain = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20) + phys + rung_bytes;
         if (trail_bytes) {
             const uint64_t left = budget > phys_plain + trail_bytes ? budget - phys_plain - trail_bytes : 0;
             if (left < std::max<uint64_t>(2 * logical_max_query, budget / 8)) trail_bytes = 0;
@@ -1705,6 +1849,7 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
         if (vlg_status s = ws_reserve(ws, list_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
         ws->trail_gen = 0;                                       // the lists take the head of the arena
         ws->fences = nullptr;
+        ws->rungs = nullptr;
         Arena A{ws->arena, ws->arena_bytes};
         uint64_t* P = A.take<uint64_t>(pc_first + pc_cap + 64);
         uint64_t* F = A.take<uint64_t>(fence_entries);

@@ -536,7 +536,7 @@ extern "C" vlg_status vlg_wtsa_search_batch(const vlg_wtsa* x, const vlg_queries
             VLG_HIP_TRY(hipMemcpyAsync(d_q, hq.data(), nq * sizeof(WQuery), hipMemcpyHostToDevice, st));
             Timed t(ws, KS_GATHER, 8ull * (M + TV));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<true>), dim3(wgs), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
-                               (uint32_t)nq, kmax, max_matches, d_counts, piece.d_first, piece.d_tuples, d_chk);
+                               (uint32_t)nq, kmax, max_matches, d_counts, static_cast<uint64_t*>(piece.d_first), static_cast<uint64_t*>(piece.d_tuples), d_chk);
             VLG_HIP_TRY(hipGetLastError());
         }
         unsigned long long chk = 0;

@@ -67,6 +67,16 @@ class SearchResult:
         """vlg_result_fetch into caller-provided host buffers (e.g. pinned memory); any pointer may be None."""
         check(lib().vlg_result_fetch(self._h, counts_ptr, offsets_ptr, first_ptr, tuples_ptr))
 
+    def fetch32_into(self, first_ptr, tuples_ptr):
+        """vlg_result_fetch32: the positions as they are held in HBM when they fit 32 bits (VlgError otherwise)."""
+        check(lib().vlg_result_fetch32(self._h, first_ptr, tuples_ptr))
+
+    def fetch32(self):
+        first = np.zeros(max(self.summary["n_matches"], 1), dtype=np.uint32)
+        tuples = np.zeros(max(self.summary["n_tuple_values"], 1), dtype=np.uint32)
+        self.fetch32_into(first.ctypes.data, tuples.ctypes.data if self.summary["n_tuple_values"] else None)
+        return first[: self.summary["n_matches"]], tuples[: self.summary["n_tuple_values"]]
+
     @property
     def counts(self):
         return self.fetch()[0]
