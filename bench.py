@@ -102,6 +102,8 @@ CLASSES = {
              ["list_sort_small_kernel", "list_sort_hist_kernel", "list_sort_chunk_kernel", "list_sort_scan_kernel", "list_sort_prefix_kernel",
               "list_sort_scatter_kernel"],
              "one read + one write of every position (2 x 4 B); the radix passes in between are overhead"),
+    "filter_ladder": ("rung_build_kernel (4-ary search ladder over the sorted lists, for the pivot filter)", ["rung_build_kernel"],
+                      "every list element read once (4 B); a third as many entries written"),
     "filter_pivot": ("filter_pivot_kernel", ["filter_pivot_kernel"], "16 B per (pivot element, level): two lower bounds"),
     "filter_pass": ("filter_pass_kernel", ["filter_pass_kernel"], "4 B per list element streamed"),
     "filter_compact": ("filter_compact_kernel", ["filter_compact_kernel", "filter_count_runs_kernel", "filter_gather_counts_kernel"],   # (+ a small rocPRIM scan: its

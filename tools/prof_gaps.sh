@@ -3,6 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift
+[ -n "$TAG" ] || { echo "usage: prof_gaps.sh <tag> [bench args...]"; exit 2; }
 O=$R/gpurun_out/$TAG
 rm -rf $O /tmp/$TAG; mkdir -p $O
 cd $R

@@ -157,6 +157,17 @@ struct StageAlloc {
     template <class U> bool operator!=(const StageAlloc<U>&) const { return false; }
 };
 template <class T> using svec = std::vector<T, StageAlloc<T>>;   // a vector whose storage is staged for device copies
+// ... and one whose resize(n) leaves the new elements as they are (arrays that a device copy fills completely)
+template <class T>
+struct StageAllocRaw : StageAlloc<T> {
+    using value_type = T;
+    StageAllocRaw() = default;
+    template <class U> StageAllocRaw(const StageAllocRaw<U>&) {}
+    template <class U> struct rebind { using other = StageAllocRaw<U>; };
+    template <class U> void construct(U*) noexcept {}
+    template <class U, class... Args> void construct(U* p, Args&&... args) { ::new ((void*)p) U(std::forward<Args>(args)...); }
+};
+template <class T> using rvec = std::vector<T, StageAllocRaw<T>>;
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 inline uint32_t bit_width64(uint64_t x) { return x ? 64u - (uint32_t)__builtin_clzll(x) : 0u; }

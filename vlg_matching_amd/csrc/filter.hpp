@@ -208,7 +208,10 @@ __global__ void __launch_bounds__(256) filter_pass_kernel(const pos_t* __restric
 // groups so that every round has one load per group in flight instead of one in all: the windows of a group ascend
 // with the lane, so first 2 x kPivotGroups wave-wide 64-ary searches bracket each group's answers between the lower bounds
 // of its smallest a and its largest b + 1, then every lane bisects its own a and b + 1 inside its group's bracket.
-constexpr uint32_t kPivotGroups = 4;
+#ifndef VLG_PIVOT_GROUPS
+#define VLG_PIVOT_GROUPS 2
+#endif
+constexpr uint32_t kPivotGroups = VLG_PIVOT_GROUPS;
 template <typename pos_t>
 __device__ __forceinline__ void pivot_ranges(const pos_t* __restrict__ P, const pos_t* __restrict__ F, uint32_t pbegin, uint32_t pend, const uint64_t (&a)[kPivotGroups],
                                              const uint64_t (&b)[kPivotGroups], bool (&on)[kPivotGroups], uint32_t (&i0)[kPivotGroups],
@@ -633,7 +636,8 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __rest
                                                              const uint32_t* __restrict__ task_seg, const uint64_t* __restrict__ task_run0,
                                                              uint32_t ntasks, const uint64_t* __restrict__ abits,
                                                              const uint32_t* __restrict__ run_cnt, const uint32_t* __restrict__ run_off,
-                                                             pos_t* __restrict__ Pc, uint64_t pc_cap /* elements Pc can take */)
+                                                             pos_t* __restrict__ Pc, uint64_t pc_cap /* elements Pc can take */,
+                                                             uint32_t dense_min /* runs with fewer survivors move them half a word per lane */)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t r0 = uniform(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kCompactRuns;
@@ -664,7 +668,7 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __rest
         const uint32_t out0 = run_off[run];
         if ((uint64_t)out0 + run_cnt[run] > pc_cap) continue;                    // (a compaction launched before the counts were known: the host sees
                                                                                  // the same total and falls back to compacting chunk by chunk)
-        if (uniform(run_cnt[run]) < kRun / 2) {
+        if (uniform(run_cnt[run]) < dense_min) {
             // sparse run (the usual case: few elements survive the filter): every lane moves the survivors of its own half word, so
             // the loop runs as often as the fullest half word has survivors, not once per word
             const uint64_t wbits = __shfl(mine, (int)(lane >> 1));
@@ -931,7 +935,7 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
             Timed t(ws, KS_FILTER_COMPACT, 0);
             VLG_HIP_TRY(rocprim::exclusive_scan(d_scan, scan_tmp, fg.d_runcnt, d_off, 0u, total_runs, rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_compact_kernel<pos_t>), dim3((uint32_t)(((total_runs + kCompactRuns - 1) / kCompactRuns + 3) / 4)),
-                               dim3(256), 0, st, P, fg.d_segs, fg.d_cseg, fg.d_crun0, fg.ncseg, fg.d_abits, fg.d_runcnt, d_off, Pc, fg.pc_cap);
+                               dim3(256), 0, st, P, fg.d_segs, fg.d_cseg, fg.d_crun0, fg.ncseg, fg.d_abits, fg.d_runcnt, d_off, Pc, fg.pc_cap, ws->compact_dense_min);
             VLG_HIP_TRY(hipGetLastError());
             spec_launched = true;
         } else A.failed = false;                                     // no room for the scan: the chunks compact their own lists

@@ -110,6 +110,8 @@ vlg_status upload_queries(vlg_queries* q)
     VLG_HIP_TRY(hipMalloc((void**)&q->d_suboff, (q->nsub + 1) * 8));
     if (!q->blob.empty()) VLG_HIP_TRY(hipMemcpy(q->d_blob, q->blob.data(), q->blob.size(), hipMemcpyHostToDevice));
     VLG_HIP_TRY(hipMemcpy(q->d_suboff, q->suboff.data(), (q->nsub + 1) * 8, hipMemcpyHostToDevice));
+    VLG_HIP_TRY(hipMalloc((void**)&q->d_qsub, (q->nq + 1) * 8));
+    VLG_HIP_TRY(hipMemcpy(q->d_qsub, q->qsub.data(), (q->nq + 1) * 8, hipMemcpyHostToDevice));
     return VLG_OK;
 }
 
@@ -319,6 +321,7 @@ extern "C" void vlg_queries_destroy(vlg_queries* q)
     if (!q) return;
     if (q->d_blob) (void)hipFree(q->d_blob);
     if (q->d_suboff) (void)hipFree(q->d_suboff);
+    if (q->d_qsub) (void)hipFree(q->d_qsub);
     delete q;
 }
 

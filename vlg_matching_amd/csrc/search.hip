@@ -36,9 +36,9 @@ using namespace vlg;
 // =============================================================================================
 // Workspace
 // =============================================================================================
-enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_LOCATE_PART, KS_LOCATE_RESOLVE, KS_SORT, KS_FILTER_PIVOT, KS_FILTER_PASS, KS_FILTER_COMPACT,
+enum { KS_BSEARCH = 0, KS_EXPAND, KS_LOCATE, KS_LOCATE_PART, KS_LOCATE_RESOLVE, KS_SORT, KS_FILTER_LADDER, KS_FILTER_PIVOT, KS_FILTER_PASS, KS_FILTER_COMPACT,
        KS_JOIN_INIT, KS_JOIN_LINK, KS_JOIN_SCAN, KS_JOIN_CHAIN, KS_GATHER, KS_EXCHANGE, KS_COUNT };
-static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "locate_partition", "locate_resolve", "sort", "filter_pivot",
+static const char* kKernelNames[KS_COUNT] = {"backward_search", "expand", "locate", "locate_partition", "locate_resolve", "sort", "filter_ladder", "filter_pivot",
                                              "filter_pass", "filter_compact", "join_init", "join_link", "join_scan", "join_chain", "gather", "exchange"};
 
 struct vlg_workspace {
@@ -65,6 +65,7 @@ struct vlg_workspace {
     void* fences = nullptr;     // F[g] = P[64 g + 63] over the lists of the super-chunk in work (join_device.hpp), or null
     void* rungs = nullptr;      // the 4-ary ladder over the same lists (join_device.hpp), or null
     uint64_t* rung_off = nullptr;   // device: first entry of every level
+    uint32_t compact_dense_min = 1024;       // compaction: runs with fewer survivors move them half a word per lane, fuller ones word by word
     uint32_t pivot_rungs = 1;   // the pivot filter searches through the ladder: 0 never (fences + bisection), 1 when it pays, 2 always
     bool want_rungs = false;    // ... and the super-chunk in work has enough pivot searches to pay for building it
     bool list_sort = true;      // 32-bit positions: every list sorted inside itself (list_sort.hpp); off: the two rocPRIM paths below
@@ -248,6 +249,7 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "filter_min")) { ws->filter_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_pivot")) { ws->filter_pivot = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter_pivot_ratio")) { ws->filter_pivot_ratio = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "compact_dense_min")) { ws->compact_dense_min = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20)); return VLG_OK; }
     if (!strcmp(name, "pivot_rungs")) { ws->pivot_rungs = value <= 0 ? 0u : (value == 1 ? 1u : 2u); return VLG_OK; }
     if (!strcmp(name, "filter_stream_min")) { ws->filter_stream_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "filter_group_bytes")) { ws->filter_group_bytes = (uint64_t)value; return VLG_OK; }
@@ -537,6 +539,23 @@ inline uint32_t runs_grid(uint64_t slots) { return (uint32_t)((((slots + kRun - 
 
 inline uint32_t grid_for(uint64_t n, uint32_t cap = 16384) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, cap)); }
 
+// Host loops over the queries (or sub-patterns) of a big batch, cut into slices for a few threads: fn(begin, end, thread).
+// Batches below 2 x min_per_thread items run on the caller's thread.
+constexpr uint32_t kHostThreads = 8;
+template <class F>
+void parallel_slices(uint64_t a, uint64_t b, uint64_t min_per_thread, F&& fn)
+{
+    const uint64_t n = b > a ? b - a : 0;
+    static const uint32_t hw = std::max(1u, std::min(kHostThreads, std::thread::hardware_concurrency()));
+    const uint32_t nt = (uint32_t)std::min<uint64_t>(hw, n / std::max<uint64_t>(1, min_per_thread));
+    if (nt <= 1) { fn(a, b, 0u); return; }
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (uint32_t t = 1; t < nt; ++t) th.emplace_back([&, t] { fn(a + n * t / nt, a + n * (t + 1) / nt, t); });
+    fn(a, a + n / nt, 0u);
+    for (auto& x : th) x.join();
+}
+
 struct Arena {
     uint8_t* base; uint64_t size; uint64_t used = 0;
     bool failed = false;         // sticky: one carve that did not fit poisons the arena, so a check after a block of carves sees it
@@ -550,10 +569,10 @@ struct Arena {
     }
 };
 
-struct Plan {                       // host view of the batch after backward search
-    std::vector<uint64_t> occ;      // per sub-pattern, 0 for dead queries
-    std::vector<uint32_t> did;      // per sub-pattern: distinct-interval id (valid when occ > 0)
-    std::vector<uint64_t> dl, docc; // per distinct interval: left border, size
+struct Plan {                       // host view of the batch after backward search (staged memory: the device plan copies straight into it)
+    rvec<uint64_t> occ;             // per sub-pattern, 0 for dead queries
+    rvec<uint32_t> did;             // per sub-pattern: distinct-interval id (valid when occ > 0)
+    rvec<uint64_t> dl, docc;        // per distinct interval: left border, size
 };
 
 template <typename pos_t> constexpr uint64_t kPhysScratchPerElem() { return 20; }   // sweep scratch; the sorted lists reuse it
@@ -868,7 +887,11 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
                 uint64_t* d_off = A.take<uint64_t>(kMaxRungs + 1);
                 svec<uint64_t> h_off(rl.off, rl.off + kMaxRungs + 1);
                 VLG_HIP_TRY(hipMemcpyAsync(d_off, h_off.data(), (kMaxRungs + 1) * 8, hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(rung_build_kernel<pos_t>), dim3(grid_for(gacc / 4, 16384)), dim3(256), 0, st, P_out, gacc, R, d_off, rl.levels);
+                {
+                    Timed t(ws, KS_FILTER_LADDER, gacc * sizeof(pos_t));
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(rung_build_kernel<pos_t>), dim3(grid_for(gacc >> kRungShift, 16384)), dim3(256), 0, st, P_out, gacc, R, d_off,
+                                       rl.levels);
+                }
                 VLG_HIP_TRY(hipGetLastError());
                 ws->rungs = R;
                 ws->rung_off = d_off;
@@ -949,7 +972,7 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
                                (uint32_t)t_seg.size(), fg->d_crun0, fg->d_runcnt, d_cnt);
             VLG_HIP_TRY(rocprim::exclusive_scan(d_scan, scan_tmp, d_cnt, d_off, 0u, runs, rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_compact_kernel<pos_t>), dim3((uint32_t)(((runs + kCompactRuns - 1) / kCompactRuns + 3) / 4)),
-                               dim3(256), 0, st, P, fg->d_segs, d_tseg, d_trun0, (uint32_t)t_seg.size(), fg->d_abits, d_cnt, d_off, Pc, ~0ull);
+                               dim3(256), 0, st, P, fg->d_segs, d_tseg, d_trun0, (uint32_t)t_seg.size(), fg->d_abits, d_cnt, d_off, Pc, ~0ull, ws->compact_dense_min);
         }
         // fences of the survivors' lists: whole blocks of [Pc, Pc + pc_total) (Pc starts on a block)
         if (ws->fences && pc_total >= 64) {
@@ -1209,10 +1232,18 @@ vlg_status plan_joins(const vlg_queries* q, const Plan& pl, const vlg_workspace*
     auto full = [&](uint64_t s) -> uint64_t { return pl.occ[s]; };
     uint64_t logical_total = 0;
     jp.logical_max_query = 0;
-    for (uint64_t qi = Q0; qi < Q1; ++qi) {
-        uint64_t t = join_bytes_of(q, qi, full);
-        logical_total += t;
-        jp.logical_max_query = std::max(jp.logical_max_query, t);
+    {
+        uint64_t part_sum[kHostThreads] = {0}, part_max[kHostThreads] = {0};
+        parallel_slices(Q0, Q1, 1u << 16, [&](uint64_t a, uint64_t b, uint32_t th) {
+            uint64_t sum = 0, mx = 0;
+            for (uint64_t qi = a; qi < b; ++qi) {
+                const uint64_t t = join_bytes_of(q, qi, full);
+                sum += t;
+                mx = std::max(mx, t);
+            }
+            part_sum[th] = sum; part_max[th] = mx;
+        });
+        for (uint32_t th = 0; th < kHostThreads; ++th) { logical_total += part_sum[th]; jp.logical_max_query = std::max(jp.logical_max_query, part_max[th]); }
     }
     // window filter: state of the filtered queries of a group (at most a third of the budget), dropped query by query if it
     // would not leave room for the largest unfiltered join
@@ -1220,16 +1251,30 @@ vlg_status plan_joins(const vlg_queries* q, const Plan& pl, const vlg_workspace*
     jp.group_cap = ws->filter_group_bytes ? std::min<uint64_t>(ws->filter_group_bytes, join_budget / 3) : join_budget / 3;
     jp.fbytes.assign(Q1 - Q0, 0);
     uint64_t filter_total = 0;
-    if (ws->filter && jp.logical_max_query + jp.group_cap <= join_budget)
-        for (uint64_t qi = Q0; qi < Q1; ++qi) {
-            uint64_t b = filter_bytes(q, pl, ws, qi, nbw);
-            if (b > jp.group_cap) b = 0;
-            jp.fbytes[qi - Q0] = b;
-            filter_total += b;
-        }
     uint64_t filter_runs = 0;                                             // runs the compaction of one chunk may have to index
-    for (uint64_t qi = Q0; qi < Q1; ++qi)
-        if (jp.fbytes[qi - Q0]) for (uint64_t s = q->qsub[qi]; s + 1 < q->qsub[qi + 1]; ++s) filter_runs += pl.occ[s] / kRun + 1;
+    if (ws->filter && jp.logical_max_query + jp.group_cap <= join_budget) {
+        uint64_t part_bytes[kHostThreads] = {0}, part_runs[kHostThreads] = {0}, part_slots[kHostThreads] = {0};
+        parallel_slices(Q0, Q1, 1u << 16, [&](uint64_t a, uint64_t b_, uint32_t th) {
+            uint64_t bytes = 0, runs = 0, slots = 0;
+            for (uint64_t qi = a; qi < b_; ++qi) {
+                uint64_t b = filter_bytes(q, pl, ws, qi, nbw);
+                if (b > jp.group_cap) b = 0;
+                jp.fbytes[qi - Q0] = b;
+                bytes += b;
+                if (b) for (uint64_t s = q->qsub[qi]; s + 1 < q->qsub[qi + 1]; ++s) { runs += pl.occ[s] / kRun + 1; slots += pl.occ[s]; }
+            }
+            part_bytes[th] = bytes; part_runs[th] = runs; part_slots[th] = slots;
+        });
+        uint64_t cand_slots = 0;
+        for (uint32_t th = 0; th < kHostThreads; ++th) { filter_total += part_bytes[th]; filter_runs += part_runs[th]; cand_slots += part_slots[th]; }
+        // The filter has a host cost per query of the batch (its tables are laid out query by query, ~25 ns each) and saves at most
+        // the join of the candidates' slots (~12 ps each): a batch of very many small queries (BASELINE config 4: 10^6 queries, a few
+        // thousand slots in those that qualify) is joined as it is.  filter_min = 0 (tests) keeps every candidate.
+        if (cand_slots < (Q1 - Q0) * (ws->filter_min / 2)) {
+            std::fill(jp.fbytes.begin(), jp.fbytes.end(), 0);
+            filter_total = 0; filter_runs = 0;
+        }
+    }
     jp.filter_need = std::min(filter_total, jp.group_cap) + filter_runs * 8;
     if (jp.filter_need >= join_budget || jp.logical_max_query > join_budget - jp.filter_need) {
         // the filter state would not leave room for the largest join: these queries are joined on their full lists
@@ -1334,6 +1379,19 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         std::vector<uint32_t> dlist;
         dlist.reserve(pl.dl.size());
         uint64_t phys = 0, Q1 = Q0;
+        if (Q0 == 0 && ws->dedup) {
+            // the usual case, without a walk over the sub-patterns: every distinct list of the batch fits one super-chunk
+            // (with dedup every id belongs to a live sub-pattern; the ids are already in ascending order)
+            uint64_t all = 0;
+            for (uint64_t d = 0; d < pl.docc.size() && all <= phys_cap; ++d) all += pl.docc[d];
+            if (all <= phys_cap) {
+                phys = all;
+                Q1 = q->nq;
+                dlist.resize(pl.dl.size());
+                for (uint32_t d = 0; d < (uint32_t)pl.dl.size(); ++d) dlist[d] = d;
+                std::fill(stamp.begin(), stamp.end(), epoch);
+            }
+        }
         while (Q1 < q->nq) {
             uint64_t add = 0;
             size_t mark = dlist.size();
@@ -1382,19 +1440,26 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             ws->tmp_bytes = sort_tmp;
         }
         const bool will_sweep = ws->sweep && phys >= ws->sweep_min && !idx->is_int;
-        uint64_t logical_max_query = 0;
-        for (uint64_t qi = Q0; qi < Q1; ++qi)
-            logical_max_query = std::max(logical_max_query, join_bytes_of(q, qi, [&](uint64_t s) -> uint64_t { return pl.occ[s]; }));
+        // per query: the largest join, and how many pivot elements the window filter will search from (for the ladder, below)
+        uint64_t logical_max_query = 0, pivot_elems = 0;
+        {
+            uint64_t part_max[kHostThreads] = {0}, part_piv[kHostThreads] = {0};
+            const bool count_pivots = ws->filter && ws->filter_pivot && ws->pivot_rungs;
+            parallel_slices(Q0, Q1, 1u << 16, [&](uint64_t a, uint64_t b, uint32_t t) {
+                uint64_t mx = 0, pv_sum = 0;
+                for (uint64_t qi = a; qi < b; ++qi) {
+                    mx = std::max(mx, join_bytes_of(q, qi, [&](uint64_t s) -> uint64_t { return pl.occ[s]; }));
+                    uint32_t pv = 0;
+                    if (count_pivots && filter_mode(q, pl, ws, qi, &pv) == 2) pv_sum += pl.occ[q->qsub[qi] + pv];
+                }
+                part_max[t] = mx; part_piv[t] = pv_sum;
+            });
+            for (uint32_t t = 0; t < kHostThreads; ++t) { logical_max_query = std::max(logical_max_query, part_max[t]); pivot_elems += part_piv[t]; }
+        }
         // the trail table (8 B per text position) and the records (8 B per occurrence) must leave room for the joins
         uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup ? (idx->hdr.n + phys) * 8 + 512 : 0;
         // (+ fences: < 1 B per element; + the pivot filter's ladder, a third of the lists, when its searches outweigh building it:
         // one pass over the lists against two descents per pivot element)
-        uint64_t pivot_elems = 0;
-        if (ws->filter && ws->filter_pivot && ws->pivot_rungs)
-            for (uint64_t qi = Q0; qi < Q1; ++qi) {
-                uint32_t pv = 0;
-                if (filter_mode(q, pl, ws, qi, &pv) == 2) pivot_elems += pl.occ[q->qsub[qi] + pv];
-            }
         ws->want_rungs = pivot_elems && (ws->pivot_rungs == 2 || (pivot_elems >= phys / 16 && pivot_elems >= 4096));
         const uint64_t rung_bytes = ws->want_rungs ? rung_layout(phys).entries * sizeof(pos_t) + 8192 : 0;
         const uint64_t phys_plain = phys * phys_per + sort_tmp + (dlist.size() + 2) * 24 + (8ull << 20) + phys + rung_bytes;
@@ -1494,17 +1559,25 @@ __global__ void interval_heads_kernel(const uint64_t* __restrict__ keys, uint64_
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
         head[j] = (keys[j] != ~0ull && (j == 0 || keys[j] != keys[j - 1])) ? 1u : 0u;
 }
-// gid = inclusive scan of the heads: the (gid-1)-th distinct interval, in ascending SA order
+// gid = inclusive scan of the heads: the (gid-1)-th distinct interval, in ascending SA order.  Also every sub-pattern's list length
+// (0 in a query that has an empty list) and their sum.
 __global__ void interval_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ sub, const uint32_t* __restrict__ gid,
-                                        uint64_t n, uint32_t kbits, uint32_t* __restrict__ did, uint64_t* __restrict__ dl, uint64_t* __restrict__ docc)
+                                        uint64_t n, uint32_t kbits, uint32_t* __restrict__ did, uint64_t* __restrict__ occ, uint64_t* __restrict__ dl,
+                                        uint64_t* __restrict__ docc, unsigned long long* __restrict__ logical)
 {
+    unsigned long long local = 0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t k = keys[j];
-        if (k == ~0ull) { did[sub[j]] = 0xFFFFFFFFu; continue; }
+        if (k == ~0ull) { did[sub[j]] = 0; occ[sub[j]] = 0; continue; }
         const uint32_t g = gid[j] - 1;
+        const uint64_t len = (k & ((1ull << kbits) - 1)) + 1;
         did[sub[j]] = g;
-        if (j == 0 || keys[j - 1] != k) { dl[g] = k >> kbits; docc[g] = (k & ((1ull << kbits) - 1)) + 1; }
+        occ[sub[j]] = len;
+        local += len;
+        if (j == 0 || keys[j - 1] != k) { dl[g] = k >> kbits; docc[g] = len; }
     }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(logical, local);
 }
 
 // Plan of a batch (which sub-patterns are live, which distinct interval each one is) from the intervals in d_l / d_r.
@@ -1533,8 +1606,8 @@ vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_
     const uint32_t kbits = 64 - std::max(32u, bit_width64(n - 1));
     hipStream_t st = ws->stream;
     const uint64_t nsub = q->nsub, nq = q->nq;
-    pl.occ.assign(nsub, 0);
-    pl.did.assign(nsub, 0);
+    pl.occ.resize(nsub);                 // (filled by the copies below: every sub-pattern gets a value on the device)
+    pl.did.resize(nsub);
     if (!nsub) return VLG_OK;
     size_t sort_tb = 0, scan_tb = 0;
     const uint64_t n8 = align_up(nsub * 8, 256), n4 = align_up(nsub * 4, 256);
@@ -1549,14 +1622,11 @@ vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_
     uint32_t* d_head = (uint32_t*)(mem + 4 * n8 + 2 * n4);
     uint32_t* d_gid = (uint32_t*)(mem + 4 * n8 + 3 * n4);
     uint32_t* d_did = (uint32_t*)(mem + 4 * n8 + 4 * n4);
-    uint64_t* d_qsub = (uint64_t*)(mem + 4 * n8 + 5 * n4);
     void* d_tmp = mem + 4 * n8 + 5 * n4 + align_up((nq + 1) * 8, 256);
-    uint32_t* d_overflow = (uint32_t*)(mem + bytes - 256);
+    uint32_t* d_flags = (uint32_t*)(mem + bytes - 256);          // [0] overflow, [2..3] sum of the list lengths
     auto run = [&]() -> vlg_status {
-        VLG_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, st));
-        svec<uint64_t> h_qsub(q->qsub.begin(), q->qsub.end());
-        VLG_HIP_TRY(hipMemcpyAsync(d_qsub, h_qsub.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(interval_keys_kernel, dim3(grid_for(nq, 2048)), dim3(256), 0, st, d_l, d_r, d_qsub, nq, kbits, keys_a, sub_a, d_overflow);
+        VLG_HIP_TRY(hipMemsetAsync(d_flags, 0, 16, st));
+        hipLaunchKernelGGL(interval_keys_kernel, dim3(grid_for(nq, 2048)), dim3(256), 0, st, d_l, d_r, q->d_qsub, nq, kbits, keys_a, sub_a, d_flags);
         rocprim::double_buffer<uint64_t> dk(keys_a, keys_b);
         rocprim::double_buffer<uint32_t> dv(sub_a, sub_b);
         size_t tb = sort_tb;
@@ -1564,16 +1634,18 @@ vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_
         hipLaunchKernelGGL(interval_heads_kernel, dim3(grid_for(nsub, 2048)), dim3(256), 0, st, dk.current(), nsub, d_head);
         tb = scan_tb;
         VLG_HIP_TRY(rocprim::inclusive_scan(d_tmp, tb, d_head, d_gid, nsub, rocprim::plus<uint32_t>(), st));
+        uint64_t* d_occ = dk.alternate();                        // the sort's other key buffer is free now
         hipLaunchKernelGGL(interval_scatter_kernel, dim3(grid_for(nsub, 2048)), dim3(256), 0, st, dk.current(), dv.current(), d_gid, nsub, kbits, d_did,
-                           d_dl, d_docc);
+                           d_occ, d_dl, d_docc, reinterpret_cast<unsigned long long*>(d_flags + 2));
         VLG_HIP_TRY(hipGetLastError());
-        uint32_t nd = 0, overflow = 0;
-        svec<uint32_t> h_did(nsub);
-        VLG_HIP_TRY(hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, st));
-        VLG_HIP_TRY(hipMemcpyAsync(&nd, d_gid + (nsub - 1), 4, hipMemcpyDeviceToHost, st));
-        VLG_HIP_TRY(hipMemcpyAsync(h_did.data(), d_did, nsub * 4, hipMemcpyDeviceToHost, st));
+        svec<uint32_t> h_flags(5, 0);                            // overflow, -, sum lo, sum hi, distinct intervals
+        VLG_HIP_TRY(hipMemcpyAsync(h_flags.data(), d_flags, 16, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipMemcpyAsync(h_flags.data() + 4, d_gid + (nsub - 1), 4, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipMemcpyAsync(pl.did.data(), d_did, nsub * 4, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipMemcpyAsync(pl.occ.data(), d_occ, nsub * 8, hipMemcpyDeviceToHost, st));
         VLG_HIP_TRY(hipStreamSynchronize(st));
-        if (overflow) { *fallback = true; return VLG_OK; }
+        if (h_flags[0]) { *fallback = true; return VLG_OK; }
+        const uint32_t nd = h_flags[4];
         pl.dl.resize(nd);
         pl.docc.resize(nd);
         if (nd) {
@@ -1581,8 +1653,7 @@ vlg_status plan_on_device(const vlg_queries* q, vlg_workspace* ws, const uint64_
             VLG_HIP_TRY(hipMemcpyAsync(pl.docc.data(), d_docc, (uint64_t)nd * 8, hipMemcpyDeviceToHost, st));
             VLG_HIP_TRY(hipStreamSynchronize(st));
         }
-        for (uint64_t s = 0; s < nsub; ++s)
-            if (h_did[s] != 0xFFFFFFFFu) { pl.did[s] = h_did[s]; pl.occ[s] = pl.docc[h_did[s]]; logical += pl.occ[s]; }
+        logical += (uint64_t)h_flags[2] | ((uint64_t)h_flags[3] << 32);
         return VLG_OK;
     };
     return run();
@@ -1780,27 +1851,6 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
     qq.hi.assign(h_hi, h_hi + qq.nsub);
     qq.end_len.assign(h_end_len, h_end_len + n_joins);
     qq.kmax = 0; qq.kmin = 0xFFFFFFFFu;
-    Plan pl;
-    pl.occ.assign(qq.nsub, 0);
-    pl.did.assign(qq.nsub, 0);
-    std::vector<uint32_t> poff(qq.nsub, 0);
-    for (uint64_t j = 0; j < n_joins; ++j) {
-        if (qq.qsub[j + 1] < qq.qsub[j] || qq.qsub[j + 1] - qq.qsub[j] > VLG_MAX_SUBPATTERNS) return fail(VLG_E_INVALID, "bad join offsets");
-        const uint32_t k = (uint32_t)(qq.qsub[j + 1] - qq.qsub[j]);
-        qq.kmax = std::max(qq.kmax, k);
-        if (k) qq.kmin = std::min(qq.kmin, k);
-        // the reference's loop would not advance with a zero length (index_sasearch.hpp:113)
-        if (k && h_end_len[j] == 0) return fail(VLG_E_INVALID, "end_len must be at least 1");
-        if (h_end_len[j] >= (1ull << 63)) return fail(VLG_E_INVALID, "end_len out of range");
-        bool live = k > 0;
-        for (uint64_t s = qq.qsub[j]; s < qq.qsub[j + 1]; ++s) {
-            if (s > qq.qsub[j] && (h_lo[s] > h_hi[s] || h_hi[s] >= (1ull << 63))) return fail(VLG_E_INVALID, "bad gap bounds");
-            live = live && h_list_off[s + 1] > h_list_off[s];
-        }
-        // a join with an empty list has no match: none of its lists is looked at (vlg_index.hpp:315-316)
-        if (live) for (uint64_t s = qq.qsub[j]; s < qq.qsub[j + 1]; ++s) { pl.occ[s] = h_list_off[s + 1] - h_list_off[s]; poff[s] = (uint32_t)h_list_off[s]; }
-    }
-    if (qq.kmin == 0xFFFFFFFFu) qq.kmin = 0;
     hipStream_t st = ws->stream;
     vlg_result* res = new vlg_result();
     memset(&res->sum, 0, sizeof res->sum);
@@ -1808,9 +1858,31 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
     res->counts.assign(n_joins, 0);
     res->k.resize(n_joins);
     for (uint64_t j = 0; j < n_joins; ++j) res->k[j] = (uint32_t)(qq.qsub[j + 1] - qq.qsub[j]);
-    for (uint64_t s = 0; s < qq.nsub; ++s) res->sum.logical_occurrences += pl.occ[s];
     unsigned long long* d_stats = nullptr;
     auto run = [&]() -> vlg_status {
+        // (the plan's arrays are staged memory: they live inside the scope this runs in)
+        Plan pl;
+        pl.occ.assign(qq.nsub, 0);
+        pl.did.assign(qq.nsub, 0);
+        std::vector<uint32_t> poff(qq.nsub, 0);
+        for (uint64_t j = 0; j < n_joins; ++j) {
+            if (qq.qsub[j + 1] < qq.qsub[j] || qq.qsub[j + 1] - qq.qsub[j] > VLG_MAX_SUBPATTERNS) return fail(VLG_E_INVALID, "bad join offsets");
+            const uint32_t k = (uint32_t)(qq.qsub[j + 1] - qq.qsub[j]);
+            qq.kmax = std::max(qq.kmax, k);
+            if (k) qq.kmin = std::min(qq.kmin, k);
+            // the reference's loop would not advance with a zero length (index_sasearch.hpp:113)
+            if (k && h_end_len[j] == 0) return fail(VLG_E_INVALID, "end_len must be at least 1");
+            if (h_end_len[j] >= (1ull << 63)) return fail(VLG_E_INVALID, "end_len out of range");
+            bool live = k > 0;
+            for (uint64_t s = qq.qsub[j]; s < qq.qsub[j + 1]; ++s) {
+                if (s > qq.qsub[j] && (h_lo[s] > h_hi[s] || h_hi[s] >= (1ull << 63))) return fail(VLG_E_INVALID, "bad gap bounds");
+                live = live && h_list_off[s + 1] > h_list_off[s];
+            }
+            // a join with an empty list has no match: none of its lists is looked at (vlg_index.hpp:315-316)
+            if (live) for (uint64_t s = qq.qsub[j]; s < qq.qsub[j + 1]; ++s) { pl.occ[s] = h_list_off[s + 1] - h_list_off[s]; poff[s] = (uint32_t)h_list_off[s]; }
+        }
+        if (qq.kmin == 0xFFFFFFFFu) qq.kmin = 0;
+        for (uint64_t s = 0; s < qq.nsub; ++s) res->sum.logical_occurrences += pl.occ[s];
         VLG_HIP_TRY(hipMalloc((void**)&d_stats, kStatsWords * 8));
         VLG_HIP_TRY(hipMemsetAsync(d_stats, 0, kStatsWords * 8, st));
         PhaseTrace tr(st);

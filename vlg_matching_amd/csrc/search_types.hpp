@@ -14,4 +14,5 @@ struct vlg_queries {
     uint32_t sym_bytes = 1;          // 1: byte sub-patterns; 4: integer alphabet (vlg_queries_parse_int), symbols little-endian in blob
     uint8_t* d_blob = nullptr;
     uint64_t* d_suboff = nullptr;
+    uint64_t* d_qsub = nullptr;      // [nq+1] on the device (the interval plan groups sub-patterns by query)
 };

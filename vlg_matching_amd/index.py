@@ -155,11 +155,11 @@ class Workspace:
         check(lib().vlg_workspace_profile(self._h, 1 if enable else 0))
 
     def kernel_stats(self):
-        arr = (capi.KernelStat * 16)()
+        arr = (capi.KernelStat * 32)()
         n = C.c_uint32()
-        check(lib().vlg_workspace_kernel_stats(self._h, arr, 16, C.byref(n)))
+        check(lib().vlg_workspace_kernel_stats(self._h, arr, 32, C.byref(n)))
         return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),
-                                           algorithmic_bytes=int(arr[i].algorithmic_bytes)) for i in range(n.value)}
+                                           algorithmic_bytes=int(arr[i].algorithmic_bytes)) for i in range(min(n.value, 32))}
 
 
 def parse_query(regexp, dialect=capi.DIALECT_LIBRARY):
