@@ -80,7 +80,7 @@ def main():
         opts = {"sweep_min": int(rng.choice([1, 1 << 22])), "sweep_tail": int(rng.choice([1, 7, 1000, 1 << 40])), "trail": int(rng.integers(0, 2)),
                 "global_sort_min": int(rng.choice([1, 1 << 40])), "list_sort": int(rng.integers(0, 2)), "filter_min": int(rng.choice([0, 1 << 12])), "filter_stream_min": int(rng.choice([0, 1 << 16])),
                 "filter_pivot": int(rng.integers(0, 2)), "filter_pivot_ratio": int(rng.choice([1, 4, 12, 64])),
-                "filter_group_bytes": int(rng.choice([0, 1 << 14, 1 << 18])), "dedup": int(rng.choice([1, 1, 0])), "pivot_rungs": int(rng.integers(0, 3))}
+                "filter_group_bytes": int(rng.choice([0, 1 << 14, 1 << 18])), "dedup": int(rng.choice([1, 1, 0])), "pivot_rungs": int(rng.integers(0, 3)), "compact_dense_min": int(rng.choice([0, 16, 256, 4096]))}
         ws = Workspace(int(rng.choice([0, 64 << 20])))
         for k_, v_ in opts.items():
             ws.set_option(k_, v_)

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 3's measurements of record, into gpurun_out/r03/ (copied into profiles/ afterwards):
 #   default bench line (cpu baseline and end-to-end region), kernel statistics + idle gaps, FETCH_SIZE and WRITE_SIZE passes
-#   (separate runs, --pmc alone), the C5 / C4 / C2 lines, the one-rank RCCL line and the two-rank rehearsal of the collective search.
+#   (separate runs, --pmc alone), the C5 / C4 / C2 lines, the one-rank RCCL line, the two-rank rehearsal of the collective search,
+#   SQ / TCP counter passes per kernel (tools/prof_sq.sh).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03
@@ -34,4 +35,7 @@ python3 bench.py --gpus 2 --single-device --backend gloo --scale 0.25 --workspac
 step "two-rank rehearsal"
 python3 bench.py --gpus 4 --single-device --backend gloo --scale 0.25 --workspace-gb 40 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > $O/rehearse_4ranks_one_device_C3x0.25.json 2> $O/rehearse_4.err || exit 1
 step "four-rank rehearsal"
+bash tools/prof_sq.sh C3 sq sq2 tcp
+for P in sq sq2 tcp; do cp gpurun_out/prof_sq_C3/$P.txt $O/pmc_${P}_bench_C3.txt; done
+step "SQ / TCP counter passes"
 ls -la $O >> $O/log

@@ -678,20 +678,45 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __rest
             for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
             uint32_t out = out0 + inc - cnt;
             const pos_t* __restrict__ src = P + sg.pbegin + off0 + 32ull * lane;
-            while (hb) {
-                const uint32_t b = (uint32_t)__ffs((int)hb) - 1;
+            while (hb) {                                                         // two survivors per turn: both loads in flight
+                const uint32_t b0 = (uint32_t)__ffs((int)hb) - 1;
                 hb &= hb - 1;
-                Pc[out++] = src[b];
+                const pos_t v0 = src[b0];
+                if (hb) {
+                    const uint32_t b1 = (uint32_t)__ffs((int)hb) - 1;
+                    hb &= hb - 1;
+                    const pos_t v1 = src[b1];
+                    Pc[out] = v0; Pc[out + 1] = v1;
+                    out += 2;
+                } else Pc[out++] = v0;
             }
             continue;
         }
+        // fuller runs word by word: the 64 lanes take the 64 slots of a word, so every line of the run is requested once.
+        // (Measured and dropped, round 3: four neighbouring slots per lane with one 16-byte load and all eight loads of the run in
+        // flight before the first store -- 29 vs 16.6 ms for the class: 130 registers, and the 16-byte loads are not aligned.)
         unsigned long long todo_w = __ballot(mine != 0);
-        while (todo_w) {
-            const int wi = __ffsll((long long)todo_w) - 1;
-            todo_w &= todo_w - 1;
-            const uint64_t bits = __shfl(mine, wi);
-            const uint32_t out = out0 + __shfl(before, wi);
-            if ((bits >> lane) & 1) Pc[out + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull))] = P[sg.pbegin + off0 + 64ull * wi + lane];
+        const pos_t* __restrict__ src = P + sg.pbegin + off0 + lane;
+        while (todo_w) {                                                         // four words per turn: their loads are in flight together
+            constexpr uint32_t U = 4;
+            int wi[U];
+            bool sel[U];
+            uint32_t at[U];
+            pos_t v[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                wi[u] = todo_w ? __ffsll((long long)todo_w) - 1 : -1;
+                todo_w &= todo_w - 1;
+                sel[u] = false;
+                if (wi[u] >= 0) {                                                // (wave-uniform)
+                    const uint64_t bits = __shfl(mine, wi[u]);
+                    sel[u] = (bits >> lane) & 1;
+                    at[u] = out0 + __shfl(before, wi[u]) + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
+                    if (sel[u]) v[u] = src[64 * wi[u]];
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) if (sel[u]) Pc[at[u]] = v[u];
         }
     }
 }

@@ -65,7 +65,8 @@ struct vlg_workspace {
     void* fences = nullptr;     // F[g] = P[64 g + 63] over the lists of the super-chunk in work (join_device.hpp), or null
     void* rungs = nullptr;      // the 4-ary ladder over the same lists (join_device.hpp), or null
     uint64_t* rung_off = nullptr;   // device: first entry of every level
-    uint32_t compact_dense_min = 1024;       // compaction: runs with fewer survivors move them half a word per lane, fuller ones word by word
+    uint32_t compact_dense_min = 256;        // compaction: runs with fewer survivors move them half a word per lane, fuller ones word by word
+                                             // (C3, ms for the class: 0 18.2, 64 18.3, 256 16.6, 512 16.8, 1024 19.2, always half words 31.5)
     uint32_t pivot_rungs = 1;   // the pivot filter searches through the ladder: 0 never (fences + bisection), 1 when it pays, 2 always
     bool want_rungs = false;    // ... and the super-chunk in work has enough pivot searches to pay for building it
     bool list_sort = true;      // 32-bit positions: every list sorted inside itself (list_sort.hpp); off: the two rocPRIM paths below
