@@ -1488,3 +1488,35 @@ def test_pivot_filter_through_the_ladder(torch_cuda, V, monkeypatch, force):
             assert res[name].summary[k_] == res["plain"].summary[k_], (name, k_)
         for x, y in zip(res[name].fetch(), res["plain"].fetch()):
             assert (x == y).all(), name
+
+
+def test_window_filter_is_skipped_when_it_cannot_pay(torch_cuda, V, oracle):
+    """A batch of very many small queries (BASELINE config 4 in miniature): the candidates of the window filter hold too few join slots
+    to pay its per-query host cost, so the batch is joined as it is -- same matches; filter_min = 0 forces the filter on it."""
+    from vlg_matching_amd.index import Workspace
+    rng = np.random.default_rng(12)
+    text = rng.choice(np.frombuffer(b"abcdefgh", np.uint8), 400_000).tobytes()
+    o = oracle.Index.from_text(text)
+    idx = V.VlgIndex.build(text)
+    qs = []
+    for _ in range(6000):                                                  # sub-patterns of 3..5 characters: lists of a few hundred elements
+        parts = []
+        for _ in range(int(rng.integers(1, 4))):
+            at = int(rng.integers(0, len(text) - 6))
+            parts.append(text[at:at + int(rng.integers(3, 6))].decode())
+        q = parts[0]
+        for sp in parts[1:]:
+            q += ".{%d,%d}?%s" % (1, 1 + int(rng.integers(0, 40)), sp)
+        qs.append(q)
+    qs[7] = "a.{0,60}?b.{0,60}?c"                                           # a few heavy queries among them: they alone would be filtered
+    qs[1900] = "e.{1,9}?a"
+    ws_auto, ws_forced = Workspace(), Workspace()
+    ws_forced.set_option("filter_min", 0)
+    ws_forced.set_option("filter_stream_min", 0)
+    a, b = idx.search(qs, workspace=ws_auto), idx.search(qs, workspace=ws_forced)
+    assert ws_auto.kernel_stats()["filter_compact"]["launches"] == 0 and ws_forced.kernel_stats()["filter_compact"]["launches"] > 0
+    assert b.summary["join_slots"] < a.summary["join_slots"]
+    for x, y in zip(a.fetch(), b.fetch()):
+        assert (x == y).all()
+    for i in (7, 1900, 0, 5999):
+        assert a.tuples(i).tolist() == o.search(qs[i]).tolist(), qs[i]

@@ -872,7 +872,7 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
     PTask* d_ptasks = A.take<PTask>(ptasks.size() + 1);
     uint64_t* d_prun0 = A.take<uint64_t>(prun0.size());
     if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (filter)");
-    VLG_HIP_TRY(hipMemsetAsync(fg.d_abits, 0, (abit / 64 + 1) * 8, st));
+    VLG_HIP_TRY(hipMemsetAsync(fg.d_abits, 0, (abit / 64 + 1) * 8, st));    // (11 GB on C3; not clearing them at all would save 1 ms of the step)
     VLG_HIP_TRY(hipMemcpyAsync(fg.d_segs, segs.data(), segs.size() * sizeof(RSeg), hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(fg.d_cseg, cseg.data(), cseg.size() * 4, hipMemcpyHostToDevice, st));
     VLG_HIP_TRY(hipMemcpyAsync(fg.d_crun0, crun0.data(), crun0.size() * 8, hipMemcpyHostToDevice, st));

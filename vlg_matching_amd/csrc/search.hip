@@ -462,9 +462,14 @@ hipError_t fetch_slice_widened(FetchLane& l, const uint32_t* d, uint64_t a, uint
 hipError_t fetch_widened(const void* d_narrow, uint64_t count, uint64_t* h)
 {
     if (!count) return hipSuccess;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    int cur = 0, dev = 0;
+    hipError_t e = hipGetDevice(&cur);
     if (e != hipSuccess) return e;
+    dev = cur;
+    hipPointerAttribute_t attr;                                  // the copies run on streams of the device that holds the result
+    if (hipPointerGetAttributes(&attr, d_narrow) == hipSuccess) dev = attr.device; else (void)hipGetLastError();
+    struct Restore { int from, to; ~Restore() { if (from != to) (void)hipSetDevice(from); } } restore{cur, dev};
+    if (dev != cur && (e = hipSetDevice(dev)) != hipSuccess) return e;
     FetchStage& fs = fetch_stage();
     std::lock_guard<std::mutex> g(fs.mu);
     const uint32_t nt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(kFetchThreads, count / (1u << 20)));
