@@ -119,7 +119,8 @@ struct RrrBV {
         uint64_t c0 = (uint64_t)h0.z | ((uint64_t)h0.w << 32), c1 = (uint64_t)h1.x | ((uint64_t)h1.y << 32),
                  c2 = (uint64_t)h1.z | ((uint64_t)h1.w << 32);
         // classes in front of the block (rrr_vector.hpp:463-467): the 192 bits of classes are shifted past one class per step
-        // (measured in round 3: unrolling the sum over the 31 fixed places with a predicate is SLOWER -- C5 locate 33.3 vs 28.8 ms)
+        // (measured in round 3: unrolling the sum over the 31 fixed places with a predicate is SLOWER -- C5 locate 33.3 vs 28.8 ms;
+        //  so are two classes per step through a 4096-entry pair table in LDS, 8 KiB more per workgroup -- 34.4 ms)
         uint32_t bits = 0;
         for (uint32_t j = 0; j < blk; ++j) {
             const uint32_t k = (uint32_t)c0 & 63u;

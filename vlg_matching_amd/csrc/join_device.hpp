@@ -201,7 +201,11 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const pos_t* __restrict__ P
 
 // Two steps at once: 128 ascending keys (lane i holds keys i and 64+i) share every window load, its fence test and the
 // loop around them, which is most of what a step costs.
-constexpr uint32_t kCoopWindows2 = 6;            // measured on C3: 2 -> 35.2, 3 -> 33.8, 4 -> 33.2, 6 -> 31.9, 8..16 -> 33..34 ms
+#ifndef VLG_COOP_WINDOWS2
+#define VLG_COOP_WINDOWS2 4
+#endif
+constexpr uint32_t kCoopWindows2 = VLG_COOP_WINDOWS2;      // round 3, link class on C3: 3 -> 22.2, 4 -> 21.9, 6 -> 22.5, 9 -> 22.8 ms (flat: the
+                                                             // far search is about as cheap per key as a window); round 2:            // measured on C3: 2 -> 35.2, 3 -> 33.8, 4 -> 33.2, 6 -> 31.9, 8..16 -> 33..34 ms
 template <typename pos_t>
 __device__ __forceinline__ void wave_lower_bound2(const pos_t* __restrict__ P, const pos_t* __restrict__ F, uint32_t wb, uint32_t b, pos_t key0, bool need0, pos_t key1,
                                                   bool need1, uint32_t& j0, pos_t& v0, uint32_t& j1, pos_t& v1)
