@@ -611,6 +611,60 @@ __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t
 // element that arrives there later has the same future, so it stops and records (that element, steps apart) in rec -- or,
 // when that element has a record already, the record one hop further.  rec[slot]: a position (high bits 0), or
 // delta << kShift | slot of the element it follows; ~0 while the element is still walking.  slot0 = first slot of the sweep.
+// one element of one round: v64 = its word (slot << kShift | SA index), e = its place in val / key
+template <class BV, typename pos_t, bool kTrail, bool kWide, class Sampling>
+__device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds<BV>& s, const Sampling& sampling, uint64_t e, uint64_t v64,
+                                              uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint32_t step, pos_t* __restrict__ out,
+                                              uint64_t* __restrict__ trail, uint64_t* __restrict__ rec, uint64_t slot0, uint64_t gen,
+                                              uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin)
+{
+    constexpr uint32_t kShift = kWide ? 33 : 32;
+    constexpr uint64_t kPosMask = (1ull << kShift) - 1;
+    uint64_t i = v64 & kPosMask;
+    uint64_t sv = 0;
+    if (sampling.probe(i, sv)) {
+        uint64_t r = sv + step;
+        if (r >= iv.n) r -= iv.n;                        // csa_wt.hpp:343-347
+        if (kTrail) rec[slot0 + (v64 >> kShift)] = r;
+        else out[v64 >> kShift] = (pos_t)r;
+        key[e] = (uint16_t)iv.sigma;
+        ++n_fin;
+    } else if (kTrail && step != 0 && (trail[i] >> 48 << 48) == gen && (trail[i] & 0xFFFFu) != step) {
+        // (round 0: nobody has walked yet; an entry of another generation is left over from an earlier sweep; an equal step is a
+        // twin -- the same index in two lists.)  Someone stood here `delta` steps ago: same text trail, `delta` positions further
+        // left when it started
+        const uint64_t m = trail[i];
+        const uint64_t owner = ((m >> 16) & 0xFFFFFFFFull) - 1, delta = step - (m & 0xFFFFu);
+        const uint64_t ro = rec[owner];
+        uint64_t r;
+        if (ro == ~0ull) r = (delta << kShift) | owner;                       // still walking: follow it
+        else if ((ro >> kShift) == 0) r = ro + delta;                          // its position is known
+        else r = ro + (delta << kShift);                                       // it follows someone itself: follow that one
+        rec[slot0 + (v64 >> kShift)] = r;
+        key[e] = (uint16_t)iv.sigma;
+        ++n_fin;
+    } else {
+        if (kTrail) trail[i] = gen | ((slot0 + (v64 >> kShift) + 1) << 16) | step;
+        uint32_t v = 0, c;
+        using walk_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;      // node-relative positions: < n
+        walk_t pos = (walk_t)i;
+        for (;;) {                                       // inverse_select: wt_pc.hpp:385-402
+            const DNode nd = s.nodes[v];
+            uint32_t bit;
+            walk_t r1;
+            BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
+            ++n_lv;
+            pos = bit ? r1 : pos - r1;
+            uint32_t ch = bit ? nd.child[1] : nd.child[0];      // (a select, not an indexed read: the node stays in registers)
+            if (ch & kLeafFlag) { c = ch & ~kLeafFlag; break; }
+            v = ch;
+        }
+        ++n_lf;
+        val[e] = (v64 & ~kPosMask) | (s.C[c] + pos);                          // LF: suffix_array_helper.hpp:341-348
+        key[e] = (uint16_t)c;
+    }
+}
+
 template <class BV, typename pos_t, bool kTrail, bool kWide, bool kTextOrder>
 __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count,
                                                          uint32_t step, pos_t* __restrict__ out,
@@ -624,53 +678,50 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
     using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
     using Sampling = typename std::conditional<kTextOrder, TextOrderSampling, SaOrderSampling<sample_t>>::type;
     const Sampling sampling(iv);
-    constexpr uint32_t kShift = kWide ? 33 : 32;
-    constexpr uint64_t kPosMask = (1ull << kShift) - 1;
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t v64 = val[e];
-        uint64_t i = v64 & kPosMask;
-        uint64_t sv = 0;
-        if (sampling.probe(i, sv)) {
-            uint64_t r = sv + step;
-            if (r >= iv.n) r -= iv.n;                        // csa_wt.hpp:343-347
-            if (kTrail) rec[slot0 + (v64 >> kShift)] = r;
-            else out[v64 >> kShift] = (pos_t)r;
-            key[e] = (uint16_t)iv.sigma;
-            ++n_fin;
-        } else if (kTrail && step != 0 && (trail[i] >> 48 << 48) == gen && (trail[i] & 0xFFFFu) != step) {
-            // (round 0: nobody has walked yet; an entry of another generation is left over from an earlier sweep; an equal step is a
-            // twin -- the same index in two lists.)  Someone stood here `delta` steps ago: same text trail, `delta` positions further
-            // left when it started
-            const uint64_t m = trail[i];
-            const uint64_t owner = ((m >> 16) & 0xFFFFFFFFull) - 1, delta = step - (m & 0xFFFFu);
-            const uint64_t ro = rec[owner];
-            uint64_t r;
-            if (ro == ~0ull) r = (delta << kShift) | owner;                       // still walking: follow it
-            else if ((ro >> kShift) == 0) r = ro + delta;                          // its position is known
-            else r = ro + (delta << kShift);                                       // it follows someone itself: follow that one
-            rec[slot0 + (v64 >> kShift)] = r;
-            key[e] = (uint16_t)iv.sigma;
-            ++n_fin;
-        } else {
-            if (kTrail) trail[i] = gen | ((slot0 + (v64 >> kShift) + 1) << 16) | step;
-            uint32_t v = 0, c;
-            using walk_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;      // node-relative positions: < n
-            walk_t pos = (walk_t)i;
-            for (;;) {                                       // inverse_select: wt_pc.hpp:385-402
-                const DNode nd = s.nodes[v];
-                uint32_t bit;
-                walk_t r1;
-                BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
-                ++n_lv;
-                pos = bit ? r1 : pos - r1;
-                uint32_t ch = bit ? nd.child[1] : nd.child[0];      // (a select, not an indexed read: the node stays in registers)
-                if (ch & kLeafFlag) { c = ch & ~kLeafFlag; break; }
-                v = ch;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x)
+        sweep_element<BV, pos_t, kTrail, kWide>(iv, s, sampling, e, val[e], val, key, step, out, trail, rec, slot0, gen, n_lv, n_lf, n_fin);
+    unsigned long long v[3] = {n_lf, n_lv, n_fin};
+    unsigned long long* const dst[3] = {&stats[0], &stats[1], n_done};
+    block_add<3>(v, dst);
+}
+
+// Round 0 without the pass that would write the elements' words first and the read that would fetch them again: an element's word
+// follows from its place -- slot t - t0, SA index l[list] + (t - first slot of the list) -- so a workgroup looks its list up once per
+// 2048 consecutive elements (as sweep_init_kernel does) and walks them at once.
+template <class BV, typename pos_t, bool kTrail, bool kWide, bool kTextOrder>
+__global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat,
+                                                          uint64_t t0, uint64_t total, uint64_t* __restrict__ val, uint16_t* __restrict__ key,
+                                                          pos_t* __restrict__ out, unsigned long long* __restrict__ stats,
+                                                          unsigned long long* __restrict__ n_done, uint64_t* __restrict__ trail,
+                                                          uint64_t* __restrict__ rec, uint64_t gen /* << 48 */)
+{
+    __shared__ WalkLds<BV> s;
+    __shared__ uint64_t s_first;
+    stage_walk(s, iv);
+    using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
+    using Sampling = typename std::conditional<kTextOrder, TextOrderSampling, SaOrderSampling<sample_t>>::type;
+    const Sampling sampling(iv);
+    constexpr uint32_t kShift = kWide ? 33 : 32;
+    constexpr uint32_t kPer = 8;
+    uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
+    for (uint64_t base = t0 + (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
+        __syncthreads();                                                         // (s_first of the previous turn has been read)
+        if (threadIdx.x == 0) {
+            uint64_t lo = 0, hi = n_pat;
+            while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (out_off[mid] <= base) lo = mid; else hi = mid; }
+            s_first = lo;
+        }
+        __syncthreads();
+        uint64_t p = s_first;
+#pragma unroll 1
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint64_t t = base + i * 256 + threadIdx.x;
+            if (t < total) {
+                while (out_off[p + 1] <= t) ++p;
+                const uint64_t v64 = ((t - t0) << kShift) | (l[p] + (t - out_off[p]));
+                sweep_element<BV, pos_t, kTrail, kWide>(iv, s, sampling, t - t0, v64, val, key, 0u, out, trail, rec, t0, gen, n_lv, n_lf, n_fin);
             }
-            ++n_lf;
-            val[e] = (v64 & ~kPosMask) | (s.C[c] + pos);                          // LF: suffix_array_helper.hpp:341-348
-            key[e] = (uint16_t)c;
         }
     }
     unsigned long long v[3] = {n_lf, n_lv, n_fin};
@@ -870,8 +921,11 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             if (trail_gen) *trail_gen = (uint32_t)gen;
             gen <<= 48;
         }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for((t1 - t0 + 7) / 8, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
-                           t0, t1, val_a);
+        // (a sweep too short for a single round hands its elements to the stragglers' kernel, which reads their words)
+        const bool fused_first = t1 - t0 > tail_threshold && [] { const char* e = getenv("VLG_NO_FUSED_FIRST_ROUND"); return !(e && e[0] == '1'); }();
+        if (!fused_first)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for((t1 - t0 + 7) / 8, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
+                               t0, t1, val_a);
         VLG_HIP_TRY(hipGetLastError());
         uint64_t alive = t1 - t0;
         uint32_t step = 0;
@@ -880,7 +934,10 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
             if (timer) timer->begin(0);
             const dim3 grid(grid_for(alive, 4096));
-#define VLG_STEP(BV, TR, TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<BV, pos_t, TR, kWide, TO>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, step, out, d_stats, d_counter, trail, rec, t0, gen)
+            const bool first = fused_first && step == 0;                       // round 0 makes the elements' words itself (sweep_first_kernel)
+            const dim3 grid_first(grid_for((alive + 7) / 8, 8192));
+#define VLG_STEP(BV, TR, TO) do { if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val_a, key_a, out, d_stats, d_counter, trail, rec, gen); \
+                                   else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<BV, pos_t, TR, kWide, TO>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, step, out, d_stats, d_counter, trail, rec, t0, gen); } while (0)
 #define VLG_STEP_BV(TR, TO) do { if (rrr) VLG_STEP(RrrBV, TR, TO); else VLG_STEP(PlainBV, TR, TO); } while (0)
             if constexpr (!kWide) {
                 if (text_order) { if (trail) VLG_STEP_BV(true, true); else VLG_STEP_BV(false, true); }
