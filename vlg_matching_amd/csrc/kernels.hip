@@ -612,7 +612,7 @@ __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t
 // when that element has a record already, the record one hop further.  rec[slot]: a position (high bits 0), or
 // delta << kShift | slot of the element it follows; ~0 while the element is still walking.  slot0 = first slot of the sweep.
 // one element of one round: v64 = its word (slot << kShift | SA index), e = its place in val / key
-template <class BV, typename pos_t, bool kTrail, bool kWide, class Sampling>
+template <class BV, typename pos_t, bool kTrail, bool kWide, bool kFirst = false, class Sampling>
 __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds<BV>& s, const Sampling& sampling, uint64_t e, uint64_t v64,
                                               uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint32_t step, pos_t* __restrict__ out,
                                               uint64_t* __restrict__ trail, uint64_t* __restrict__ rec, uint64_t slot0, uint64_t gen,
@@ -645,6 +645,7 @@ __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds
         ++n_fin;
     } else {
         if (kTrail) trail[i] = gen | ((slot0 + (v64 >> kShift) + 1) << 16) | step;
+        if (kTrail && kFirst) rec[slot0 + (v64 >> kShift)] = ~0ull;               // still walking (no pass clears the records beforehand)
         uint32_t v = 0, c;
         using walk_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;      // node-relative positions: < n
         walk_t pos = (walk_t)i;
@@ -720,7 +721,7 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
             if (t < total) {
                 while (out_off[p + 1] <= t) ++p;
                 const uint64_t v64 = ((t - t0) << kShift) | (l[p] + (t - out_off[p]));
-                sweep_element<BV, pos_t, kTrail, kWide>(iv, s, sampling, t - t0, v64, val, key, 0u, out, trail, rec, t0, gen, n_lv, n_lf, n_fin);
+                sweep_element<BV, pos_t, kTrail, kWide, true>(iv, s, sampling, t - t0, v64, val, key, 0u, out, trail, rec, t0, gen, n_lv, n_lf, n_fin);
             }
         }
     }
@@ -908,7 +909,6 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     if (kWide && text_order) return fail(VLG_E_UNSUPPORTED, "text-order sampling with 64-bit SA indices");
     const unsigned bits = bit_width64(iv.sigma);            // keys 0..sigma (sigma = finished, sorts last)
     const uint64_t batch_max = sweep_batch_max<kWide>();
-    if (trail) VLG_HIP_TRY(hipMemsetAsync(rec, 0xFF, total * 8, stream));
     for (uint64_t t0 = 0; t0 < total; t0 += batch_max) {
         const uint64_t t1 = std::min(total, t0 + batch_max);
         uint64_t gen = 0;
@@ -923,9 +923,11 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
         }
         // (a sweep too short for a single round hands its elements to the stragglers' kernel, which reads their words)
         const bool fused_first = t1 - t0 > tail_threshold && [] { const char* e = getenv("VLG_NO_FUSED_FIRST_ROUND"); return !(e && e[0] == '1'); }();
-        if (!fused_first)
+        if (!fused_first) {
+            if (trail) VLG_HIP_TRY(hipMemsetAsync(rec + t0, 0xFF, (t1 - t0) * 8, stream));      // "still walking" (sweep_first_kernel writes it itself)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for((t1 - t0 + 7) / 8, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
                                t0, t1, val_a);
+        }
         VLG_HIP_TRY(hipGetLastError());
         uint64_t alive = t1 - t0;
         uint32_t step = 0;
