@@ -1417,12 +1417,12 @@ def test_narrow_results_widen_on_fetch(torch_cuda, V, oracle, monkeypatch):
     positions (VLG_FORCE_POS64=1, the wtsa index) refuse the narrow fetch."""
     torch = torch_cuda
     rng = np.random.default_rng(5)
-    text = rng.choice(np.frombuffer(b"ab", np.uint8), 30_000_000, p=[0.7, 0.3]).tobytes()
+    text = rng.choice(np.frombuffer(b"ab", np.uint8), 50_000_000, p=[0.7, 0.3]).tobytes()
     idx = V.VlgIndex.build(text)
     qs = ["ab.{0,3}?a", "a", "ba.{1,2}?b.{0,2}?a", "bbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbbb", "b.{0,0}?b"]
     res = idx.search(qs)
     counts, off, first, tup = res.fetch()
-    assert res.summary["n_matches"] > 8 * (8 << 20) // 4                  # more than one staging block for each of the fetch threads
+    assert res.summary["n_matches"] > 16 * (8 << 20) // 4                 # more than one staging block for each of the fetch threads
     t = np.frombuffer(text, np.uint8)
     a_at = np.flatnonzero(t == ord("a")).astype(np.uint64)
     assert (res.positions(1) == a_at).all()                                # every 'a' of the text, in order
