@@ -83,7 +83,7 @@ def _random_queries(text, rng, nq, kmax=4, mmax=4, gapmax=60, gaplo=20):
 
 
 @pytest.mark.parametrize("name,seed", [("dna", 1), ("dna_skew", 2), ("zipf", 3), ("100a", 4), ("abab", 5)])
-def test_lazy_search_equals_oracle_and_fm_index_path(V, oracle, name, seed):
+def test_lazy_search_equals_oracle_and_fm_index_path(V, oracle, monkeypatch, name, seed):
     text = {"dna": dna_text(20000, 1).tobytes(), "dna_skew": dna_text(15000, 2, (0.7, 0.1, 0.1, 0.1)).tobytes(),
             "zipf": skewed_text(20000, 3).tobytes(), "100a": b"a" * 100, "abab": (b"ab" * 3000) + b"aab" * 500}[name]
     rng = np.random.default_rng(seed)
@@ -106,6 +106,13 @@ def test_lazy_search_equals_oracle_and_fm_index_path(V, oracle, name, seed):
         part = w.search(qs, max_matches=cap)
         for i in range(len(qs)):
             assert part.tuples(i).tolist() == res.tuples(i).tolist()[:cap], (cap, qs[i])
+    # one lane per query (the round-2 kernel) instead of one wavefront: same tuples
+    monkeypatch.setenv("VLG_WTSA_LANE_PER_QUERY", "1")
+    old = w.search(qs)
+    for x, y in zip(old.fetch(), res.fetch()):
+        assert (x == y).all()
+    assert [w.search(qs, max_matches=2).tuples(i).tolist() for i in range(len(qs))] == [res.tuples(i).tolist()[:2] for i in range(len(qs))]
+    monkeypatch.delenv("VLG_WTSA_LANE_PER_QUERY")
     # first positions only
     from vlg_matching_amd.index import Workspace
     ws = Workspace()

@@ -172,7 +172,14 @@ __global__ void __launch_bounds__(256) wtsa_ranges_kernel(WtsaView w, const uint
 // walks per match or failed alignment, whatever the lengths of its lists -- and it stops after max_matches matches.
 struct WQuery { uint32_t k, sub0; uint64_t end_len, out_first, out_tuple; };
 
-template <bool kEmit>
+// kWave: ONE WAVEFRONT owns a query.  All 64 lanes run the same pointer machine (same walks, same addresses), and whenever the
+// pointer of the query's SHORTEST list is set, the lanes look at the next 64 elements of that list at once -- one quantile walk each,
+// then two count_less walks per neighbouring list -- and the pointer skips to the first element that has a partner inside the gap
+// window on either side.  An element without one is in no tuple at all, so dropping it changes no least tuple and no restart
+// position (the argument of the window filter); what it removes is the query's sequential walk over every
+// fruitless alignment -- 3 k leaps per element of the shortest list, each two 30-level walks -- which is what a heavy query
+// without early matches used to cost (seconds on C3).  kWave false: one lane per query, 64 queries per wavefront.
+template <bool kEmit, bool kWave>
 __global__ void __launch_bounds__(64) wtsa_search_kernel(WtsaView w, const uint64_t* __restrict__ sp, const uint64_t* __restrict__ len,
                                                          const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi,
                                                          const WQuery* __restrict__ qs, uint32_t nq, uint32_t kmax, uint64_t max_matches,
@@ -181,7 +188,8 @@ __global__ void __launch_bounds__(64) wtsa_search_kernel(WtsaView w, const uint6
 {
     extern __shared__ uint32_t s_dyn[];                            // [2][kmax][64]: rank and value under every pointer, per lane
     const uint32_t lane = threadIdx.x;
-    const uint64_t qi = (uint64_t)blockIdx.x * 64 + lane;
+    const uint64_t qi = kWave ? (uint64_t)blockIdx.x : (uint64_t)blockIdx.x * 64 + lane;
+    const bool writer = !kWave || lane == 0;                      // kWave: every lane holds the same state, one of them reports it
     uint32_t* s_rank = s_dyn;
     uint32_t* s_val = s_dyn + (size_t)kmax * 64;
     WQuery Q{0, 0, 0, 0, 0};
@@ -189,6 +197,11 @@ __global__ void __launch_bounds__(64) wtsa_search_kernel(WtsaView w, const uint6
     const uint32_t k = Q.k;
     bool fin = qi >= nq || k == 0;
     for (uint32_t i = 0; i < k && !fin; ++i) fin = len[Q.sub0 + i] == 0;     // vlg_index.hpp:315-316: an empty range ends it at once
+    uint32_t piv = 0;                                              // kWave: the shortest list of the query
+    if (kWave && !fin && k >= 2) {
+        uint64_t best = ~0ull;
+        for (uint32_t i = 0; i < k; ++i) if (len[Q.sub0 + i] < best) { best = len[Q.sub0 + i]; piv = i; }
+    }
     uint64_t emitted = 0;
     unsigned long long sum = 0;
     // pending walk: level `lv`; op 0 = count_less(key) -> rank, then always the quantile of that rank
@@ -203,6 +216,35 @@ __global__ void __launch_bounds__(64) wtsa_search_kernel(WtsaView w, const uint6
             const uint64_t li = sp[s], ni = len[s];
             uint64_t r = s_rank[lv * 64 + lane];
             if (need_count) r = wtsa_walk<false>(w, li, ni, key);         // (every key lies beyond the element under the pointer: it only moves forward)
+            if (kWave && k >= 2 && lv == piv) {
+                // (wave-uniform from here to the ballot: every lane holds the same r)  64 elements of the shortest list at a time
+                while (r < ni) {
+                    const uint64_t cand = r + lane;
+                    bool ok = false;
+                    if (cand < ni) {
+                        const uint64_t v = wtsa_walk<true>(w, li, ni, cand);
+                        ok = true;
+                        if (piv > 0) {                                      // an element u of the list before with lo <= v - u <= hi
+                            const uint64_t l_ = lo[s], h_ = hi[s];
+                            if (v < l_) ok = false;
+                            else {
+                                const uint64_t a = v > h_ ? v - h_ : 0, b = v - l_;
+                                const uint64_t lp = sp[s - 1], np = len[s - 1];
+                                ok = wtsa_walk<false>(w, lp, np, b + 1) > wtsa_walk<false>(w, lp, np, a);
+                            }
+                        }
+                        if (ok && piv + 1 < k) {                            // an element x of the list behind with lo' <= x - v <= hi'
+                            const uint64_t l_ = lo[s + 1], h_ = hi[s + 1];
+                            const uint64_t a = v + l_ < v ? ~0ull : v + l_, b = v + h_ < v ? ~0ull : v + h_;
+                            const uint64_t ln = sp[s + 1], nn = len[s + 1];
+                            ok = a != ~0ull && (b == ~0ull ? nn : wtsa_walk<false>(w, ln, nn, b + 1)) > wtsa_walk<false>(w, ln, nn, a);
+                        }
+                    }
+                    const unsigned long long m = __ballot(ok);
+                    if (m) { r += (uint32_t)__ffsll((long long)m) - 1; break; }
+                    r += 64;
+                }
+            }
             if (r >= ni) fin = true;                                        // the list has run out: nothing more for this query
             else {
                 const uint64_t v = wtsa_walk<true>(w, li, ni, r);
@@ -225,8 +267,8 @@ __global__ void __launch_bounds__(64) wtsa_search_kernel(WtsaView w, const uint6
                     }
                     if (lv + 1 == k) {                                      // a match: report it, then pull the first pointer behind it
                         const uint64_t first = s_val[lane];
-                        sum += first;
-                        if (kEmit) {
+                        if (writer) sum += first;
+                        if (kEmit && writer) {
                             out_first[Q.out_first + emitted] = first;
                             if (out_tuples) {
                                 uint64_t* tp = out_tuples + Q.out_tuple + emitted * k;
@@ -250,10 +292,24 @@ __global__ void __launch_bounds__(64) wtsa_search_kernel(WtsaView w, const uint6
             }
         }
     }
-    if (!kEmit && qi < nq) counts[qi] = emitted;
+    if (qi < nq && writer && counts) counts[qi] = emitted;
     if (kEmit && checksum) {
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
         if (lane == 0 && sum) atomicAdd(checksum, sum);
+    }
+}
+
+// capped searches run once, every query writing into its own cap-sized stretch; this moves the matches together (query-major)
+__global__ void wtsa_compact_kernel(const WQuery* __restrict__ from, const uint64_t* __restrict__ to_first, const uint64_t* __restrict__ to_tuple,
+                                    const unsigned long long* __restrict__ counts, uint32_t nq, uint64_t cap, const uint64_t* __restrict__ t_first,
+                                    const uint64_t* __restrict__ t_tuples, uint64_t* __restrict__ out_first, uint64_t* __restrict__ out_tuples)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)nq * cap; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t qi = t / cap, m = t - qi * cap;
+        if (m >= counts[qi]) continue;
+        const WQuery Q = from[qi];
+        out_first[to_first[qi] + m] = t_first[Q.out_first + m];
+        if (out_tuples) for (uint32_t i = 0; i < Q.k; ++i) out_tuples[to_tuple[qi] + m * Q.k + i] = t_tuples[Q.out_tuple + m * Q.k + i];
     }
 }
 
@@ -512,12 +568,67 @@ extern "C" vlg_status vlg_wtsa_search_batch(const vlg_wtsa* x, const vlg_queries
         }
         const uint32_t kmax = std::max<uint32_t>(q->kmax, 1);
         const size_t lds = (size_t)2 * kmax * 64 * 4;
-        const uint32_t wgs = (uint32_t)((nq + 63) / 64);
+        // one wavefront per query (its shortest list is looked at 64 elements at a time), or the older one lane per query
+        const bool wave = [] { const char* e = getenv("VLG_WTSA_LANE_PER_QUERY"); return !(e && e[0] == '1'); }();
+        const uint32_t wgs = wave ? (uint32_t)nq : (uint32_t)((nq + 63) / 64);
         const WtsaView w = wtsa_view(x);
+        // A capped search whose matches fit a scratch buffer at cap per query runs ONCE (the uncapped one counts first, then emits)
+        const uint64_t per_query = max_matches * (1 + (ws->tuples ? (uint64_t)kmax : 0)) * 8;
+        if (wave && max_matches && max_matches <= (1u << 20) && nq * per_query <= (2ull << 30)) {
+            uint64_t* t_first = nullptr;
+            VLG_HIP_TRY(hipMalloc((void**)&t_first, nq * per_query + 2 * (nq + 1) * 8));
+            struct Free { void* p; ~Free() { (void)hipFree(p); } } free_tmp{t_first};
+            uint64_t* t_tuples = ws->tuples ? t_first + nq * max_matches : nullptr;
+            uint64_t* d_to_first = t_first + nq * per_query / 8;
+            uint64_t* d_to_tuple = d_to_first + nq + 1;
+            for (uint64_t i = 0; i < nq; ++i) { hq[i].out_first = i * max_matches; hq[i].out_tuple = i * max_matches * kmax; }
+            VLG_HIP_TRY(hipMemcpyAsync(d_q, hq.data(), nq * sizeof(WQuery), hipMemcpyHostToDevice, st));
+            {
+                Timed t(ws, KS_JOIN_CHAIN, 0);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<true, true>), dim3(wgs), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
+                                   (uint32_t)nq, kmax, max_matches, d_counts, t_first, t_tuples, d_chk);
+            }
+            VLG_HIP_TRY(hipGetLastError());
+            svec<unsigned long long> counts(nq);
+            unsigned long long chk = 0;
+            VLG_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, nq * 8, hipMemcpyDeviceToHost, st));
+            VLG_HIP_TRY(hipMemcpyAsync(&chk, d_chk, 8, hipMemcpyDeviceToHost, st));
+            VLG_HIP_TRY(hipStreamSynchronize(st));
+            svec<uint64_t> to_first(nq + 1), to_tuple(nq + 1);
+            uint64_t M = 0, TV = 0;
+            for (uint64_t i = 0; i < nq; ++i) {
+                to_first[i] = M; to_tuple[i] = TV;
+                M += counts[i]; TV += ws->tuples ? counts[i] * hq[i].k : 0;
+                res->counts[i] = counts[i];
+            }
+            piece.matches = M; piece.tuple_vals = TV;
+            if (M) {
+                VLG_HIP_TRY(result_alloc(&piece.d_first, M * 8, &piece.first_bytes));
+                if (TV) VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * 8, &piece.tuple_bytes));
+                VLG_HIP_TRY(hipMemcpyAsync(d_to_first, to_first.data(), nq * 8, hipMemcpyHostToDevice, st));
+                VLG_HIP_TRY(hipMemcpyAsync(d_to_tuple, to_tuple.data(), nq * 8, hipMemcpyHostToDevice, st));
+                Timed t(ws, KS_GATHER, 8ull * (M + TV));
+                hipLaunchKernelGGL(wtsa_compact_kernel, dim3(grid_for(nq * max_matches, 8192)), dim3(256), 0, st, d_q, d_to_first, d_to_tuple, d_counts,
+                                   (uint32_t)nq, max_matches, t_first, TV ? t_tuples : nullptr, static_cast<uint64_t*>(piece.d_first),
+                                   static_cast<uint64_t*>(piece.d_tuples));
+                VLG_HIP_TRY(hipGetLastError());
+            }
+            VLG_HIP_TRY(hipStreamSynchronize(st));
+            res->pieces.push_back(piece);
+            res->sum.n_matches = M;
+            res->sum.n_tuple_values = TV;
+            res->sum.checksum = chk;
+            res->sum.n_chunks = 1;
+            return VLG_OK;
+        }
         {
             Timed t(ws, KS_JOIN_CHAIN, 0);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<false>), dim3(wgs), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
-                               (uint32_t)nq, kmax, max_matches, d_counts, nullptr, nullptr, nullptr);
+            if (wave)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<false, true>), dim3(wgs), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
+                                   (uint32_t)nq, kmax, max_matches, d_counts, nullptr, nullptr, nullptr);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<false, false>), dim3(wgs), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
+                                   (uint32_t)nq, kmax, max_matches, d_counts, nullptr, nullptr, nullptr);
         }
         VLG_HIP_TRY(hipGetLastError());
         svec<unsigned long long> counts(nq);
@@ -535,8 +646,12 @@ extern "C" vlg_status vlg_wtsa_search_batch(const vlg_wtsa* x, const vlg_queries
             if (TV) VLG_HIP_TRY(result_alloc(&piece.d_tuples, TV * 8, &piece.tuple_bytes));
             VLG_HIP_TRY(hipMemcpyAsync(d_q, hq.data(), nq * sizeof(WQuery), hipMemcpyHostToDevice, st));
             Timed t(ws, KS_GATHER, 8ull * (M + TV));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<true>), dim3(wgs), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
-                               (uint32_t)nq, kmax, max_matches, d_counts, static_cast<uint64_t*>(piece.d_first), static_cast<uint64_t*>(piece.d_tuples), d_chk);
+            if (wave)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<true, true>), dim3(wgs), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
+                                   (uint32_t)nq, kmax, max_matches, d_counts, static_cast<uint64_t*>(piece.d_first), static_cast<uint64_t*>(piece.d_tuples), d_chk);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(wtsa_search_kernel<true, false>), dim3(wgs), dim3(64), lds, st, w, d_sp, d_len, d_lo, d_hi, d_q,
+                                   (uint32_t)nq, kmax, max_matches, d_counts, static_cast<uint64_t*>(piece.d_first), static_cast<uint64_t*>(piece.d_tuples), d_chk);
             VLG_HIP_TRY(hipGetLastError());
         }
         unsigned long long chk = 0;
