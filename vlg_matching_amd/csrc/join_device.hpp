@@ -102,16 +102,23 @@ inline RungLayout rung_layout(uint64_t total)
     return L;
 }
 
+// (F: the fences of the same array, written on the way when the ladder has a level of blocks of 64 -- it is that level -- or null)
 template <typename pos_t>
-__global__ void rung_build_kernel(const pos_t* __restrict__ P, uint64_t total, pos_t* __restrict__ R, const uint64_t* __restrict__ off, uint32_t levels)
+__global__ void rung_build_kernel(const pos_t* __restrict__ P, uint64_t total, pos_t* __restrict__ R, const uint64_t* __restrict__ off, uint32_t levels,
+                                  pos_t* __restrict__ F)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total >> kRungShift); i += (uint64_t)gridDim.x * blockDim.x) {
         const pos_t v = P[kRungFan * i + kRungFan - 1];
         R[off[1] + i] = v;
         uint64_t k = i;
-        for (uint32_t j = 2; j <= levels && (k & (kRungFan - 1)) == kRungFan - 1; ++j) { k >>= kRungShift; R[off[j] + k] = v; }
+        for (uint32_t j = 2; j <= levels && (k & (kRungFan - 1)) == kRungFan - 1; ++j) {
+            k >>= kRungShift;
+            R[off[j] + k] = v;
+            if (F && kRungShift * j == 6) F[k] = v;
+        }
     }
 }
+constexpr bool kRungsHoldFences = 6 % kRungShift == 0 && kRungShift < 6;       // some level has blocks of 64
 
 template <typename pos_t> struct alignas(4 * sizeof(pos_t)) RungQuad { pos_t v[4]; };
 

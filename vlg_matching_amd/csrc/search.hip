@@ -885,12 +885,10 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         const uint64_t entries = cover / 64 + 2;
         if (!A.failed && A.size - A.used > entries * sizeof(pos_t) + 4096) {
             pos_t* F = A.take<pos_t>(entries);
-            if (gacc >= 64)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(fence_build_kernel<pos_t>), dim3(grid_for(gacc / 64, 8192)), dim3(256), 0, st, P_out, (uint64_t)0, gacc / 64, F);
-            VLG_HIP_TRY(hipGetLastError());
             ws->fences = F;
         }
         // the ladder for the pivot filter (a third of the lists' size): only when the window filter will run on these lists
+        bool fences_written = false;
         if (ws->fences && ws->want_rungs && gacc >= 64) {
             const RungLayout rl = rung_layout(gacc);
             if (A.size - A.used > rl.entries * sizeof(pos_t) + 8192) {
@@ -898,15 +896,21 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
                 uint64_t* d_off = A.take<uint64_t>(kMaxRungs + 1);
                 svec<uint64_t> h_off(rl.off, rl.off + kMaxRungs + 1);
                 VLG_HIP_TRY(hipMemcpyAsync(d_off, h_off.data(), (kMaxRungs + 1) * 8, hipMemcpyHostToDevice, st));
+                fences_written = kRungsHoldFences && rl.levels >= 6 / kRungShift;      // the fences are one of its levels: written on the way
                 {
                     Timed t(ws, KS_FILTER_LADDER, gacc * sizeof(pos_t));
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(rung_build_kernel<pos_t>), dim3(grid_for(gacc >> kRungShift, 16384)), dim3(256), 0, st, P_out, gacc, R, d_off,
-                                       rl.levels);
+                                       rl.levels, fences_written ? static_cast<pos_t*>(ws->fences) : (pos_t*)nullptr);
                 }
                 VLG_HIP_TRY(hipGetLastError());
                 ws->rungs = R;
                 ws->rung_off = d_off;
             }
+        }
+        if (ws->fences && !fences_written && gacc >= 64) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fence_build_kernel<pos_t>), dim3(grid_for(gacc / 64, 8192)), dim3(256), 0, st, P_out, (uint64_t)0, gacc / 64,
+                               static_cast<pos_t*>(ws->fences));
+            VLG_HIP_TRY(hipGetLastError());
         }
     }
     res->sum.located_occurrences += acc;
