@@ -92,7 +92,8 @@ def load_pmc():
 CLASSES = {
     "backward_search": ("backward_search_kernel", ["backward_search_kernel"], "32 B per wavelet-tree level of every rank (SURVEY 8d K2)"),
     "expand": ("expand_kernel", [], ""),
-    "locate": ("sweep_step_kernel", ["sweep_step_kernel", "locate_kernel"],      # (locate_kernel<.., kTail> finishes the stragglers)
+    "locate": ("sweep_step_kernel (rounds 1..; round 0 is sweep_first_kernel, the stragglers are finished by locate_kernel<.., kTail>: one launch each)",
+               ["sweep_step_kernel", "sweep_first_kernel", "locate_kernel"],
                "32 B per tree level actually walked + one SA sample per occurrence (SURVEY 8d K3)"),
     "locate_partition": ("rocprim radix_sort_pairs (u16 symbol key, u64 element): one 5-bit pass per round",
                          ["rocprim:radix_sort_onesweep<unsigned_short,unsigned_long>"],
@@ -575,7 +576,8 @@ def main():
                 tr = rd + wr
             class_ms = st["total_ms"] / args.steps
             traffic_per_launch = tr / (st["launches"] / args.steps) if tr is not None and st["launches"] else None
-            return {"bound": "hbm", "kernel": disp, "kernel_class": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            return {"bound": "hbm", "kernel": disp, "kernel_class": name, "kernels_in_class": members,   # (avg_launch_ms averages over the launches of all of them)
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic_per_launch,
                     "traffic_detail": None if tr is None else {
                         "read_raw_per_step": rd, "read_if_all_wide_streaming_per_step": 2 * rd, "write_per_step": wr,
