@@ -60,8 +60,9 @@ struct vlg_workspace {
     uint64_t filter_stream_min = 1ull << 16;   // ... and so are those below this that would be filtered by streaming sweeps
     bool filter_pivot = true;   // filter from the shortest list of a query outwards when it is much shorter than the rest
     uint64_t filter_group_bytes = 0;    // cap of the filter state of one group of queries (0: a third of the join budget)
-    uint64_t filter_pivot_ratio = 6;    // ... i.e. when all lists together are at least this many times longer (C3, ms per batch: 24 -> 262,
-                                        // 12 -> 251, 6 -> 246.6, 4 -> 246.4, <= 3 -> 248: the probes win wherever a list is clearly the shortest)
+    uint64_t filter_pivot_ratio = 3;    // ... i.e. when all lists together are at least this many times longer (C3, ms per batch, with the
+                                        // ladder: 8 -> 173.2, 6 -> 171.1, 4 -> 169.0, 3 -> 168.9, 2 -> 168.8; with bracket + bisection it was
+                                        // 24 -> 262, 12 -> 251, 6 -> 246.6, 4 -> 246.4, <= 3 -> 248): the descents win wherever a list is the shortest
     void* fences = nullptr;     // F[g] = P[64 g + 63] over the lists of the super-chunk in work (join_device.hpp), or null
     void* rungs = nullptr;      // the 4-ary ladder over the same lists (join_device.hpp), or null
     uint64_t* rung_off = nullptr;   // device: first entry of every level
