@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--bv", choices=["plain", "rrr"], default=None, help="wavelet-tree bit-vectors (default: rrr for C5, else plain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling region")
+    ap.add_argument("--strong-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the strong-scaling region may take before the weak-scaling line is printed without it")
     ap.add_argument("--strong-sharding", choices=["lists", "affinity", "work"], default="lists",
                     help="strong-scaling region: 'lists' = collective search (distinct lists sharded for locate + sort, sorted lists "
                          "all-gathered, queries sharded for the joins); 'affinity' / 'work' = only the query loop is sharded")
@@ -481,78 +483,85 @@ def main():
         del pin_first
 
     # ---- strong scaling: THE batch (rank 0's) cut by work, every rank searches its slice ------------------------------------
-    strong = None
-    if dist is not None and not args.no_strong and args.strong_sharding == "lists":
-        # collective search: every rank gets THE batch (rank 0's), locates + sorts its share of the distinct lists, receives the other
-        # shares (RCCL all-gather of the sorted lists; gloo rehearsals move them through the host), joins its piece of the queries
-        box = [queries if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        qs = Queries(box[0])
-        comm_x = None
-        if args.backend == "nccl":
-            comm_x = vdist.Comm.from_torch_dist(dist)
-            ws.set_comm(comm_x)
-        else:
-            ws.set_exchange(world, rank, vdist.host_exchange(dist))
-        idx.search(qs, workspace=ws)                           # warm-up
-        ws.profile(True)
-        dt_s, my_dt_s, r_s = timed(lambda: idx.search(qs, workspace=ws), args.steps)
-        x_stats = ws.kernel_stats()
-        ws.profile(False)
-        ss = r_s.summary
-        tq_all = ss["n_queries"]
-        owned = r_s.owned_queries()
-        n_own = sum(b - a for a, b in owned) if owned else tq_all
-        tq, tocc, tm = reduce_sum([n_own, ss["located_occurrences"], ss["n_matches"]])
-        chk = vdist.reduce_checksum(ss["checksum"], dist, dev)
-        pr = gather_per_rank([my_dt_s / args.steps * 1e3, n_own, ss["located_occurrences"], x_stats["exchange"]["total_ms"] / args.steps,
-                              x_stats["exchange"]["algorithmic_bytes"] / args.steps])
-        strong = {"scaling": "strong", "value": tq * args.steps / dt_s, "unit": "queries/s", "ms_per_step": dt_s / args.steps * 1e3,
-                  "queries": tq, "matches": tm, "checksum": chk, "located_occ_per_step_all_ranks": tocc,
-                  "per_rank": [{"ms_per_step": p[0], "queries": int(p[1]), "located_occ": int(p[2]), "exchange_ms": p[3],
-                                "exchange_bytes_received": int(p[4])} for p in pr],
-                  "sharding": "lists",
-                  "exchange": "vlg_comm_allgatherv (RCCL)" if comm_x is not None else "host (gloo rehearsal)",
-                  "note": "the 1-GPU batch answered by all ranks together: every distinct occurrence list is located and sorted by exactly one "
-                          "rank (located_occ summed over ranks = the 1-GPU figure), the sorted lists are all-gathered, every rank filters and "
-                          "joins a contiguous piece of the queries of equal join work"}
-        ws.set_comm(None)
-        if comm_x is not None:
-            comm_x.close()
-        if rank == 0:
-            assert tq == s["n_queries"] and tm == s["n_matches"] and chk == s["checksum"] and tocc == s["located_occurrences"], (tq, tm, chk, tocc, s)
-    elif dist is not None and not args.no_strong:
-        if rank == 0:
-            if args.strong_sharding == "affinity":             # queries that share their longest list stay together
-                l_, r_, q_all = idx.intervals(queries)
-                sets = vdist.shard_by_affinity(l_, r_, q_all.subpattern_range(), world)
-                slices = [[queries[i] for i in st_] for st_ in sets]
+    def strong_region():
+        strong = None
+        fault = os.environ.get("VLG_BENCH_STRONG_FAULT", "")       # rehearsal of the watchdog: the last rank fails or stalls here
+        if fault and rank == world - 1:
+            if fault == "raise":
+                raise RuntimeError("VLG_BENCH_STRONG_FAULT=raise")
+            time.sleep(1e6)
+        if dist is not None and not args.no_strong and args.strong_sharding == "lists":
+            # collective search: every rank gets THE batch (rank 0's), locates + sorts its share of the distinct lists, receives the other
+            # shares (RCCL all-gather of the sorted lists; gloo rehearsals move them through the host), joins its piece of the queries
+            box = [queries if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            qs = Queries(box[0])
+            comm_x = None
+            if args.backend == "nccl":
+                comm_x = vdist.Comm.from_torch_dist(dist)
+                ws.set_comm(comm_x)
             else:
-                w = idx.query_weights(queries)                 # sum of SA-interval sizes per query: one backward-search pass
-                slices = [queries[b:e] for b, e in vdist.shard_by_work(w, world)]
-        else:
-            slices = None
-        mine = [None]
-        dist.scatter_object_list(mine, slices, src=0)
-        qs = Queries(mine[0])
-        idx.search(qs, workspace=ws)                           # warm-up of the slice's shapes
-        dt_s, my_dt_s, r_s = timed(lambda: idx.search(qs, workspace=ws), args.steps)
-        ss = r_s.summary
-        tq, tocc, tm, tlog = reduce_sum([ss["n_queries"], ss["located_occurrences"], ss["n_matches"], ss["logical_occurrences"]])
-        chk = vdist.reduce_checksum(ss["checksum"], dist, dev)
-        pr = gather_per_rank([my_dt_s / args.steps * 1e3, ss["n_queries"], ss["located_occurrences"], ss["logical_occurrences"]])
-        strong = {"scaling": "strong", "value": tq * args.steps / dt_s, "unit": "queries/s", "ms_per_step": dt_s / args.steps * 1e3,
-                  "queries": tq, "matches": tm, "checksum": chk, "located_occ_per_step_all_ranks": tocc, "logical_occ_per_step": tlog,
-                  "per_rank": [{"ms_per_step": p[0], "queries": int(p[1]), "located_occ": int(p[2]), "logical_occ": int(p[3])} for p in pr],
-                  "sharding": args.strong_sharding,
-                  "note": "the 1-GPU batch sharded; each rank locates the distinct intervals of its own queries, so a list that queries "
-                          "on several ranks share is located once per such rank (located_occ summed over ranks >= the 1-GPU figure). "
-                          "'affinity' keeps the queries that share their longest list on one rank (vlg_matching_amd.dist.shard_by_affinity); "
-                          "'work' cuts contiguous slices of equal sum of SA-interval sizes"}
-        if rank == 0:
-            # same batch as the weak region of rank 0: totals must agree
-            assert tq == s["n_queries"] and tm == s["n_matches"] and chk == s["checksum"], (tq, tm, chk, s)
+                ws.set_exchange(world, rank, vdist.host_exchange(dist))
+            idx.search(qs, workspace=ws)                           # warm-up
+            ws.profile(True)
+            dt_s, my_dt_s, r_s = timed(lambda: idx.search(qs, workspace=ws), args.steps)
+            x_stats = ws.kernel_stats()
+            ws.profile(False)
+            ss = r_s.summary
+            tq_all = ss["n_queries"]
+            owned = r_s.owned_queries()
+            n_own = sum(b - a for a, b in owned) if owned else tq_all
+            tq, tocc, tm = reduce_sum([n_own, ss["located_occurrences"], ss["n_matches"]])
+            chk = vdist.reduce_checksum(ss["checksum"], dist, dev)
+            pr = gather_per_rank([my_dt_s / args.steps * 1e3, n_own, ss["located_occurrences"], x_stats["exchange"]["total_ms"] / args.steps,
+                                  x_stats["exchange"]["algorithmic_bytes"] / args.steps])
+            strong = {"scaling": "strong", "value": tq * args.steps / dt_s, "unit": "queries/s", "ms_per_step": dt_s / args.steps * 1e3,
+                      "queries": tq, "matches": tm, "checksum": chk, "located_occ_per_step_all_ranks": tocc,
+                      "per_rank": [{"ms_per_step": p[0], "queries": int(p[1]), "located_occ": int(p[2]), "exchange_ms": p[3],
+                                    "exchange_bytes_received": int(p[4])} for p in pr],
+                      "sharding": "lists",
+                      "exchange": "vlg_comm_allgatherv (RCCL)" if comm_x is not None else "host (gloo rehearsal)",
+                      "note": "the 1-GPU batch answered by all ranks together: every distinct occurrence list is located and sorted by exactly one "
+                              "rank (located_occ summed over ranks = the 1-GPU figure), the sorted lists are all-gathered, every rank filters and "
+                              "joins a contiguous piece of the queries of equal join work"}
+            ws.set_comm(None)
+            if comm_x is not None:
+                comm_x.close()
+            if rank == 0 and not (tq == s["n_queries"] and tm == s["n_matches"] and chk == s["checksum"] and tocc == s["located_occurrences"]):
+                raise AssertionError("collective search disagrees with the 1-GPU batch: %r vs %r" % ((tq, tm, chk, tocc), s))
+        elif dist is not None and not args.no_strong:
+            if rank == 0:
+                if args.strong_sharding == "affinity":             # queries that share their longest list stay together
+                    l_, r_, q_all = idx.intervals(queries)
+                    sets = vdist.shard_by_affinity(l_, r_, q_all.subpattern_range(), world)
+                    slices = [[queries[i] for i in st_] for st_ in sets]
+                else:
+                    w = idx.query_weights(queries)                 # sum of SA-interval sizes per query: one backward-search pass
+                    slices = [queries[b:e] for b, e in vdist.shard_by_work(w, world)]
+            else:
+                slices = None
+            mine = [None]
+            dist.scatter_object_list(mine, slices, src=0)
+            qs = Queries(mine[0])
+            idx.search(qs, workspace=ws)                           # warm-up of the slice's shapes
+            dt_s, my_dt_s, r_s = timed(lambda: idx.search(qs, workspace=ws), args.steps)
+            ss = r_s.summary
+            tq, tocc, tm, tlog = reduce_sum([ss["n_queries"], ss["located_occurrences"], ss["n_matches"], ss["logical_occurrences"]])
+            chk = vdist.reduce_checksum(ss["checksum"], dist, dev)
+            pr = gather_per_rank([my_dt_s / args.steps * 1e3, ss["n_queries"], ss["located_occurrences"], ss["logical_occurrences"]])
+            strong = {"scaling": "strong", "value": tq * args.steps / dt_s, "unit": "queries/s", "ms_per_step": dt_s / args.steps * 1e3,
+                      "queries": tq, "matches": tm, "checksum": chk, "located_occ_per_step_all_ranks": tocc, "logical_occ_per_step": tlog,
+                      "per_rank": [{"ms_per_step": p[0], "queries": int(p[1]), "located_occ": int(p[2]), "logical_occ": int(p[3])} for p in pr],
+                      "sharding": args.strong_sharding,
+                      "note": "the 1-GPU batch sharded; each rank locates the distinct intervals of its own queries, so a list that queries "
+                              "on several ranks share is located once per such rank (located_occ summed over ranks >= the 1-GPU figure). "
+                              "'affinity' keeps the queries that share their longest list on one rank (vlg_matching_amd.dist.shard_by_affinity); "
+                              "'work' cuts contiguous slices of equal sum of SA-interval sizes"}
+            if rank == 0 and not (tq == s["n_queries"] and tm == s["n_matches"] and chk == s["checksum"]):   # same batch as rank 0's weak region
+                raise AssertionError("sharded batch disagrees with the 1-GPU batch: %r vs %r" % ((tq, tm, chk), s))
+        return strong
 
+    out = None
     if rank == 0:
         pmc = load_pmc()
         step_ms = dt / args.steps * 1e3
@@ -630,7 +639,7 @@ def main():
             "per_rank": [{"ms_per_step": p[0], "located_occ": int(p[1]), "matches": int(p[2])} for p in per_rank],
             "e2e_ms_per_step": e2e["ms_per_step"] if e2e else None,
             "e2e": e2e,
-            "strong_scaling": strong,
+            "strong_scaling": None,
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kstats.items()},
             "kernels_ms_sum_per_step": sum(v["total_ms"] for v in kstats.values()) / args.steps,
             "roofline": roof(dominant),                                  # the dominant kernel class of the step
@@ -645,6 +654,42 @@ def main():
             sas = cpu_sasearch(host_text, queries, n_logical / max(n_queries, 1))
             if sas is not None:
                 out["cpu_baseline"]["sasearch"] = sas
+
+    # The strong region is the only part of an N-GPU run that exchanges data between the ranks (RCCL all-gather of the sorted lists).
+    # Whatever happens in it -- an exception on one rank, a collective that never completes -- the weak-scaling line measured above
+    # is still printed: every rank runs a watchdog; when it fires, rank 0 prints the line with the error in `strong_scaling` and
+    # every rank leaves.  The watchdog stays armed through the agreement all-reduce behind the region, so a rank that failed
+    # alone (the others then wait inside a collective) ends all of them.
+    if dist is not None and not args.no_strong:
+        import threading
+        finished = threading.Event()
+        failure = [None]
+
+        def watchdog():
+            if finished.wait(args.strong_timeout):
+                return
+            msg = failure[0] or ("strong-scaling region did not finish within %d s" % args.strong_timeout)
+            log("rank %d: %s -- leaving; the weak-scaling line stands" % (rank, msg))
+            if rank == 0:
+                out["strong_scaling"] = {"error": msg}
+                print(json.dumps(out), flush=True)
+            sys.stdout.flush()
+            os._exit(0)                                            # (the error is in the line and on stderr; a non-zero code would make the launcher drop the line)
+        threading.Thread(target=watchdog, daemon=True).start()
+        strong = None
+        try:
+            strong = strong_region()
+        except Exception as e:                                     # noqa: BLE001 -- reported in the line
+            import traceback
+            traceback.print_exc()
+            failure[0] = "rank %d: %s: %s" % (rank, type(e).__name__, e)
+        ok = torch.tensor([0 if failure[0] else 1], dtype=torch.int64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                  # (hangs if another rank is stuck: the watchdog ends that)
+        finished.set()
+        if rank == 0:
+            out["strong_scaling"] = strong if int(ok.item()) == 1 and strong is not None else {
+                "error": failure[0] or "a rank failed inside the strong-scaling region (see its stderr)"}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
