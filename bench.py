@@ -250,6 +250,10 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink text and batch (development only)")
     ap.add_argument("--workspace-gb", type=float, default=160.0)
     ap.add_argument("--bv", choices=["plain", "rrr"], default=None, help="wavelet-tree bit-vectors (default: rrr for C5, else plain)")
+    ap.add_argument("--sa-dens", type=int, default=32,
+                    help="suffix-array sample density t_dens of csa_wt<> (default 32 = the benchmark's index; 1 keeps the whole suffix "
+                         "array resident in HBM: 4 B x n, no LF walk in locate). Not the headline config unless 32.")
+    ap.add_argument("--no-dense-sa", action="store_true", help="N = 1: skip the secondary run on the index that keeps the whole suffix array")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling region")
     ap.add_argument("--strong-timeout", type=float, default=240.0,
@@ -325,6 +329,11 @@ def main():
         del d_text
         torch.cuda.empty_cache()
         log("index built on device in %.2f s: %s" % (t_build, idx.info()))
+        if args.sa_dens != 32:
+            t0 = time.perf_counter()
+            idx = idx.resample(text_order=False, dens=args.sa_dens)      # csa_wt<wt_huff<>, sa_dens, .> over the same BWT
+            torch.cuda.synchronize()
+            log("resampled in SA order with density %d in %.2f s: %s" % (args.sa_dens, time.perf_counter() - t0, idx.info()))
         if (args.bv or ("rrr" if args.config == "C5" else "plain")) == "rrr":
             t0 = time.perf_counter()
             plain_idx, idx = idx, idx.compress()
@@ -482,6 +491,32 @@ def main():
                                   "parsed and searched (last fetch inside the clock)" % args.steps)
         del pin_first
 
+    # ---- the same batch on an index that keeps the whole suffix array in HBM (t_dens = 1: 4 B x n more; what 288 GB afford) ----------
+    #      Reported beside the metric, never as the metric: BASELINE's index is csa_wt<wt_huff<>, 32, 64>.
+    dense = None
+    if world == 1 and args.sa_dens == 32 and not args.no_dense_sa and info["n"] <= (1 << 32):
+        t0 = time.perf_counter()
+        idx_d = idx.resample(text_order=False, dens=1)
+        torch.cuda.synchronize()
+        t_rs = time.perf_counter() - t0
+        idx_d.search(q, workspace=ws)                          # warm-up
+        ws.profile(True)
+        dt_d, _, r_d = timed(lambda: idx_d.search(q, workspace=ws), args.steps)
+        ks_d = ws.kernel_stats()
+        ws.profile(False)
+        sd = r_d.summary
+        assert sd["checksum"] == s["checksum"] and sd["n_matches"] == s["n_matches"] and sd["located_occurrences"] == s["located_occurrences"]
+        assert sd["lf_steps"] == 0
+        dense = {"ms_per_step": dt_d / args.steps * 1e3, "value": s["n_queries"] * args.steps / dt_d, "unit": "queries/s",
+                 "located_occ_per_sec": sd["located_occurrences"] * args.steps / dt_d,
+                 "index_hbm_bytes": idx_d.info()["hbm_bytes"], "resample_s": t_rs,
+                 "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in ks_d.items() if v["total_ms"] > 0},
+                 "what": "NOT the metric: the same batch, same matches and checksum, on csa_wt<wt_huff<>, 1, .> made by "
+                         "vlg_index_resample(SA order, 1) -- every suffix-array value is a sample, locate copies SA intervals "
+                         "(sa_dense_copy_kernel), no LF walk, no trails, no records"}
+        del idx_d, r_d
+        torch.cuda.empty_cache()
+
     # ---- strong scaling: THE batch (rank 0's) cut by work, every rank searches its slice ------------------------------------
     def strong_region():
         strong = None
@@ -617,9 +652,10 @@ def main():
             # text positions are 32-bit inside the kernels up to n = 2^32 + 1 (C4: 33-bit SA indices, 32-bit positions); u64 at the boundary
             "dtype": "u32" if info["n"] <= (1 << 32) + 1 and os.environ.get("VLG_FORCE_POS64", "0") != "1" else "u64",
             "data": "synthetic",
-            "config": {"workload": "%s%s: %s text n=%d (seed %d), %d queries/GPU x k=%d, m=%d, gap .{%d,%d}?, t_dens=32"
+            "config": {"workload": "%s%s: %s text n=%d (seed %d), %d queries/GPU x k=%d, m=%d, gap .{%d,%d}?, t_dens=%d%s"
                                    % (args.config, "" if args.scale == 1.0 else " x%g" % args.scale, cfg["kind"], cfg["n"],
-                                      cfg["seed"], cfg["nq"], cfg["k"], cfg["m"], cfg["gap"][0], cfg["gap"][1]),
+                                      cfg["seed"], cfg["nq"], cfg["k"], cfg["m"], cfg["gap"][0], cfg["gap"][1], args.sa_dens,
+                                      "" if args.sa_dens == 32 else " (NOT the benchmark's index: --sa-dens)"),
                        "bit_vectors": "rrr_vector<63>" if info["bv_kind"] else "plain (256-bit super-blocks)",
                        "sigma": info["sigma"], "mean_code_len_bits": info["wt_bits"] / info["n"],
                        "index_hbm_bytes": info["hbm_bytes"],
@@ -639,6 +675,7 @@ def main():
             "per_rank": [{"ms_per_step": p[0], "located_occ": int(p[1]), "matches": int(p[2])} for p in per_rank],
             "e2e_ms_per_step": e2e["ms_per_step"] if e2e else None,
             "e2e": e2e,
+            "hbm_resident_sa": dense,
             "strong_scaling": None,
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kstats.items()},
             "kernels_ms_sum_per_step": sum(v["total_ms"] for v in kstats.values()) / args.steps,

@@ -1215,6 +1215,55 @@ def test_text_order_sa_sampling(torch_cuda, V, oracle, name, dens):
     assert (r2.counts == ref.counts).all() and r2.summary["checksum"] == ref.summary["checksum"]
 
 
+@pytest.mark.parametrize("name", ["dna_50k", "zipf40", "100a", "abracadabra", "dna_skew"])
+def test_dense_suffix_array_index(torch_cuda, V, oracle, monkeypatch, name):
+    """csa_wt<wt_huff<>, 1, .>: the whole suffix array resident in HBM (vlg_index_resample(SA order, 1)).  Its samples
+    ARE the suffix array, locate copies SA intervals (sa_dense_copy_kernel: zero LF steps, no trails, no records), and every search
+    mode -- the sweep's fast path, the lane-per-occurrence kernel, narrow and forced-wide positions -- returns the tuples of the
+    oracle and the checksum of the benchmark's t_dens = 32 index (csa_wt.hpp:335-348 with a sample at every index)."""
+    torch = torch_cuda
+    from vlg_matching_amd.index import Workspace
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    sa = oracle.suffix_array(np.frombuffer(text + bytes(1), np.uint8)).astype(np.int64)
+    base = V.VlgIndex.build(text)
+    rng = np.random.default_rng(11)
+    qs = random_queries(text, rng, 150, kmax=4, mmax=4)
+    want = [o.search(q).tolist() for q in qs]
+    ref = base.search(qs)
+    for src in (base, base.compress()):
+        idx = src.resample(text_order=False, dens=1)
+        info = idx.info()
+        assert info["sampling"] == 0 and info["sa_sample_dens"] == 1 and info["n_samples"] == len(sa)
+        if src is base:                                          # (an rrr index does not export its parts)
+            assert idx.export_parts()["samples"][: len(sa)].astype(np.int64).tolist() == sa.tolist()
+        d_i = dev_u64(torch, np.arange(len(sa), dtype=np.uint64))
+        d_o = torch.zeros_like(d_i)
+        V.capi.check(V.lib().vlg_sa_batch(idx._h, d_i.data_ptr(), d_o.data_ptr(), len(sa), None))
+        torch.cuda.synchronize()
+        assert (host_u64(d_o).astype(np.int64) == sa).all()
+        for opts in ({"sweep_min": 1}, {"sweep_min": 1, "dedup": 0}, {"sweep_min": 1 << 30}, {"sweep_min": 1, "trail": 0}):
+            ws = Workspace()
+            for k_, v_ in opts.items():
+                ws.set_option(k_, v_)
+            res = idx.search(qs, workspace=ws)
+            for i in range(len(qs)):
+                assert res.tuples(i).tolist() == want[i], (qs[i], opts)
+            assert res.summary["checksum"] == ref.summary["checksum"] and res.summary["n_matches"] == ref.summary["n_matches"]
+            assert res.summary["lf_steps"] == 0, opts
+    # built with density 1 right away, with 64-bit samples and wide SA indices (=1: 64-bit positions, =2: 32-bit positions)
+    for force in ("1", "2"):
+        monkeypatch.setenv("VLG_FORCE_POS64", force)
+        wide = V.VlgIndex.build(text, dens=1)
+        assert wide.info()["pos_bytes"] == 8 and wide.info()["sa_sample_dens"] == 1
+        ws = Workspace()
+        ws.set_option("sweep_min", 1)
+        res = wide.search(qs, workspace=ws)
+        for i in range(len(qs)):
+            assert res.tuples(i).tolist() == want[i], (qs[i], force)
+        assert res.summary["checksum"] == ref.summary["checksum"] and res.summary["lf_steps"] == 0
+
+
 def _int_texts():
     rng = np.random.default_rng(31)
     return {

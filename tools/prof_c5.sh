@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_c5
 rm -rf $O; mkdir -p $O
 cd $R
-B="python3 bench.py --config C5 --no-cpu-baseline --no-e2e --no-strong"
+B="python3 bench.py --config C5 --no-cpu-baseline --no-e2e --no-dense-sa --no-strong"
 date +"%T start" >> $O/log
 $B --steps 2 --warmup 1 > $O/bench_plain.json 2>$O/bench_plain.err || exit 1
 date +"%T plain done" >> $O/log

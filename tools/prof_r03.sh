@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03
 rm -rf $O; mkdir -p $O
 cd $R
-B="python3 bench.py --no-cpu-baseline --no-e2e"
+B="python3 bench.py --no-cpu-baseline --no-e2e --no-dense-sa"
 step() { date +"%T $1" >> $O/log; }
 step start
 python3 bench.py > $O/bench_C3_default.json 2> $O/bench_C3_default.err || exit 1
@@ -25,15 +25,15 @@ for f in $(find /tmp/r03_write -name "*counter_collection.csv"); do cp $f $O/pmc
 step "WRITE_SIZE pass"
 python3 bench.py --config C5 --steps 3 --warmup 1 > $O/bench_C5.json 2> $O/bench_C5.err || exit 1
 step "C5 line"
-python3 bench.py --config C4 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > $O/bench_C4.json 2> $O/bench_C4.err || exit 1
+python3 bench.py --config C4 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-dense-sa > $O/bench_C4.json 2> $O/bench_C4.err || exit 1
 step "C4 line"
 python3 bench.py --config C2 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_C2.json 2> $O/bench_C2.err || exit 1
 step "C2 line"
-python3 bench.py --gpus 1 --dist-at-1 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > $O/bench_C3_one_rank_rccl.json 2> $O/bench_C3_one_rank_rccl.err || exit 1
+python3 bench.py --gpus 1 --dist-at-1 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-dense-sa > $O/bench_C3_one_rank_rccl.json 2> $O/bench_C3_one_rank_rccl.err || exit 1
 step "one-rank RCCL line"
-python3 bench.py --gpus 2 --single-device --backend gloo --scale 0.25 --workspace-gb 60 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > $O/rehearse_2ranks_one_device_C3x0.25.json 2> $O/rehearse_2.err || exit 1
+python3 bench.py --gpus 2 --single-device --backend gloo --scale 0.25 --workspace-gb 60 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-dense-sa > $O/rehearse_2ranks_one_device_C3x0.25.json 2> $O/rehearse_2.err || exit 1
 step "two-rank rehearsal"
-python3 bench.py --gpus 4 --single-device --backend gloo --scale 0.25 --workspace-gb 40 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > $O/rehearse_4ranks_one_device_C3x0.25.json 2> $O/rehearse_4.err || exit 1
+python3 bench.py --gpus 4 --single-device --backend gloo --scale 0.25 --workspace-gb 40 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-dense-sa > $O/rehearse_4ranks_one_device_C3x0.25.json 2> $O/rehearse_4.err || exit 1
 step "four-rank rehearsal"
 bash tools/prof_sq.sh C3 sq sq2 tcp
 for P in sq sq2 tcp; do cp gpurun_out/prof_sq_C3/$P.txt $O/pmc_${P}_bench_C3.txt; done

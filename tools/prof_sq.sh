@@ -9,7 +9,7 @@ PASSES=${@:-sq ta}
 O=$R/gpurun_out/prof_sq_$C
 mkdir -p $O
 cd $R
-B="python3 bench.py --config $C --no-cpu-baseline --no-e2e --no-strong"
+B="python3 bench.py --config $C --no-cpu-baseline --no-e2e --no-dense-sa --no-strong"
 for P in $PASSES; do
   case $P in
     sq)  CTR="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY";;

@@ -606,6 +606,35 @@ __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t
     }
 }
 
+// The suffix array itself resident in HBM (SA-order sampling with density 1: csa_wt<wt_huff<>, 1, .>, 4 B x n -- 4.3 GB for a 1 GiB text,
+// what 288 GB of HBM afford and the reference's CPU index does not): locate is a copy of the SA intervals, csa[i] = sample[i]
+// (csa_wt.hpp:335-348 with zero LF steps).  Same list lookup as sweep_init_kernel; reads and writes are coalesced inside a list.
+template <typename pos_t, typename sample_t>
+__global__ void __launch_bounds__(256) sa_dense_copy_kernel(const sample_t* __restrict__ sa, const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off,
+                                                            uint64_t n_pat, uint64_t total, pos_t* __restrict__ out)
+{
+    constexpr uint32_t kPer = 8;
+    __shared__ uint64_t s_first;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t lo = 0, hi = n_pat;
+            while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (out_off[mid] <= base) lo = mid; else hi = mid; }
+            s_first = lo;
+        }
+        __syncthreads();
+        uint64_t p = s_first;
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint64_t t = base + i * 256 + threadIdx.x;
+            if (t < total) {
+                while (out_off[p + 1] <= t) ++p;
+                out[t] = (pos_t)sa[l[p] + (t - out_off[p])];
+            }
+        }
+    }
+}
+
 // kTrail: LF trails are shared.  trail[i] = generation << 48 | (element + 1) << 16 | step remembers the first element that stood on
 // SA index i in THIS sweep and at which step (the generation stamp spares clearing 8 bytes per text position for every batch); an
 // element that arrives there later has the same future, so it stops and records (that element, steps apart) in rec -- or,
@@ -907,6 +936,16 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     if (sizeof(pos_t) == 4 && iv.n > (1ull << 32) + 1) return fail(VLG_E_INTERNAL, "sorted sweep: positions do not fit 32 bits");
     const bool rrr = iv.bv_kind == kBvRrr63, text_order = iv.sampling == kSamplingTextOrder;
     if (kWide && text_order) return fail(VLG_E_UNSUPPORTED, "text-order sampling with 64-bit SA indices");
+    if (iv.dens == 1 && !text_order && total) {                  // every SA index is sampled: no walk, no trails, no records
+        using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
+        if (timer) timer->begin(0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_dense_copy_kernel<pos_t, sample_t>), dim3(grid_for((total + 7) / 8, 32768)), dim3(256), 0, stream,
+                           reinterpret_cast<const sample_t*>(iv.samples), d_l, d_out_off, n_pat, total, d_out);
+        if (timer) timer->end(0);
+        VLG_HIP_TRY(hipGetLastError());
+        if (hook_due) { hook_due = false; if (vlg_status hs = (*while_first_step)()) return hs; }
+        return VLG_OK;
+    }
     const unsigned bits = bit_width64(iv.sigma);            // keys 0..sigma (sigma = finished, sorts last)
     const uint64_t batch_max = sweep_batch_max<kWide>();
     for (uint64_t t0 = 0; t0 < total; t0 += batch_max) {

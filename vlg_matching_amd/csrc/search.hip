@@ -1473,7 +1473,9 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             for (uint32_t t = 0; t < kHostThreads; ++t) { logical_max_query = std::max(logical_max_query, part_max[t]); pivot_elems += part_piv[t]; }
         }
         // the trail table (8 B per text position) and the records (8 B per occurrence) must leave room for the joins
-        uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup ? (idx->hdr.n + phys) * 8 + 512 : 0;
+        // (an index that keeps the whole suffix array -- SA-order samples of density 1 -- walks nothing: no trails, no records)
+        const bool dense_sa = idx->hdr.dens == 1 && idx->hdr.sampling == kSamplingSaOrder;
+        uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup && !dense_sa ? (idx->hdr.n + phys) * 8 + 512 : 0;
         // (+ fences: < 1 B per element; + the pivot filter's ladder, a third of the lists, when its searches outweigh building it:
         // one pass over the lists against two descents per pivot element)
         ws->want_rungs = pivot_elems && (ws->pivot_rungs == 2 || (pivot_elems >= phys / 16 && pivot_elems >= 4096));
