@@ -323,17 +323,12 @@ def main():
         d_text = torch.from_numpy(text).cuda()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        idx = V.VlgIndex.build_device(d_text.data_ptr(), len(text))
+        idx = V.VlgIndex.build_device(d_text.data_ptr(), len(text), dens=args.sa_dens)    # csa_wt<wt_huff<>, sa_dens, .>
         torch.cuda.synchronize()
         t_build = time.perf_counter() - t0
         del d_text
         torch.cuda.empty_cache()
         log("index built on device in %.2f s: %s" % (t_build, idx.info()))
-        if args.sa_dens != 32:
-            t0 = time.perf_counter()
-            idx = idx.resample(text_order=False, dens=args.sa_dens)      # csa_wt<wt_huff<>, sa_dens, .> over the same BWT
-            torch.cuda.synchronize()
-            log("resampled in SA order with density %d in %.2f s: %s" % (args.sa_dens, time.perf_counter() - t0, idx.info()))
         if (args.bv or ("rrr" if args.config == "C5" else "plain")) == "rrr":
             t0 = time.perf_counter()
             plain_idx, idx = idx, idx.compress()
