@@ -464,6 +464,13 @@ def test_cpp_driver_pipeline_matches_oracle(V, oracle, tmp_path):
                           text=True, timeout=300).stdout
     kvp = dict(l[2:].split(" = ") for l in outp.splitlines() if l.startswith("# ") and " = " in l)
     assert kvp["num_results"] == kv["num_results"] and kvp["checksum"] == kv["checksum"] and kvp["gpu_mode"] == "processes"
+    # -S: the loaded t_dens = 32 index expanded to the whole suffix array in HBM (index_fm_gpu::keep_suffix_array), alone, sharded
+    # over device slices and in the process-per-GPU mode: same lines
+    for extra in ([], ["-g", "2"], ["-g", "1", "-P"]):
+        outs = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt"), "-S"] + extra, check=True, capture_output=True,
+                              text=True, timeout=300).stdout
+        kvs = dict(l[2:].split(" = ") for l in outs.splitlines() if l.startswith("# ") and " = " in l)
+        assert kvs["num_results"] == kv["num_results"] and kvs["checksum"] == kv["checksum"], extra
 
 
 @pytest.mark.parametrize("name,seed,tail", [("dna_50k", 71, 16), ("zipf40", 72, 1), ("100a", 73, 4), ("dna_skew", 74, 1000), ("abracadabra", 75, 1)])

@@ -36,7 +36,7 @@ static void print_summary(std::vector<long long> timings, size_t num_results, si
 
 // One rank of `-g N -P`: nothing here has touched a GPU before the fork in main().  The communicator's id travels through a file
 // that rank 0 writes (atomically: write + rename) and the others wait for.
-static int run_rank(const std::string& col_dir, const std::string& pat_file, int rank, int n_ranks, const std::string& id_file)
+static int run_rank(const std::string& col_dir, const std::string& pat_file, int rank, int n_ranks, const std::string& id_file, bool keep_sa)
 {
     try {
         int ndev = 0;
@@ -67,6 +67,7 @@ static int run_rank(const std::string& col_dir, const std::string& pat_file, int
             else { index_fm_gpu built(col); idx.swap(built); }
         }
         idx.broadcast(comm, 0);
+        if (keep_sa) idx.keep_suffix_array();                        // (every rank expands its own copy: cheaper than 5x the broadcast)
         auto load_us = duration_cast<microseconds>(high_resolution_clock::now() - t_load).count();
         std::vector<gapped_pattern> pats = parse_pattern_file(pat_file);
         const index_fm_gpu& cidx = idx;
@@ -98,17 +99,18 @@ static int run_rank(const std::string& col_dir, const std::string& pat_file, int
 int main(int argc, char* const argv[])
 {
     std::string col_dir, pat_file;
-    bool one_by_one = false, per_process = false;
+    bool one_by_one = false, per_process = false, keep_sa = false;
     int op, n_gpus = 1;
-    while ((op = getopt(argc, argv, "c:p:1g:P")) != -1) {
+    while ((op = getopt(argc, argv, "c:p:1g:PS")) != -1) {
         if (op == 'c') col_dir = optarg;
         else if (op == 'p') pat_file = optarg;
         else if (op == '1') one_by_one = true;
         else if (op == 'g') n_gpus = atoi(optarg);
         else if (op == 'P') per_process = true;
+        else if (op == 'S') keep_sa = true;                          // the whole suffix array resident in HBM (index_fm_gpu::keep_suffix_array)
     }
     if (col_dir.empty() || pat_file.empty() || n_gpus < 1) {
-        fprintf(stdout, "%s -c <collection directory> -p <pattern file> [-1] [-g <GPUs> [-P]]\n", argv[0]);
+        fprintf(stdout, "%s -c <collection directory> -p <pattern file> [-1] [-g <GPUs> [-P]] [-S]\n", argv[0]);
         return EXIT_FAILURE;
     }
     if (per_process) {
@@ -119,7 +121,7 @@ int main(int argc, char* const argv[])
         for (int r = 0; r < n_gpus; ++r) {
             const pid_t pid = fork();
             if (pid < 0) { perror("fork"); return EXIT_FAILURE; }
-            if (pid == 0) _exit(run_rank(col_dir, pat_file, r, n_gpus, id_file));
+            if (pid == 0) _exit(run_rank(col_dir, pat_file, r, n_gpus, id_file, keep_sa));
             kids.push_back(pid);
         }
         int rc = 0;
@@ -143,6 +145,7 @@ int main(int argc, char* const argv[])
         std::ifstream ifs(index_file, std::ios::binary);
         if (ifs.is_open()) idx.load(ifs);
         else { index_fm_gpu built(col); idx.swap(built); }
+        if (keep_sa) idx.keep_suffix_array();
         auto load_us = duration_cast<microseconds>(high_resolution_clock::now() - t_load).count();
         std::vector<gapped_pattern> pats = parse_pattern_file(pat_file);
         size_t num_results = 0, checksum = 0;

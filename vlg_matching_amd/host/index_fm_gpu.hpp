@@ -129,6 +129,18 @@ class index_fm_gpu
         check(vlg_index_from_parts(&p, &m_idx));
     }
 
+    // The whole suffix array resident in HBM: the loaded index is replaced by csa_wt<wt_huff<>, 1, .> over the same BWT
+    // (t_dens of csa_wt.hpp:60-72 at its densest; 4 B per character more), made on the device; locate then copies SA intervals instead
+    // of walking LF.  Same results.  What serialize() / save_sdsl() wrote before stays the benchmark's t_dens = 32 index.
+    void keep_suffix_array()
+    {
+        vlg_index* dense = nullptr;
+        check(vlg_index_resample(m_idx, VLG_SAMPLING_SA_ORDER, 1, &dense));
+        drop_replicas();
+        vlg_index_destroy(m_idx);
+        m_idx = dense;
+    }
+
     // the reference's own on-disk format of csa_wt<wt_huff<>,32,64> (what store_to_file / load_from_file of stock sdsl use)
     void save_sdsl(const std::string& path) const { check(vlg_index_save_sdsl(m_idx, path.c_str())); }
     void load_sdsl(const std::string& path)
