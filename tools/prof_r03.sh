@@ -27,6 +27,8 @@ python3 bench.py --config C5 --steps 3 --warmup 1 > $O/bench_C5.json 2> $O/bench
 step "C5 line"
 python3 bench.py --config C4 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-dense-sa > $O/bench_C4.json 2> $O/bench_C4.err || exit 1
 step "C4 line"
+python3 bench.py --config C4 --sa-dens 1 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > $O/bench_C4_dense_sa.json 2> $O/bench_C4_dense_sa.err || exit 1
+step "C4 line, suffix array resident"
 python3 bench.py --config C2 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_C2.json 2> $O/bench_C2.err || exit 1
 step "C2 line"
 python3 bench.py --gpus 1 --dist-at-1 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-dense-sa > $O/bench_C3_one_rank_rccl.json 2> $O/bench_C3_one_rank_rccl.err || exit 1
