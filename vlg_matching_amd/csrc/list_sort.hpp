@@ -187,10 +187,18 @@ inline uint64_t list_sort_scratch_bytes(uint64_t n_long, uint64_t n_tiles, uint6
 // The host side comes in two halves so that the tables are built and uploaded BEFORE the lists exist (while locate still runs):
 // list_sort_prepare sizes and uploads everything (status VLG_E_WORKSPACE: no room in the arena -- nothing was carved or launched,
 // the caller takes the device-wide sort), list_sort_enqueue launches the kernels.
+// classes of short lists by length: one workgroup of (threads x items) >= length sorts the list; a workgroup's time is that of its
+// padded size, so neighbouring classes are a factor 2 apart (VLG_SORT_CLASSES=3: the three classes 256 / 1024 / 4096 of before)
+#ifndef VLG_SORT_CLASSES
+#define VLG_SORT_CLASSES 5
+#endif
+constexpr uint32_t kSortClasses = VLG_SORT_CLASSES;
+static_assert(kSortClasses == 3 || kSortClasses == 5, "three or five classes of short lists");
+constexpr uint32_t kSortClassMax[5] = {256, kSortClasses == 5 ? 512u : 1024u, kSortClasses == 5 ? 1024u : kSortTile, 2048, kSortTile};
 struct ListSortPlan {
     bool ready = false;
-    uint32_t n_small[3] = {0, 0, 0};
-    uint32_t* d_small[3] = {nullptr, nullptr, nullptr};
+    uint32_t n_small[kSortClasses] = {};
+    uint32_t* d_small[kSortClasses] = {};
     uint32_t n_long = 0, n_tiles = 0, n_chunks = 0;
     SortList* d_longs = nullptr;
     uint32_t *d_tile_list = nullptr, *d_chunk_list = nullptr, *d_tot = nullptr, *d_pref = nullptr;
@@ -199,16 +207,17 @@ struct ListSortPlan {
 
 inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Arena& A, hipStream_t st, ListSortPlan& lp)
 {
-    svec<uint32_t> small[3];                                       // <= 256, <= 1024, <= kSortTile elements
+    svec<uint32_t> small[kSortClasses];                            // <= kSortClassMax[c] elements
     svec<SortList> longs;
     svec<uint32_t> tile_list, chunk_list;
     for (uint32_t l = 0; l < nd; ++l) {
         const uint64_t len = off64[l + 1] - off64[l];
         if (len <= 1) continue;
-        if (len <= 256) small[0].push_back(l);
-        else if (len <= 1024) small[1].push_back(l);
-        else if (len <= kSortTile) small[2].push_back(l);
-        else {
+        if (len <= kSortTile) {
+            uint32_t c = 0;
+            while (len > kSortClassMax[c]) ++c;
+            small[c].push_back(l);
+        } else {
             if (len > 0xFFFFFFFFull) return fail(VLG_E_INTERNAL, "list sort: list too long");
             const uint32_t tiles = (uint32_t)((len + kSortTile - 1) / kSortTile), chunks = (tiles + kSortChunk - 1) / kSortChunk;
             const uint32_t m = (uint32_t)longs.size();
@@ -219,11 +228,11 @@ inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Ar
     }
     {   // room for everything, or nothing is carved
         uint64_t need = 4096;
-        for (int c = 0; c < 3; ++c) need += align_up(small[c].size() * 4, 256);
+        for (uint32_t c = 0; c < kSortClasses; ++c) need += align_up(small[c].size() * 4, 256);
         if (!longs.empty()) need += list_sort_scratch_bytes(longs.size(), tile_list.size(), chunk_list.size());
         if (A.failed || A.size - A.used < need) return fail(VLG_E_WORKSPACE, "list sort: no room for its tables");
     }
-    for (int c = 0; c < 3; ++c) {
+    for (uint32_t c = 0; c < kSortClasses; ++c) {
         lp.n_small[c] = (uint32_t)small[c].size();
         if (small[c].empty()) continue;
         lp.d_small[c] = A.take<uint32_t>(small[c].size());
@@ -250,9 +259,14 @@ inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Ar
 // P: the lists (in suffix-array order inside), `other`: a second buffer of the same size; the sorted lists end up in P.
 inline vlg_status list_sort_enqueue(const ListSortPlan& lp, uint32_t* P, uint32_t* other, const uint64_t* d_off64, unsigned bits, hipStream_t st)
 {
-    if (lp.n_small[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<64, 4>), dim3(lp.n_small[0]), dim3(64), 0, st, P, d_off64, lp.d_small[0], lp.n_small[0], bits);
-    if (lp.n_small[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<256, 4>), dim3(lp.n_small[1]), dim3(256), 0, st, P, d_off64, lp.d_small[1], lp.n_small[1], bits);
-    if (lp.n_small[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<256, 16>), dim3(lp.n_small[2]), dim3(256), 0, st, P, d_off64, lp.d_small[2], lp.n_small[2], bits);
+#define VLG_SMALL(C, T, I) do { static_assert(T * I == kSortClassMax[C], "class size"); \
+        if (lp.n_small[C]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<T, I>), dim3(lp.n_small[C]), dim3(T), 0, st, P, d_off64, lp.d_small[C], lp.n_small[C], bits); } while (0)
+#if VLG_SORT_CLASSES == 5
+    VLG_SMALL(0, 64, 4); VLG_SMALL(1, 128, 4); VLG_SMALL(2, 256, 4); VLG_SMALL(3, 256, 8); VLG_SMALL(4, 256, 16);
+#else
+    VLG_SMALL(0, 64, 4); VLG_SMALL(1, 256, 4); VLG_SMALL(2, 256, 16);
+#endif
+#undef VLG_SMALL
     VLG_HIP_TRY(hipGetLastError());
     if (!lp.n_long) return VLG_OK;
     const unsigned passes = bits <= 16 ? 2 : 4;                    // even: the lists come back to P
