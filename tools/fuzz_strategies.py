@@ -90,11 +90,16 @@ def main():
         variant = "plain"
         if mode != "0":
             os.environ["VLG_FORCE_POS64"] = mode
-            other = V.VlgIndex.build(text)
-            variant = "pos64=" + mode
+            d = int(rng.choice([32, 32, 1]))                         # (1: sa_dense_copy_kernel on 64-bit samples)
+            other = V.VlgIndex.build(text, dens=d)
+            variant = "pos64=%s/%d" % (mode, d)
         elif rng.random() < 0.3:                                     # text_order_sa_sampling on top (plain or rrr)
             other = other.resample(text_order=True, dens=int(rng.choice([1, 4, 32, 64])))
             variant = "text-order"
+        elif rng.random() < 0.3:                                     # SA-order samples of another density; 1 = the whole suffix array resident
+            d = int(rng.choice([1, 1, 2, 5, 64]))
+            other = other.resample(text_order=False, dens=d)
+            variant = "sa-order/%d" % d
         os.environ["VLG_NO_SPECULATIVE_COMPACT"] = str(rng.choice(["0", "0", "1"]))
         opts["variant"] = variant
         try:
