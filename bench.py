@@ -278,6 +278,15 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                                     # does not return
 
+    # ONE JSON line on stdout: libraries below this process write to file descriptor 1 on their own (RCCL prints a version banner when
+    # a communicator is made, gloo its connection lines), so everything but the line goes to stderr and the line to the real stdout
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     import numpy as np
     import torch
 
@@ -719,7 +728,7 @@ def main():
             log("rank %d: %s -- leaving; the weak-scaling line stands" % (rank, msg))
             if rank == 0:
                 out["strong_scaling"] = {"error": msg}
-                print(json.dumps(out), flush=True)
+                emit(out)
             sys.stdout.flush()
             os._exit(0)                                            # (the error is in the line and on stderr; a non-zero code would make the launcher drop the line)
         threading.Thread(target=watchdog, daemon=True).start()
@@ -737,7 +746,7 @@ def main():
             out["strong_scaling"] = strong if int(ok.item()) == 1 and strong is not None else {
                 "error": failure[0] or "a rank failed inside the strong-scaling region (see its stderr)"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
