@@ -606,6 +606,28 @@ __global__ void sweep_init_kernel(const uint64_t* __restrict__ l, const uint64_t
     }
 }
 
+// The lists that hold the elements [base, end) of a workgroup's turn, staged in LDS: looking an element's list up (whose interval it
+// belongs to, where that starts) is a chain of dependent reads in front of everything else the element does, and the next element's
+// chain starts where this one's ended -- out of LDS it costs tens of cycles instead of L2 round trips.  A turn whose elements spread
+// over more than kListStage lists (lists of a few elements each) walks the global arrays as before.  VLG_STAGE_LISTS=0: never staged.
+#ifndef VLG_STAGE_LISTS
+#define VLG_STAGE_LISTS 1
+#endif
+constexpr bool kStageLists = VLG_STAGE_LISTS != 0;
+constexpr uint32_t kListStage = 256;
+struct ListStage { uint64_t off[kListStage + 1]; uint64_t l[kListStage]; };
+__device__ __forceinline__ bool stage_lists(ListStage& ls, const uint64_t* __restrict__ out_off, const uint64_t* __restrict__ l, uint64_t n_pat,
+                                            uint64_t first, uint64_t end)
+{
+    for (uint32_t j = threadIdx.x; j <= kListStage; j += blockDim.x) {
+        const uint64_t p = first + j;
+        ls.off[j] = out_off[p < n_pat ? p : n_pat];
+        if (j < kListStage) ls.l[j] = l[p < n_pat ? p : n_pat - 1];
+    }
+    __syncthreads();
+    return ls.off[kListStage] >= end;                      // (the same word in every thread: the branch on it is uniform)
+}
+
 // The suffix array itself resident in HBM (SA-order sampling with density 1: csa_wt<wt_huff<>, 1, .>, 4 B x n -- 4.3 GB for a 1 GiB text,
 // what 288 GB of HBM afford and the reference's CPU index does not): locate is a copy of the SA intervals, csa[i] = sample[i]
 // (csa_wt.hpp:335-348 with zero LF steps).  Same list lookup as sweep_init_kernel; reads and writes are coalesced inside a list.
@@ -615,6 +637,7 @@ __global__ void __launch_bounds__(256) sa_dense_copy_kernel(const sample_t* __re
 {
     constexpr uint32_t kPer = 8;
     __shared__ uint64_t s_first;
+    __shared__ ListStage s_lists;
     for (uint64_t base = (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -624,6 +647,19 @@ __global__ void __launch_bounds__(256) sa_dense_copy_kernel(const sample_t* __re
         }
         __syncthreads();
         uint64_t p = s_first;
+        const uint64_t end = base + 256 * kPer < total ? base + 256 * kPer : total;
+        if (kStageLists && stage_lists(s_lists, out_off, l, n_pat, p, end)) {
+            uint32_t q = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kPer; ++i) {
+                const uint64_t t = base + i * 256 + threadIdx.x;
+                if (t < total) {
+                    while (s_lists.off[q + 1] <= t) ++q;
+                    out[t] = (pos_t)sa[s_lists.l[q] + (t - s_lists.off[q])];
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (uint32_t i = 0; i < kPer; ++i) {
             const uint64_t t = base + i * 256 + threadIdx.x;
@@ -728,6 +764,7 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
 {
     __shared__ WalkLds<BV> s;
     __shared__ uint64_t s_first;
+    __shared__ ListStage s_lists;
     stage_walk(s, iv);
     using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
     using Sampling = typename std::conditional<kTextOrder, TextOrderSampling, SaOrderSampling<sample_t>>::type;
@@ -744,12 +781,22 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
         }
         __syncthreads();
         uint64_t p = s_first;
+        const uint64_t end = base + 256 * kPer < total ? base + 256 * kPer : total;
+        const bool staged = kStageLists && stage_lists(s_lists, out_off, l, n_pat, p, end);
+        uint32_t q = 0;
 #pragma unroll 1
         for (uint32_t i = 0; i < kPer; ++i) {
             const uint64_t t = base + i * 256 + threadIdx.x;
             if (t < total) {
-                while (out_off[p + 1] <= t) ++p;
-                const uint64_t v64 = ((t - t0) << kShift) | (l[p] + (t - out_off[p]));
+                uint64_t sai;
+                if (staged) {
+                    while (s_lists.off[q + 1] <= t) ++q;
+                    sai = s_lists.l[q] + (t - s_lists.off[q]);
+                } else {
+                    while (out_off[p + 1] <= t) ++p;
+                    sai = l[p] + (t - out_off[p]);
+                }
+                const uint64_t v64 = ((t - t0) << kShift) | sai;
                 sweep_element<BV, pos_t, kTrail, kWide, true>(iv, s, sampling, t - t0, v64, val, key, 0u, out, trail, rec, t0, gen, n_lv, n_lf, n_fin);
             }
         }
