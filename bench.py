@@ -241,6 +241,19 @@ def cpu_sasearch(text, queries, occ_per_query_mean, budget_occ=60000000, budget_
                     "queries/s = sample occurrences/s / mean occurrences per query of the full batch"}
 
 
+def claim_stdout():
+    """ONE JSON line on stdout: libraries below this process write to file descriptor 1 on their own (RCCL prints a version banner when
+    a communicator is made, gloo its connection lines), so from here on everything written to fd 1 -- by them or by print() -- goes to
+    stderr, and the returned function writes an object as one line to the real stdout."""
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+    return emit
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,14 +291,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                                     # does not return
 
-    # ONE JSON line on stdout: libraries below this process write to file descriptor 1 on their own (RCCL prints a version banner when
-    # a communicator is made, gloo its connection lines), so everything but the line goes to stderr and the line to the real stdout
-    real_stdout = os.dup(1)
-    sys.stdout.flush()
-    os.dup2(2, 1)
-
-    def emit(obj):
-        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+    emit = claim_stdout()
 
     import numpy as np
     import torch

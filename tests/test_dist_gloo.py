@@ -153,3 +153,19 @@ def test_bench_wait_ranks_ends_the_survivors_of_a_dead_rank():
     assert time.time() - t0 < 30
     ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
     assert bench.wait_ranks(ok, poll_s=0.05) == 0
+
+
+def test_bench_stdout_carries_the_json_line_alone():
+    """bench.py's contract is ONE JSON line on stdout, but RCCL (its version banner at communicator creation) and gloo (its connection
+    lines) write to file descriptor 1 on their own: after claim_stdout() whatever a library or print() writes to fd 1 lands on stderr and
+    only emit() reaches the real stdout."""
+    import json
+    import subprocess
+    prog = ("import os, sys; sys.path.insert(0, %r); import bench; emit = bench.claim_stdout(); "
+            "os.write(1, b'RCCL version : banner\\n'); print('a print'); sys.stdout.flush(); "
+            "os.system('echo from a child process'); emit({'metric': 'm', 'value': 1})" % ROOT)
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("\n") == 1 and json.loads(r.stdout) == {"metric": "m", "value": 1}
+    for noise in ("RCCL version : banner", "a print", "from a child process"):
+        assert noise in r.stderr
