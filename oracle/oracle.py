@@ -278,21 +278,22 @@ def join(lists, lo, hi, end_len, cap=None):
 class Index:
     """CPU restatement of csa_wt<wt_huff<>,32,64> + the VLG search on top of it."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, dens=32):
         assert handle
         self.h = handle
+        self.dens = int(dens) if dens else 32              # t_dens of csa_wt<> (csa_wt.hpp:60-72)
 
     @classmethod
     def from_text(cls, text, dens=32):
         t = _np_u8(text)
         assert not (t == 0).any(), "text must not contain a zero byte (construct.hpp:36-45)"
-        return cls(lib().vlgo_build(t.ctypes.data, len(t), dens))
+        return cls(lib().vlgo_build(t.ctypes.data, len(t), dens), dens)
 
     @classmethod
     def from_bwt(cls, bwt, sa, dens=32):
         b = _np_u8(bwt)
         s = np.ascontiguousarray(sa, dtype=np.uint64)
-        return cls(lib().vlgo_build_from_bwt(b.ctypes.data, s.ctypes.data, len(b), dens))
+        return cls(lib().vlgo_build_from_bwt(b.ctypes.data, s.ctypes.data, len(b), dens), dens)
 
     @classmethod
     def from_parts(cls, p):
@@ -305,7 +306,7 @@ class Index:
         h = lib().vlgo_from_parts(int(p["n"]), int(p["sigma"]), c2c.ctypes.data, Cc.ctypes.data, bv.ctypes.data,
                                   int(p["bv_bits"]), nodes.ctypes.data, len(nodes), smp.ctypes.data, len(smp),
                                   int(p.get("dens", 32)))
-        return cls(h)
+        return cls(h, int(p.get("dens", 32)))
 
     def __del__(self):
         try:
@@ -333,7 +334,7 @@ class Index:
         nw = (bits + 63) // 64
         ns = int(L.vlgo_n_samples(self.h))
         return {
-            "n": self.n, "sigma": self.sigma, "dens": 32,
+            "n": self.n, "sigma": self.sigma, "dens": self.dens,
             "char2comp": np.ctypeslib.as_array(L.vlgo_char2comp(self.h), shape=(256,)).copy(),
             "C": np.ctypeslib.as_array(L.vlgo_C(self.h), shape=(self.sigma + 1,)).copy(),
             "bv_bits": bits,

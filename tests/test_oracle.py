@@ -204,6 +204,32 @@ def test_from_parts_roundtrip(oracle):
     assert (a.rank_blocks() == b.rank_blocks()).all()
 
 
+@pytest.mark.parametrize("dens", [1, 2, 7, 32, 64])
+def test_sa_order_sampling_density_in_the_oracle(oracle, dens):
+    """sa_order_sa_sampling at other densities (csa_sampling_strategy.hpp:64-112, t_dens of csa_wt.hpp:60-72): the samples are SA[0],
+    SA[dens], ...; csa[i] == SA[i] whatever the density, after exactly the LF steps it takes to reach an index that is a multiple of
+    dens (csa_wt.hpp:335-348) -- none at all for dens = 1, the suffix array itself (what the GPU index keeps resident as an option,
+    DESIGN.md 6) -- and searches do not depend on it.  parts() carries the density it was built with."""
+    text = skewed_text(3000, 9).tobytes()
+    sa = oracle.suffix_array(np.frombuffer(text + bytes(1), dtype=np.uint8)).astype(np.int64)
+    ref = oracle.Index.from_text(text)
+    idx = oracle.Index.from_text(text, dens=dens)
+    p = idx.parts()
+    assert p["dens"] == dens and p["samples"].astype(np.int64).tolist() == sa[::dens].tolist()
+    import ctypes as C
+    L = oracle.lib()
+    for i in range(0, idx.n, 7):
+        lf_steps, levels = C.c_uint64(0), C.c_uint64(0)
+        assert L.vlgo_sa(idx.h, i, C.byref(lf_steps), C.byref(levels)) == sa[i]
+        j, steps = i, 0
+        while j % dens:
+            j, steps = ref.lf(j), steps + 1
+        assert lf_steps.value == steps and (dens > 1 or steps == 0)
+    back = oracle.Index.from_parts(p)
+    for q in ["!.{0,9}?\"", "#\"", "!!.{1,30}?!.{0,5}?\"", "\"#.{0,100}?!"]:
+        assert idx.search(q).tolist() == ref.search(q).tolist() == back.search(q).tolist()
+
+
 @pytest.mark.parametrize("dialect", [0, 1])
 def test_sasearch_restatement_equals_fm_path(oracle, dialect):
     """The plain-suffix-array index of the benchmark (index_sasearch.hpp) and the FM path answer alike: same SA ranges
