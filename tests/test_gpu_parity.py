@@ -1244,6 +1244,9 @@ def test_dense_suffix_array_index(torch_cuda, V, oracle, monkeypatch, name):
         assert info["sampling"] == 0 and info["sa_sample_dens"] == 1 and info["n_samples"] == len(sa)
         if src is base:                                          # (an rrr index does not export its parts)
             assert idx.export_parts()["samples"][: len(sa)].astype(np.int64).tolist() == sa.tolist()
+            want_parts = oracle.Index.from_text(text, dens=1).parts()   # the restated csa_wt<wt_huff<>, 1, .>
+            assert idx.export_parts()["dens"] == want_parts["dens"] == 1
+            assert_parts_equal(idx.export_parts(), want_parts)
         d_i = dev_u64(torch, np.arange(len(sa), dtype=np.uint64))
         d_o = torch.zeros_like(d_i)
         V.capi.check(V.lib().vlg_sa_batch(idx._h, d_i.data_ptr(), d_o.data_ptr(), len(sa), None))
