@@ -292,6 +292,9 @@ def main():
         self_launch(args)                                     # does not return
 
     emit = claim_stdout()
+    # (the host driver of this pool only supports dmabuf IPC: without this RCCL fails with hipIpcGetMemHandle: invalid argument;
+    # set before anything initialises HIP, kept if the launcher already chose a value)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
     import torch
