@@ -241,6 +241,69 @@ def cpu_sasearch(text, queries, occ_per_query_mean, budget_occ=60000000, budget_
                     "queries/s = sample occurrences/s / mean occurrences per query of the full batch"}
 
 
+STRONG_FAILED_EXIT = 3          # exit code of every rank when the strong-scaling region failed or stalled (the JSON line is printed first)
+
+
+def guarded_region(region, store, rank, world, timeout_s, report, exit_fn=os._exit, poll_s=0.25):
+    """region() on every rank, under a watchdog, with the outcome agreed through the process group's key-value STORE and not
+    through a collective: a rank that raised must not enter an all-reduce while its peers sit inside another collective (on
+    RCCL a mismatched collective is undefined, not a clean hang).  Every rank posts `ok` or `fail` for itself; when a failure
+    is posted, or the region has not finished on all ranks within timeout_s, each rank calls report(message) -- rank 0 prints
+    the weak-scaling line with the error there -- and leaves through exit_fn(STRONG_FAILED_EXIT): launchers and CI gating on the
+    exit status see the failure, consumers of stdout still get the line.  Returns region()'s value when all ranks finished."""
+    import threading
+    finished = threading.Event()
+    key_fail, key_ok = "vlg_strong_fail", "vlg_strong_ok_%d"
+
+    def failed_message():
+        try:
+            return store.get(key_fail).decode("utf-8", "replace") if store.check([key_fail]) else None
+        except Exception:                                      # noqa: BLE001 -- the store is gone with rank 0: the run is over
+            return "the process group's store is unreachable"
+
+    def leave(msg):
+        try:
+            report(msg)
+        finally:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            exit_fn(STRONG_FAILED_EXIT)
+
+    def watchdog():
+        t0 = time.time()
+        while not finished.wait(poll_s):
+            msg = failed_message()
+            if msg is None and time.time() - t0 > timeout_s:
+                msg = "strong-scaling region did not finish within %d s" % timeout_s
+            if msg is not None:
+                leave(msg)
+                finished.set()                                 # (only reached when exit_fn returns: tests)
+                return
+    threading.Thread(target=watchdog, daemon=True).start()
+    value = None
+    try:
+        value = region()
+        store.set(key_ok % rank, "1")
+    except Exception as e:                                     # noqa: BLE001 -- reported in the line
+        import traceback
+        traceback.print_exc()
+        store.set(key_fail, "rank %d: %s: %s" % (rank, type(e).__name__, e))
+    # all ranks done?  (the watchdog ends the wait when somebody failed or stalled)
+    keys = [key_ok % r for r in range(world)]
+    while not finished.is_set():
+        try:
+            if store.check(keys):
+                break
+        except Exception:                                      # noqa: BLE001
+            pass
+        if failed_message() is not None:
+            time.sleep(10 * poll_s)                            # the watchdog thread reports and exits; do not race it
+            continue
+        time.sleep(poll_s / 4)
+    finished.set()
+    return value
+
+
 def claim_stdout():
     """ONE JSON line on stdout: libraries below this process write to file descriptor 1 on their own (RCCL prints a version banner when
     a communicator is made, gloo its connection lines), so from here on everything written to fd 1 -- by them or by print() -- goes to
@@ -722,38 +785,16 @@ def main():
 
     # The strong region is the only part of an N-GPU run that exchanges data between the ranks (RCCL all-gather of the sorted lists).
     # Whatever happens in it -- an exception on one rank, a collective that never completes -- the weak-scaling line measured above
-    # is still printed: every rank runs a watchdog; when it fires, rank 0 prints the line with the error in `strong_scaling` and
-    # every rank leaves.  The watchdog stays armed through the agreement all-reduce behind the region, so a rank that failed
-    # alone (the others then wait inside a collective) ends all of them.
+    # is still printed, and then every rank leaves with STRONG_FAILED_EXIT (guarded_region below).
     if dist is not None and not args.no_strong:
-        import threading
-        finished = threading.Event()
-        failure = [None]
-
-        def watchdog():
-            if finished.wait(args.strong_timeout):
-                return
-            msg = failure[0] or ("strong-scaling region did not finish within %d s" % args.strong_timeout)
-            log("rank %d: %s -- leaving; the weak-scaling line stands" % (rank, msg))
+        def report(msg):
+            log("rank %d: %s -- leaving with exit code %d; the weak-scaling line stands" % (rank, msg, STRONG_FAILED_EXIT))
             if rank == 0:
                 out["strong_scaling"] = {"error": msg}
                 emit(out)
-            sys.stdout.flush()
-            os._exit(0)                                            # (the error is in the line and on stderr; a non-zero code would make the launcher drop the line)
-        threading.Thread(target=watchdog, daemon=True).start()
-        strong = None
-        try:
-            strong = strong_region()
-        except Exception as e:                                     # noqa: BLE001 -- reported in the line
-            import traceback
-            traceback.print_exc()
-            failure[0] = "rank %d: %s: %s" % (rank, type(e).__name__, e)
-        ok = torch.tensor([0 if failure[0] else 1], dtype=torch.int64, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                  # (hangs if another rank is stuck: the watchdog ends that)
-        finished.set()
+        strong = guarded_region(strong_region, dist.distributed_c10d._get_default_store(), rank, world, args.strong_timeout, report)
         if rank == 0:
-            out["strong_scaling"] = strong if int(ok.item()) == 1 and strong is not None else {
-                "error": failure[0] or "a rank failed inside the strong-scaling region (see its stderr)"}
+            out["strong_scaling"] = strong
     if rank == 0:
         emit(out)
     if dist is not None:

@@ -201,3 +201,29 @@ def test_sdsl_file_reader_on_reference_written_rrr_image(V, refmod, tmp_path):
             assert (got["nodes"][f] == want["nodes"][f]).all(), f
     with pytest.raises(V.VlgError):
         V.index.read_sdsl_file(tmp_path / "dna.rrr.sdsl", rrr=False)        # an rrr image is not a plain one
+
+
+def test_rccl_loader_reports_a_missing_library(V):
+    """vlg_comm_* bind RCCL at run time.  When the chosen library cannot be opened every entry point returns VLG_E_UNSUPPORTED
+    with the loader's message (it used to read dlerror() twice and crash on the second, cleared, answer).  VLG_RCCL_LIBRARY is an
+    explicit choice: nothing else is probed behind it.  Child process: the binding is made once per process."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, ctypes as C
+sys.path.insert(0, sys.argv[1])
+import vlg_matching_amd as V
+L = V.lib()
+buf = (C.c_uint8 * 128)()
+s = L.vlg_comm_unique_id(C.cast(buf, C.c_void_p))
+print("status", s, (L.vlg_last_error() or b"").decode())
+s2 = L.vlg_comm_info(C.c_void_p(1), None, None)
+print("status2", s2)
+'''
+    env = dict(os.environ, VLG_RCCL_LIBRARY="/nonexistent/librccl_bogus.so")
+    r = subprocess.run([sys.executable, "-c", script, ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-600:])
+    lines = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines())
+    assert lines["status"].startswith("%d " % V.capi.E_UNSUPPORTED), r.stdout
+    assert "RCCL not found" in lines["status"] and "librccl_bogus" in lines["status"]
+    assert lines["status2"].strip() == str(V.capi.E_UNSUPPORTED)

@@ -169,3 +169,64 @@ def test_bench_stdout_carries_the_json_line_alone():
     assert r.stdout.count("\n") == 1 and json.loads(r.stdout) == {"metric": "m", "value": 1}
     for noise in ("RCCL version : banner", "a print", "from a child process"):
         assert noise in r.stderr
+
+
+_GUARD_SCRIPT = r'''
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+import bench
+rank, fault = int(os.environ["RANK"]), os.environ["FAULT"]
+emit = bench.claim_stdout()              # before the process group, as in bench.py: gloo prints its connection lines to fd 1
+dist.init_process_group("gloo", rank=rank, world_size=2)
+out = {"metric": "m", "value": 1, "strong_scaling": None}
+
+def region():
+    if rank == 1 and fault == "raise":
+        raise RuntimeError("injected")
+    if rank == 1 and fault == "hang":
+        time.sleep(1e6)
+    t = torch.ones(1)
+    dist.all_reduce(t)                 # never completes when rank 1 is not in it
+    return {"sum": float(t.item())}
+
+def report(msg):
+    if rank == 0:
+        out["strong_scaling"] = {"error": msg}
+        emit(out)
+
+v = bench.guarded_region(region, dist.distributed_c10d._get_default_store(), rank, 2, float(os.environ["TIMEOUT"]), report)
+if rank == 0:
+    out["strong_scaling"] = v
+    emit(out)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("fault", ["none", "raise", "hang"])
+def test_bench_strong_region_watchdog_prints_the_line_and_exits_nonzero(fault):
+    """bench.guarded_region: a rank that raises, or a collective that never completes, inside the strong-scaling region still
+    yields the weak-scaling JSON line on rank 0 (with the error in it) -- and every rank then exits with STRONG_FAILED_EXIT, so
+    a launcher gating on the status sees it.  The outcome is agreed through the store, never through a collective."""
+    import json
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FAULT=fault, TIMEOUT="4")
+        procs.append(subprocess.Popen([sys.executable, "-c", _GUARD_SCRIPT, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert outs[0][0].count("\n") == 1 and outs[1][0] == "", (outs[0][0], outs[1][0])
+    assert line["metric"] == "m" and line["value"] == 1
+    if fault == "none":
+        assert [p.returncode for p in procs] == [0, 0], [o[1][-400:] for o in outs]
+        assert line["strong_scaling"] == {"sum": 2.0}
+    else:
+        assert [p.returncode for p in procs] == [bench.STRONG_FAILED_EXIT] * 2, ([p.returncode for p in procs], [o[1][-400:] for o in outs])
+        assert "error" in line["strong_scaling"]
+        assert ("injected" in line["strong_scaling"]["error"]) == (fault == "raise")

@@ -449,16 +449,32 @@ def test_cpp_driver_pipeline_matches_oracle(V, oracle, tmp_path):
     assert int(kv["num_patterns"]) == len(pats) - 1
     for key in ("total_time_mus", "min_time_mus", "qrt_1st_time_mus", "mean_time_mus", "median_time_mus", "qrt_3rd_time_mus", "max_time_mus"):
         assert key in kv
+    # batch mode: one clock around the batch, shared out over the queries by their work (1 + sum of occurrence counts, 1 for a query
+    # with an empty list) -- the TIMING lines follow the pattern file's order, add up to the batch time and say how they were made
+    timing = [int(l.split(" = ")[1]) for l in out.splitlines() if l.startswith("TIMING = ")]
+    assert kv["timing_mode"] == "batch_apportioned_by_occurrences" and len(timing) == len(pats) - 1
+    w = []
+    for p in pats:
+        try:
+            subs = oracle.query_fields(oracle.parse(p, 1))[0]
+        except oracle.ParseError:
+            continue
+        occ = [o.backward_search(sp)[0] for sp in subs]
+        w.append(1 + (0 if min(occ) == 0 else sum(occ)))
+    total = int(kv["total_time_mus"])
+    assert total - len(timing) <= sum(timing) <= total
+    assert all(abs(t - total * wi / sum(w)) <= 1 for t, wi in zip(timing, w))
+    assert int(kv["max_time_mus"]) == max(timing) and int(kv["min_time_mus"]) == min(timing)
     out1 = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt"), "-1"], check=True, capture_output=True, text=True).stdout
     kv1 = dict(l[2:].split(" = ") for l in out1.splitlines() if l.startswith("# ") and " = " in l)
-    assert kv1["num_results"] == kv["num_results"] and kv1["checksum"] == kv["checksum"]
+    assert kv1["num_results"] == kv["num_results"] and kv1["checksum"] == kv["checksum"] and kv1["timing_mode"] == "per_query_clock"
     # -g N: the pattern file sharded over N device slices (index replicated by a peer copy, slices cut by work, one host thread
     # each; on a one-GPU box the slices share the device, which still runs replicate + shard + merge)
     for g in ("2", "3"):
         outg = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt"), "-g", g], check=True, capture_output=True, text=True).stdout
         kvg = dict(l[2:].split(" = ") for l in outg.splitlines() if l.startswith("# ") and " = " in l)
         assert kvg["num_results"] == kv["num_results"] and kvg["checksum"] == kv["checksum"] and kvg["num_gpus"] == g
-    # -g 1 -P: one PROCESS per GPU over RCCL (forked before any GPU call; vlg_comm_create from a unique id passed through a file,
+    # -g 1 -P: one PROCESS per GPU over RCCL (forked before any GPU call; vlg_comm_create from a unique id passed through a pipe made before the fork,
     # vlg_index_broadcast, counters through vlg_comm_allreduce_sum_u64) -- with the one rank a one-GPU box can host
     outp = subprocess.run([_bin("gm_search_gpu"), "-c", col, "-p", str(tmp_path / "pats.txt"), "-g", "1", "-P"], check=True, capture_output=True,
                           text=True, timeout=300).stdout

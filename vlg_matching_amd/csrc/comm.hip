@@ -11,32 +11,33 @@
 #include <string>
 #include <vector>
 #include "common.hpp"
+#include "rccl_decl.hpp"
 
 using namespace vlg;
 
 namespace {
 
-// the few declarations of rccl.h this file needs (kept local: the library does not link RCCL)
-typedef struct ncclComm* ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSuccess = 0 };
-enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5 };
-enum { ncclSum = 0 };
+// (the few declarations of rccl.h this file needs live in rccl_decl.hpp; rccl_abi_check.cpp asserts them against the real header)
+using ncclComm_t = vlg_rccl::comm_t;
+using ncclUniqueId = vlg_rccl::UniqueId;
+constexpr int ncclSuccess = vlg_rccl::kSuccess, ncclUint8 = vlg_rccl::kUint8, ncclUint64 = vlg_rccl::kUint64, ncclSum = vlg_rccl::kSum;
 
 struct Rccl {
     bool ok = false;
     std::string err, path;                                   // path: the library the entry points came from
-    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*CommCount)(ncclComm_t, int*) = nullptr;
-    int (*CommUserRank)(ncclComm_t, int*) = nullptr;
-    int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    vlg_rccl::GetUniqueId_fn GetUniqueId = nullptr;
+    vlg_rccl::CommInitRank_fn CommInitRank = nullptr;
+    vlg_rccl::CommDestroy_fn CommDestroy = nullptr;
+    vlg_rccl::CommCount_fn CommCount = nullptr;
+    vlg_rccl::CommUserRank_fn CommUserRank = nullptr;
+    vlg_rccl::Broadcast_fn Broadcast = nullptr;
+    vlg_rccl::AllReduce_fn AllReduce = nullptr;
+    vlg_rccl::AllGather_fn AllGather = nullptr;
+    vlg_rccl::Send_fn Send = nullptr;
+    vlg_rccl::Recv_fn Recv = nullptr;
+    vlg_rccl::Group_fn GroupStart = nullptr;
+    vlg_rccl::Group_fn GroupEnd = nullptr;
+    vlg_rccl::GetErrorString_fn GetErrorString = nullptr;
 };
 
 Rccl& rccl()
@@ -45,7 +46,11 @@ Rccl& rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         void* h = nullptr;                                   // nullptr: RTLD_DEFAULT, what the process already exports globally
-        if (!dlsym(RTLD_DEFAULT, "ncclCommInitRank")) {
+        const char* forced = getenv("VLG_RCCL_LIBRARY");     // an explicit choice wins over every probe, and nothing else is tried
+        if (forced && *forced) {
+            h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!h) { const char* e = dlerror(); r.err = std::string("RCCL not found (VLG_RCCL_LIBRARY=") + forced + "): " + (e ? e : ""); return; }
+        } else if (!dlsym(RTLD_DEFAULT, "ncclCommInitRank")) {
             // an RCCL mapped into the process without global symbols (PyTorch's own librccl.so is): take a handle to THAT copy
             std::string mapped;
             if (FILE* f = fopen("/proc/self/maps", "r")) {
@@ -58,13 +63,16 @@ Rccl& rccl()
                 fclose(f);
             }
             if (!mapped.empty()) h = dlopen(mapped.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
-            const char* names[] = {getenv("VLG_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            std::string last_error;
             for (const char* n : names) {
                 if (h) break;
-                if (!n || !*n) continue;
                 h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (!h) { const char* e = dlerror(); if (e) last_error = e; }      // (dlerror() clears the message: read it once)
             }
-            if (!h) { r.err = std::string("RCCL not found (librccl.so.1): ") + (dlerror() ? dlerror() : ""); return; }
+            if (!h) { r.err = "RCCL not found (librccl.so.1): " + last_error; return; }
+        }
+        if (h) {
             Dl_info di;
             void* any = dlsym(h, "ncclGetUniqueId");
             if (any && dladdr(any, &di) && di.dli_fname) r.path = di.dli_fname;
@@ -82,6 +90,8 @@ Rccl& rccl()
         VLG_BIND(Broadcast, "ncclBroadcast")
         VLG_BIND(AllReduce, "ncclAllReduce")
         VLG_BIND(AllGather, "ncclAllGather")
+        VLG_BIND(Send, "ncclSend")
+        VLG_BIND(Recv, "ncclRecv")
         VLG_BIND(GroupStart, "ncclGroupStart")
         VLG_BIND(GroupEnd, "ncclGroupEnd")
         VLG_BIND(GetErrorString, "ncclGetErrorString")

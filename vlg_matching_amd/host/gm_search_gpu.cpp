@@ -1,7 +1,8 @@
 // gm_search equivalent for the GPU index (benchmark/gapped-matching/src/gm_search.cpp): same command line (-c, -p),
-// same machine-readable "# key = value" lines on stdout.  Queries are searched as ONE batch; the per-query "TIMING"
-// and quartile lines therefore report the batch time divided by the number of patterns (-1 runs query by query, with real
-// per-query times).  -g N shards the pattern file over N GPUs of the node (index replicated, no exchange between the slices):
+// same machine-readable "# key = value" lines on stdout.  Queries are searched as ONE batch, so no clock can be put around a
+// single query as gm_search.cpp:96-107 does: the per-query "TIMING" and quartile lines (gm_search.cpp:142-160) carry the batch
+// time APPORTIONED BY WORK -- query i gets total x w_i / sum(w), w = 1 + the sum of its sub-patterns' occurrence counts, what
+// the matcher locates and joins for it -- and `# timing_mode` says so; -1 runs query by query with real per-query clocks.  -g N shards the pattern file over N GPUs of the node (index replicated, no exchange between the slices):
 // by default one process drives all of them (a host thread per device, replicas by peer copies); -g N -P starts ONE PROCESS PER
 // GPU instead -- rank 0 loads the index, its image goes to the others by one RCCL broadcast (vlg_index_broadcast), every rank
 // searches its slice and the counters are all-reduced.
@@ -32,11 +33,27 @@ static std::vector<gapped_pattern> parse_pattern_file(const std::string& file)
 }
 
 static void print_summary(std::vector<long long> timings, size_t num_results, size_t checksum, long long total_us, long long load_us, size_t n_pat, int n_gpus,
-                          const char* mode);
+                          const char* mode, const char* timing_mode);
 
-// One rank of `-g N -P`: nothing here has touched a GPU before the fork in main().  The communicator's id travels through a file
-// that rank 0 writes (atomically: write + rename) and the others wait for.
-static int run_rank(const std::string& col_dir, const std::string& pat_file, int rank, int n_ranks, const std::string& id_file, bool keep_sa)
+// the batch's time shared out over its queries by their work (index_fm_gpu::query_weights)
+static std::vector<long long> apportion(const index_fm_gpu& idx, const std::vector<gapped_pattern>& pats, long long total_us)
+{
+    std::vector<long long> t(pats.size(), 0);
+    if (pats.empty()) return t;
+    const std::vector<double> w = idx.query_weights(pats);
+    double sum = 0;
+    for (double x : w) sum += x;
+    for (size_t i = 0; i < pats.size(); ++i) t[i] = (long long)((double)total_us * w[i] / sum);
+    return t;
+}
+
+// One rank of `-g N -P`: nothing here has touched a GPU before the fork in main().  The communicator's id travels from rank 0 to
+// every other rank through a pipe the parent made before forking (id_fd: rank 0 holds the write ends of all of them, rank r the
+// read end of its own) -- nothing on the file system, nothing another user could pre-create or a recycled pid could leave behind.
+static bool write_all(int fd, const char* p, size_t n) { while (n) { const ssize_t w = write(fd, p, n); if (w <= 0) return false; p += w; n -= (size_t)w; } return true; }
+static bool read_all(int fd, char* p, size_t n) { while (n) { const ssize_t r = read(fd, p, n); if (r <= 0) return false; p += r; n -= (size_t)r; } return true; }
+
+static int run_rank(const std::string& col_dir, const std::string& pat_file, int rank, int n_ranks, const std::vector<int>& id_fd, bool keep_sa)
 {
     try {
         int ndev = 0;
@@ -45,16 +62,13 @@ static int run_rank(const std::string& col_dir, const std::string& pat_file, int
         vlg_comm_id id;
         if (rank == 0) {
             check(vlg_comm_unique_id(&id));
-            const std::string tmp = id_file + ".tmp";
-            { std::ofstream o(tmp, std::ios::binary); o.write(id.bytes, sizeof id.bytes); if (!o) throw std::runtime_error("cannot write " + tmp); }
-            if (rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("cannot publish " + id_file);
-        } else {
-            bool got = false;
-            for (int tries = 0; tries < 12000 && !got; ++tries) {                 // two minutes
-                std::ifstream i(id_file, std::ios::binary);
-                if (i && i.read(id.bytes, sizeof id.bytes)) got = true; else usleep(10000);
+            for (int r = 1; r < n_ranks; ++r) {
+                if (!write_all(id_fd[r], id.bytes, sizeof id.bytes)) throw std::runtime_error("cannot hand the communicator id to rank " + std::to_string(r));
+                close(id_fd[r]);
             }
-            if (!got) throw std::runtime_error("rank 0 never published the communicator id");
+        } else {
+            if (!read_all(id_fd[rank], id.bytes, sizeof id.bytes)) throw std::runtime_error("rank 0 never sent the communicator id");   // (EOF: rank 0 died)
+            close(id_fd[rank]);
         }
         void* comm = nullptr;
         check(vlg_comm_create(&id, n_ranks, rank, &comm));
@@ -84,9 +98,7 @@ static int run_rank(const std::string& col_dir, const std::string& pat_file, int
         check(vlg_comm_allreduce_sum_u64(comm, times.data(), (uint32_t)n_ranks, nullptr));
         const long long total_us = (long long)*std::max_element(times.begin(), times.end());
         if (rank == 0) {
-            std::vector<long long> timings(pats.size(), pats.empty() ? 0 : total_us / (long long)pats.size());
-            print_summary(timings, sums[0], sums[1], total_us, load_us, pats.size(), n_ranks, "processes");
-            remove(id_file.c_str());
+            print_summary(apportion(cidx, pats, total_us), sums[0], sums[1], total_us, load_us, pats.size(), n_ranks, "processes", "batch_apportioned_by_occurrences");
         }
         vlg_comm_destroy(comm);
         return 0;
@@ -114,16 +126,30 @@ int main(int argc, char* const argv[])
         return EXIT_FAILURE;
     }
     if (per_process) {
-        // fork BEFORE anything initialises the GPU (no HIP call has been made: the C-ABI is only touched inside the children)
-        const std::string id_file = "/tmp/vlg_comm_id_" + std::to_string((long long)getpid());
-        remove(id_file.c_str());
+        // fork BEFORE anything initialises the GPU (no HIP call has been made: the C-ABI is only touched inside the children).
+        // Not under a profiler whose preloaded library initialises the GPU before main() (rocprofv3 --pmc does): profile -g N
+        // without -P, or a single rank.
+        std::vector<int> rd(n_gpus, -1), wr(n_gpus, -1);             // pipe r carries the communicator id from rank 0 to rank r
+        for (int r = 1; r < n_gpus; ++r) {
+            int fds[2];
+            if (pipe(fds) != 0) { perror("pipe"); return EXIT_FAILURE; }
+            rd[r] = fds[0]; wr[r] = fds[1];
+        }
         std::vector<pid_t> kids;
         for (int r = 0; r < n_gpus; ++r) {
             const pid_t pid = fork();
             if (pid < 0) { perror("fork"); return EXIT_FAILURE; }
-            if (pid == 0) _exit(run_rank(col_dir, pat_file, r, n_gpus, id_file, keep_sa));
+            if (pid == 0) {
+                // rank 0 keeps the write ends, rank r its own read end; every other descriptor is closed so that a dead rank 0 reads as EOF
+                for (int j = 1; j < n_gpus; ++j) {
+                    if (r != 0) close(wr[j]);
+                    if (j != r) close(rd[j]);
+                }
+                _exit(run_rank(col_dir, pat_file, r, n_gpus, r == 0 ? wr : rd, keep_sa));
+            }
             kids.push_back(pid);
         }
+        for (int r = 1; r < n_gpus; ++r) { close(rd[r]); close(wr[r]); }
         int rc = 0;
         size_t left = kids.size();
         while (left) {                                               // any rank that fails ends the others (they would wait in a collective)
@@ -134,7 +160,6 @@ int main(int argc, char* const argv[])
             const int code = WIFEXITED(status) ? WEXITSTATUS(status) : EXIT_FAILURE;
             if (code && !rc) { rc = code; for (pid_t k : kids) if (k != done) kill(k, SIGTERM); }
         }
-        remove(id_file.c_str());
         return rc;
     }
     try {
@@ -164,8 +189,9 @@ int main(int argc, char* const argv[])
             for (auto& r : res) for (auto pos : r.positions) { checksum += pos; num_results++; }
         }
         long long total_us = duration_cast<microseconds>(high_resolution_clock::now() - t0).count();
-        if (!one_by_one) timings.assign(pats.size(), pats.empty() ? 0 : total_us / (long long)pats.size());
-        print_summary(timings, num_results, checksum, total_us, load_us, pats.size(), n_gpus, n_gpus > 1 ? "threads" : "single");
+        if (!one_by_one) timings = apportion(idx, pats, total_us);       // (after the clock has stopped: one more backward-search pass)
+        print_summary(timings, num_results, checksum, total_us, load_us, pats.size(), n_gpus, n_gpus > 1 ? "threads" : "single",
+                      one_by_one ? "per_query_clock" : "batch_apportioned_by_occurrences");
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << std::endl;
         return EXIT_FAILURE;
@@ -174,7 +200,7 @@ int main(int argc, char* const argv[])
 }
 
 static void print_summary(std::vector<long long> timings, size_t num_results, size_t checksum, long long total_us, long long load_us, size_t n_pat, int n_gpus,
-                          const char* mode)
+                          const char* mode, const char* timing_mode)
 {
     for (auto t : timings) std::cout << "TIMING = " << t << std::endl;
     std::sort(timings.begin(), timings.end());
@@ -194,4 +220,5 @@ static void print_summary(std::vector<long long> timings, size_t num_results, si
     std::cout << "# num_patterns = " << n_pat << std::endl;
     std::cout << "# num_gpus = " << n_gpus << std::endl;
     std::cout << "# gpu_mode = " << mode << std::endl;
+    std::cout << "# timing_mode = " << timing_mode << std::endl;
 }

@@ -180,26 +180,37 @@ class index_fm_gpu
     // Contiguous slices of equal estimated work for n shards: the sum of the SA-interval sizes of a query's sub-patterns (0 when one
     // of them does not occur: such a query locates nothing), from one backward-search pass on this index -- what SURVEY.md 8(e)
     // shards by.  Every rank of a multi-process run computes the same cuts from its own replica.  -> cut[n + 1]
-    std::vector<uint64_t> work_cuts(const std::vector<gapped_pattern>& pats, int n, int dialect = VLG_DIALECT_BENCHMARK) const
+    // work of every query as the matcher sees it before it runs: 1 + the sum of its sub-patterns' occurrence counts (0 + 1 for a
+    // query with an empty list: nothing of it is located) -- sdsl::count per sub-pattern, one backward-search pass on the device
+    std::vector<double> query_weights(const std::vector<gapped_pattern>& pats, int dialect = VLG_DIALECT_BENCHMARK) const
     {
-        std::vector<uint64_t> cut(n + 1, pats.size());
-        cut[0] = 0;
-        if (n <= 1 || pats.empty()) return cut;
+        std::vector<double> w(pats.size(), 1.0);
+        if (pats.empty()) return w;
         parsed_batch pb;
         parse(pats, 0, pats.size(), dialect, pb);
         std::vector<uint32_t> k(pats.size() + 1);
         std::vector<uint64_t> occ(vlg_queries_subpatterns(pb.q) + 1);
         check(vlg_queries_k(pb.q, k.data()));
         check(vlg_queries_occurrences(m_idx, pb.q, occ.data(), nullptr));
-        std::vector<double> cum(pats.size() + 1, 0.0);
         size_t s = 0;
         for (size_t i = 0; i < pats.size(); ++i) {
-            double w = 0;
+            double sum = 0;
             bool dead = false;
-            for (uint32_t j = 0; j < k[i]; ++j) { w += (double)occ[s + j]; dead |= occ[s + j] == 0; }
+            for (uint32_t j = 0; j < k[i]; ++j) { sum += (double)occ[s + j]; dead |= occ[s + j] == 0; }
             s += k[i];
-            cum[i + 1] = cum[i] + (dead ? 0.0 : w) + 1.0;
+            w[i] = (dead ? 0.0 : sum) + 1.0;
         }
+        return w;
+    }
+
+    std::vector<uint64_t> work_cuts(const std::vector<gapped_pattern>& pats, int n, int dialect = VLG_DIALECT_BENCHMARK) const
+    {
+        std::vector<uint64_t> cut(n + 1, pats.size());
+        cut[0] = 0;
+        if (n <= 1 || pats.empty()) return cut;
+        const std::vector<double> w = query_weights(pats, dialect);
+        std::vector<double> cum(pats.size() + 1, 0.0);
+        for (size_t i = 0; i < pats.size(); ++i) cum[i + 1] = cum[i] + w[i];
         for (int d = 1; d < n; ++d) {                             // the nearer of the two cuts around the target
             const double target = cum.back() * d / n;
             size_t i = (size_t)(std::lower_bound(cum.begin() + 1, cum.end(), target) - (cum.begin() + 1));
