@@ -367,7 +367,16 @@ typedef struct {
                                      would locate query by query)                                 */
     uint64_t join_slots;          /* list elements the join passes evaluated: the non-final lists of every live
                                      query, after the window filter                               */
+    uint64_t locate_mode;         /* how the last super-chunk's occurrences were located: VLG_LOCATE_*  */
 } vlg_result_summary;
+/* csa[i] = iterated LF to a sampled index (csa_wt.hpp:335-348), organised per batch as
+ *   WALKS     one walk per occurrence (few occurrences; integer alphabets; workspace option "sweep" = 0)
+ *   SWEEP     all occurrences advance together in SA order, walks that meet share their LF steps ("trail" = 1)
+ *   UNSAMPLE  a batch that locates a large part of all text positions ("unsample_pct" per cent, default 40): one walker per SA
+ *             sample rebuilds the whole suffix array -- n LF steps whatever the batch, each SA index visited once -- and the
+ *             lists are copied out of it; recomputed for every batch, nothing is kept
+ *   COPY      an index that keeps every SA value (sa_sample_dens = 1): no LF step at all                               */
+enum { VLG_LOCATE_NONE = 0, VLG_LOCATE_WALKS = 1, VLG_LOCATE_SWEEP = 2, VLG_LOCATE_UNSAMPLE = 3, VLG_LOCATE_COPY = 4 };
 
 vlg_status vlg_result_summary_get(const vlg_result* r, vlg_result_summary* s);
 /* Copy to host.  counts[q] = matches of query q; offsets = exclusive prefix sum (n_queries+1);

@@ -518,6 +518,48 @@ def test_locate_trail_sharing_equals_plain_locate_and_oracle(V, oracle, name, se
         assert b.tuples(i).tolist() == o.search(qs[i]).tolist(), qs[i]
 
 
+@pytest.mark.parametrize("name,seed,tail,force", [("dna_50k", 81, 16, ""), ("zipf40", 82, 1, ""), ("100a", 83, 4, ""), ("dna_skew", 84, 1 << 30, ""),
+                                                  ("abracadabra", 85, 1, ""), ("zipf40", 86, 64, "2"), ("dna_50k", 87, 1, "2")])
+def test_locate_by_unsampling_equals_sweep_walks_and_oracle(V, oracle, monkeypatch, name, seed, tail, force):
+    """K3u: a dense batch rebuilds the whole suffix array from the SA samples -- one walker per sample, every SA index visited once,
+    n - n_samples LF steps whatever the batch -- and copies its intervals out of it.  Same positions, tuples and checksums as the
+    sorted sweep with shared trails, the per-occurrence walks and the oracle; on plain and rrr bit-vectors, with narrow and (force =
+    "2": BASELINE config 4's mix) 33-bit SA indices, with the walkers finished by the sorted rounds or by the stragglers' kernel."""
+    from vlg_matching_amd.index import Workspace
+    if force:
+        monkeypatch.setenv("VLG_FORCE_POS64", force)
+    text = TEXTS[name]()
+    o = oracle.Index.from_text(text)
+    rng = np.random.default_rng(seed)
+    qs = random_queries(text, rng, 300, kmax=4, mmax=4)
+    t = text.decode("latin-1")
+    qs += [t[:1], t[:2], t[:3], t[1:2], t[:1] + ".{0,9}?" + t[:2], t[-1:], t[-2:]]
+    want = [o.search(q).tolist() for q in qs]
+    plain = V.VlgIndex.build(text)
+    for idx in (plain, plain.compress(), V.VlgIndex.build(text, dens=5)):
+        ws_w, ws_s, ws_u = Workspace(), Workspace(), Workspace()
+        ws_w.set_option("sweep", 0)
+        for ws in (ws_s, ws_u):
+            ws.set_option("sweep_min", 1)
+            ws.set_option("sweep_tail", 16)
+        ws_s.set_option("unsample_pct", 0)
+        for k_, v_ in (("unsample_pct", 1), ("unsample_min", 1), ("unsample_tail", tail)):
+            ws_u.set_option(k_, v_)
+        w, s_, u = idx.search(qs, workspace=ws_w), idx.search(qs, workspace=ws_s), idx.search(qs, workspace=ws_u)
+        assert (w.summary["locate_mode"], s_.summary["locate_mode"], u.summary["locate_mode"]) == (V.capi.LOCATE_WALKS, V.capi.LOCATE_SWEEP, V.capi.LOCATE_UNSAMPLE)
+        info = idx.info()
+        # LF is a permutation of the SA indices and every walker ends ON a sampled index: each index is reached by exactly one step
+        assert u.summary["lf_steps"] == info["n"] or info["sigma"] == 1
+        st = ws_u.kernel_stats()
+        assert st["locate_resolve"]["launches"] == 0 and st["locate"]["launches"] >= 2
+        for k in ("n_matches", "checksum", "n_tuple_values", "located_occurrences", "logical_occurrences"):
+            assert w.summary[k] == s_.summary[k] == u.summary[k], k
+        for x, y, z in zip(w.fetch(), s_.fetch(), u.fetch()):
+            assert (x == y).all() and (x == z).all()
+        for i in range(len(qs)):
+            assert u.tuples(i).tolist() == want[i], qs[i]
+
+
 def test_first_positions_only(V, oracle):
     """Workspace option "tuples" = 0: what the benchmark's gapped_search_result holds (index_sasearch.hpp:58-118) -- counts,
     first positions and checksum as with tuples, no tuple values, and a tuples buffer is refused."""

@@ -6,6 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
+LOCATE_NONE, LOCATE_WALKS, LOCATE_SWEEP, LOCATE_UNSAMPLE, LOCATE_COPY = range(5)
 OK, E_INVALID, E_NO_DEVICE, E_OOM, E_PARSE, E_ZERO_BYTE, E_UNSUPPORTED, E_WORKSPACE, E_INTERNAL = range(9)
 DIALECT_LIBRARY, DIALECT_BENCHMARK = 0, 1
 
@@ -40,7 +41,7 @@ class IndexInfo(C.Structure):
 class ResultSummary(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_queries", "n_matches", "checksum", "n_tuple_values", "located_occurrences",
                                            "lf_steps", "wt_levels_locate", "wt_levels_bsearch", "n_chunks",
-                                           "logical_occurrences", "join_slots")]
+                                           "logical_occurrences", "join_slots", "locate_mode")]
 
 
 class ParsedQuery(C.Structure):

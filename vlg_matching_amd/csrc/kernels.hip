@@ -850,6 +850,170 @@ __global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict
     block_add<1>(v, dst);
 }
 
+// =============================================================================================
+// K3u: locate by UNSAMPLING the suffix array (dense batches).
+//
+// csa[i] walks LF from i to the next sampled index (csa_wt.hpp:335-348).  Trail sharing (above) already lets the walks of one batch
+// share their steps; when a batch asks for a large part of all text positions (BASELINE configs 3 and 4: 60 % of them) the limit of
+// that idea is cheaper still: start ONE walker at every SA sample (i = d j, SA[i] = samples[j]) and let it walk LF until it stands on
+// the next sampled index, writing SA[LF(i)] = SA[i] - 1 on every step (suffix_array_helper.hpp:336-349).  The walks are disjoint
+// and cover every SA index exactly once: n LF steps whatever the batch holds, no trail table (8 B x n), no records, no pointer
+// jumping afterwards -- the occurrence lists are then plain copies of SA intervals (sa_dense_copy_kernel).  Everything is recomputed
+// from the index's samples for every batch; nothing survives the call.  The walkers are kept in ascending SA-index order exactly as
+// in the sorted sweep (stable partition by the symbol read), so neighbouring lanes read neighbouring super-blocks.
+// Element words: narrow  val = SA value << 32 | SA index,  key = symbol;
+//                wide    val = (SA value & 2^31 - 1) << 33 | SA index (33 bits),  key = symbol | (bit 31 of the SA value) << 15
+// (a wide index has n <= 2^32 + 1 here, so every value a walker WRITES is a text position < 2^32: only the sentinel suffix's own
+// sample, SA[0] = n - 1, can be 2^32, and it is never written through a walker nor part of a pattern's interval).
+// =============================================================================================
+constexpr uint16_t kUnsampleDead = 0x7FFFu;                   // key of a walker that has arrived (sorts behind every symbol)
+
+template <bool kWide> struct WalkerWord;
+template <> struct WalkerWord<false> {
+    static __device__ __forceinline__ void unpack(uint64_t w, uint16_t, uint64_t& i, uint32_t& v) { i = w & 0xFFFFFFFFull; v = (uint32_t)(w >> 32); }
+    static __device__ __forceinline__ uint64_t word(uint64_t i, uint32_t v) { return ((uint64_t)v << 32) | i; }
+    static __device__ __forceinline__ uint16_t key(uint32_t c, uint32_t) { return (uint16_t)c; }
+};
+template <> struct WalkerWord<true> {
+    static __device__ __forceinline__ void unpack(uint64_t w, uint16_t k, uint64_t& i, uint32_t& v)
+    {
+        i = w & ((1ull << 33) - 1);
+        v = (uint32_t)(w >> 33) | ((uint32_t)(k >> 15) << 31);
+    }
+    static __device__ __forceinline__ uint64_t word(uint64_t i, uint32_t v) { return ((uint64_t)(v & 0x7FFFFFFFu) << 33) | i; }
+    static __device__ __forceinline__ uint16_t key(uint32_t c, uint32_t v) { return (uint16_t)(c | ((v >> 31) << 15)); }
+};
+
+// one LF step from SA index i: the symbol read (compact) and LF(i)
+template <class BV, bool kWide>
+__device__ __forceinline__ uint64_t lf_step(const IndexView& iv, const WalkLds<BV>& s, uint64_t i, uint32_t& c, uint32_t& n_lv)
+{
+    using walk_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;      // node-relative positions: < n
+    uint32_t v = 0;
+    walk_t pos = (walk_t)i;
+    for (;;) {                                               // inverse_select: wt_pc.hpp:385-402
+        const DNode nd = s.nodes[v];
+        uint32_t bit;
+        walk_t r1;
+        BV::rank_bit(iv, s.sh, nd.base, pos, r1, bit);
+        ++n_lv;
+        pos = bit ? r1 : pos - r1;
+        const uint32_t ch = bit ? nd.child[1] : nd.child[0];
+        if (ch & kLeafFlag) { c = ch & ~kLeafFlag; break; }
+        v = ch;
+    }
+    return s.C[c] + (uint64_t)pos;                           // LF: suffix_array_helper.hpp:341-348
+}
+
+// kFirst: round 0 -- element e is sample e (no words read); otherwise the walkers [0, count) of val / key, dead ones skipped (the
+// host may pass a count from a few rounds ago: the dead are at the end, the partition keeps them there).
+template <class BV, bool kWide, bool kFirst>
+__global__ void __launch_bounds__(256) unsample_step_kernel(IndexView iv, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count,
+                                                            uint32_t* __restrict__ sa, unsigned long long* __restrict__ stats /* lf, levels */,
+                                                            unsigned long long* __restrict__ n_done)
+{
+    __shared__ WalkLds<BV> s;
+    stage_walk(s, iv);
+    using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
+    const sample_t* __restrict__ samples = reinterpret_cast<const sample_t*>(iv.samples);
+    const uint32_t dens = iv.dens, dmask = dens - 1;
+    const bool pow2 = (dens & dmask) == 0;
+    uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t i;
+        uint32_t v;
+        if (kFirst) {
+            i = e * dens;
+            const uint64_t sv = (uint64_t)samples[e];
+            v = (uint32_t)sv;                                // (2^32 for the sentinel suffix of a wide index: v - 1 below is still right)
+            sa[i] = v;
+            if (iv.sigma == 1) { key[e] = kUnsampleDead; ++n_fin; continue; }      // degenerate: only the sentinel exists
+        } else {
+            const uint16_t k = key[e];
+            if ((k & 0x7FFFu) == kUnsampleDead) continue;
+            WalkerWord<kWide>::unpack(val[e], k, i, v);
+        }
+        uint32_t c;
+        const uint64_t i2 = lf_step<BV, kWide>(iv, s, i, c, n_lv);
+        ++n_lf;
+        const uint32_t v2 = (!kWide && v == 0) ? (uint32_t)(iv.n - 1) : v - 1;      // SA[LF(i)] = SA[i] - 1 (mod n): csa_wt.hpp:343-347
+        const bool arrived = pow2 ? ((i2 & dmask) == 0) : (i2 % dens == 0);
+        if (arrived) { key[e] = kUnsampleDead; ++n_fin; }
+        else {
+            sa[i2] = v2;
+            val[e] = WalkerWord<kWide>::word(i2, v2);
+            key[e] = WalkerWord<kWide>::key(c, v2);
+        }
+    }
+    unsigned long long v3[3] = {n_lf, n_lv, n_fin};
+    unsigned long long* const dst[3] = {&stats[0], &stats[1], n_done};
+    block_add<3>(v3, dst);
+}
+
+// The last walkers (how long a walk is, is geometrically distributed: a few are still on their way after 100 rounds) finish without
+// being sorted any more, lane by lane with refill as in locate_kernel: a wave owns a slice of the walkers, a lane that arrives pulls
+// the next one.
+template <class BV, bool kWide>
+__global__ void __launch_bounds__(256) unsample_tail_kernel(IndexView iv, const uint64_t* __restrict__ val, const uint16_t* __restrict__ key, uint64_t total,
+                                                            uint32_t per_wave, uint32_t* __restrict__ sa, unsigned long long* __restrict__ stats)
+{
+    __shared__ WalkLds<BV> s;
+    stage_walk(s, iv);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint64_t next = wave * per_wave;
+    const uint64_t slice_end = next + per_wave < total ? next + per_wave : total;
+    const uint32_t dens = iv.dens, dmask = dens - 1;
+    const bool pow2 = (dens & dmask) == 0;
+    uint64_t i = 0;
+    uint32_t v = 0, node = 0;
+    bool active = false, need = true;
+    uint32_t n_lf = 0, n_lv = 0;
+    for (;;) {
+        const unsigned long long m = __ballot(need);
+        if (m) {
+            const uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
+            if (need) {
+                const uint64_t cand = next + before;
+                active = false;
+                if (cand < slice_end) {
+                    const uint16_t k = key[cand];
+                    if ((k & 0x7FFFu) != kUnsampleDead) { WalkerWord<kWide>::unpack(val[cand], k, i, v); node = 0; active = true; }
+                }
+                need = !active && cand < slice_end;          // a dead walker: take another one next turn
+            }
+            next += __popcll(m);
+        }
+        if (!__any(active) && !__any(need)) break;
+        if (active) {
+            const DNode nd = s.nodes[node];
+            uint32_t bit;
+            uint64_t r1;
+            BV::rank_bit(iv, s.sh, nd.base, i, r1, bit);
+            ++n_lv;
+            const uint64_t ni = bit ? r1 : i - r1;
+            const uint32_t ch = bit ? nd.child[1] : nd.child[0];
+            if (ch & kLeafFlag) {
+                i = s.C[ch & ~kLeafFlag] + ni;
+                v = (!kWide && v == 0) ? (uint32_t)(iv.n - 1) : v - 1;
+                node = 0;
+                ++n_lf;
+                const bool arrived = pow2 ? ((i & dmask) == 0) : (i % dens == 0);
+                if (arrived) { need = true; active = false; }
+                else sa[i] = v;
+            } else {
+                i = ni;
+                node = ch;
+            }
+        }
+    }
+    if (stats) {
+        unsigned long long v2[2] = {n_lf, n_lv};
+        unsigned long long* const dst[2] = {&stats[0], &stats[1]};
+        block_add<2>(v2, dst);
+    }
+}
+
 // ISA samples (csa_sampling_strategy.hpp:626-642: isa_sample[SA[i] / d'] = i for every i with SA[i] % d' == 0), computed from the
 // index alone: a lane starts at one SA sample (i, SA[i]) and walks LF -- (LF(i), SA[i] - 1) -- until the next sampled
 // index, so every SA index is visited exactly once and every text position passes by with its SA index.
@@ -1094,6 +1258,95 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     }
     return VLG_OK;
 }
+// K3u (above): the whole suffix array into sa_full (n words of 32 bits), then the SA intervals of the lists into d_out.
+// val / key buffers for n_samples walkers; temp as for the sweep.  Rounds are enqueued kUnsampleSync at a time: the count of walkers
+// still on their way is read back only then (the kernels skip the ones that have arrived, which the partition keeps at the end).
+constexpr uint32_t kUnsampleSync = 4;
+template <bool kWide>
+vlg_status launch_unsample(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total, uint32_t* d_out,
+                           uint32_t* sa_full, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp, size_t temp_bytes,
+                           unsigned long long* d_counter, unsigned long long* h_done /* 8 pinned bytes */, unsigned long long* d_stats, uint64_t tail_threshold,
+                           hipStream_t stream, LaunchTimer* timer, const std::function<vlg_status()>* while_first_step)
+{
+    bool hook_due = while_first_step != nullptr;
+    if (iv.sampling != kSamplingSaOrder || iv.dens < 2) return fail(VLG_E_INTERNAL, "unsampling needs SA-order samples of density >= 2");
+    if (iv.sample_bytes != (kWide ? 8u : 4u)) return fail(VLG_E_INTERNAL, "unsampling: sample width does not match the instantiation");
+    if (iv.n > (1ull << 32) + 1 || (!kWide && iv.n > (1ull << 32))) return fail(VLG_E_UNSUPPORTED, "unsampling: text too long for 32-bit positions");
+    if (iv.sigma >= 0x7FFFu) return fail(VLG_E_INTERNAL, "unsampling: alphabet too large for the key");
+    const bool rrr = iv.bv_kind == kBvRrr63;
+    const unsigned bits = bit_width64(iv.sigma);            // keys 0 .. sigma - 1, dead = all ones in these bits too (sorts last)
+    uint64_t alive = iv.n_samples, done_total = 0;
+    VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
+    uint32_t round = 0;
+    while (alive > tail_threshold) {
+        for (uint32_t r = 0; r < kUnsampleSync; ++r, ++round) {
+            if (timer) timer->begin(0);
+            const dim3 grid(grid_for(alive, 8192));
+#define VLG_UNS(BV) do { if (round == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(unsample_step_kernel<BV, kWide, true>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, sa_full, d_stats, d_counter); \
+                         else hipLaunchKernelGGL(HIP_KERNEL_NAME(unsample_step_kernel<BV, kWide, false>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, sa_full, d_stats, d_counter); } while (0)
+            if (rrr) VLG_UNS(RrrBV); else VLG_UNS(PlainBV);
+#undef VLG_UNS
+            if (timer) timer->end(0);
+            VLG_HIP_TRY(hipGetLastError());
+            size_t tb = temp_bytes;
+            if (timer) timer->begin(1, 20ull * alive);
+            rocprim::double_buffer<uint16_t> dk(key_a, key_b);
+            rocprim::double_buffer<uint64_t> dv(val_a, val_b);
+            const hipError_t se = rocprim::radix_sort_pairs(temp, tb, dk, dv, alive, 0, bits, stream);
+            if (timer) timer->end(1);
+            VLG_HIP_TRY(se);
+            key_a = dk.current(); key_b = dk.alternate();
+            val_a = dv.current(); val_b = dv.alternate();
+            if (hook_due) { hook_due = false; if (vlg_status hs = (*while_first_step)()) return hs; }
+        }
+        VLG_HIP_TRY(hipMemcpyAsync(h_done, d_counter, 8, hipMemcpyDeviceToHost, stream));
+        VLG_HIP_TRY(hipStreamSynchronize(stream));
+        done_total = *h_done;
+        if (done_total > iv.n_samples) return fail(VLG_E_INTERNAL, "unsampling: more walkers arrived than were started");
+        alive = iv.n_samples - done_total;
+        if (round > (1u << 20)) return fail(VLG_E_INTERNAL, "unsampling did not converge");
+    }
+    if (round == 0 && iv.n_samples) {
+        // too few walkers for a single sorted round: round 0 still makes their words (and writes the samples themselves)
+        if (timer) timer->begin(0);
+        const dim3 grid(grid_for(alive, 8192));
+        if (rrr) hipLaunchKernelGGL(HIP_KERNEL_NAME(unsample_step_kernel<RrrBV, kWide, true>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, sa_full, d_stats, d_counter);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(unsample_step_kernel<PlainBV, kWide, true>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, sa_full, d_stats, d_counter);
+        if (timer) timer->end(0);
+        VLG_HIP_TRY(hipGetLastError());
+        ++round;
+    }
+    if (hook_due) { hook_due = false; if (vlg_status hs = (*while_first_step)()) return hs; }
+    if (alive || round == 1) {
+        // (after an unsorted round 0 the dead are anywhere: the tail looks at all of them)
+        const uint64_t span = round == 1 ? iv.n_samples : alive;
+        const uint64_t target_waves = 256ull * 32 * 4;
+        uint64_t per_wave = (span + target_waves - 1) / target_waves;
+        per_wave = std::min<uint64_t>(std::max<uint64_t>(per_wave, 64 * 4), 1u << 20);
+        const uint64_t waves = (span + per_wave - 1) / per_wave;
+        const dim3 grid((uint32_t)((waves + 3) / 4));
+        if (timer) timer->begin(0);
+        if (rrr) hipLaunchKernelGGL(HIP_KERNEL_NAME(unsample_tail_kernel<RrrBV, kWide>), grid, dim3(256), 0, stream, iv, val_a, key_a, span, (uint32_t)per_wave, sa_full, d_stats);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(unsample_tail_kernel<PlainBV, kWide>), grid, dim3(256), 0, stream, iv, val_a, key_a, span, (uint32_t)per_wave, sa_full, d_stats);
+        if (timer) timer->end(0);
+        VLG_HIP_TRY(hipGetLastError());
+    }
+    if (total) {
+        if (timer) timer->begin(0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_dense_copy_kernel<uint32_t, uint32_t>), dim3(grid_for((total + 7) / 8, 32768)), dim3(256), 0, stream,
+                           sa_full, d_l, d_out_off, n_pat, total, d_out);
+        if (timer) timer->end(0);
+        VLG_HIP_TRY(hipGetLastError());
+    }
+    return VLG_OK;
+}
+template vlg_status launch_unsample<false>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint32_t*, uint32_t*, uint64_t*, uint64_t*,
+                                           uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, unsigned long long*, uint64_t, hipStream_t,
+                                           LaunchTimer*, const std::function<vlg_status()>*);
+template vlg_status launch_unsample<true>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint32_t*, uint32_t*, uint64_t*, uint64_t*,
+                                          uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, unsigned long long*, uint64_t, hipStream_t,
+                                          LaunchTimer*, const std::function<vlg_status()>*);
+
 #define VLG_SWEEP_INST(P, W)                                                                                                          \
     template vlg_status launch_locate_sweep<P, W>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, P*, uint64_t*, \
                                                   uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, \

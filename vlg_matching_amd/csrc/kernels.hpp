@@ -31,6 +31,14 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
                                hipStream_t stream, LaunchTimer* timer, uint64_t* trail, uint64_t* rec, uint32_t* trail_gen,
                                const std::function<vlg_status()>* while_first_step = nullptr);
+// K3u: the whole suffix array reconstructed from the samples (one LF walker per sample, n LF steps in all) into sa_full (n x 4 B),
+// then the SA intervals of the lists copied into d_out.  For batches that locate a large part of all text positions.
+// Scratch: val_a / val_b (8 B) and key_a / key_b (2 B) for n_samples walkers, temp as for the sweep, counter 8 B.
+template <bool kWide>
+vlg_status launch_unsample(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total, uint32_t* d_out,
+                           uint32_t* sa_full, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp, size_t temp_bytes,
+                           unsigned long long* d_counter, unsigned long long* h_done /* 8 pinned bytes */, unsigned long long* d_stats, uint64_t tail_threshold,
+                           hipStream_t stream, LaunchTimer* timer, const std::function<vlg_status()>* while_first_step = nullptr);
 template <typename T> vlg_status launch_narrow(const uint64_t* d_in, T* d_out, uint64_t count, hipStream_t stream);
 template <typename T> vlg_status launch_widen(const T* d_in, uint64_t* d_out, uint64_t count, hipStream_t stream);
 

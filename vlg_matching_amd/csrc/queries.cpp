@@ -157,7 +157,9 @@ extern "C" vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_of
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const uint64_t n_slices = n_queries >= 8192 ? std::min<uint64_t>(std::min<unsigned>(hw, 16u), n_queries / 2048) : 1;
     std::vector<Slice> slices(std::max<uint64_t>(n_slices, 1));
-    auto work = [&](uint64_t si) {
+    // (no exception may leave a worker thread -- std::terminate -- or cross the C boundary: a slice that runs out of memory records
+    // VLG_E_OOM like any other error of its queries)
+    auto work_body = [&](uint64_t si) {
         Slice& sl = slices[si];
         const uint64_t b = n_queries * si / slices.size(), e = n_queries * (si + 1) / slices.size();
         sl.k.reserve(e - b); sl.end_len.reserve(e - b);
@@ -181,12 +183,25 @@ extern "C" vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_of
             sl.end_len.push_back(st ? 0 : p.end_len);
         }
     };
+    bool oom = false;
+    auto work = [&](uint64_t si) {
+        try { work_body(si); }
+        catch (...) { slices[si].first_err = VLG_E_OOM; slices[si].first_why = "out of host memory while parsing the batch"; }
+    };
     if (slices.size() == 1) work(0);
     else {
         std::vector<std::thread> th;
-        for (uint64_t si = 0; si < slices.size(); ++si) th.emplace_back(work, si);
+        uint64_t started = 0;
+        try {
+            th.reserve(slices.size());
+            for (; started < slices.size(); ++started) th.emplace_back(work, started);
+        } catch (...) {}                                           // no more threads to be had: the rest of the slices on this one
         for (auto& t : th) t.join();
+        for (uint64_t si = started; si < slices.size(); ++si) work(si);
     }
+    for (const Slice& sl : slices) oom |= sl.first_err == VLG_E_OOM;
+    if (oom) { delete q; return fail(VLG_E_OOM, "out of host memory while parsing the batch"); }
+    try {
     vlg_status first_err = VLG_OK;
     std::string first_why;
     uint64_t tot_blob = 0, tot_sub = 0;
@@ -204,6 +219,7 @@ extern "C" vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_of
     }
     q->nsub = q->suboff.size() - 1;
     if (first_err && !h_status) { delete q; return fail(first_err, first_why); }
+    } catch (const std::bad_alloc&) { delete q; return fail(VLG_E_OOM, "out of host memory while assembling the batch"); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete q; return fail(VLG_E_NO_DEVICE, "no HIP device available"); }
     if (vlg_status st = upload_queries(q)) { vlg_queries_destroy(q); return st; }

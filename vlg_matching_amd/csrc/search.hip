@@ -74,6 +74,15 @@ struct vlg_workspace {
     uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
     uint64_t sweep_tail = 1ull << 22;   // stragglers of a sweep are finished one lane each (C3, ms per batch: 2^20 214.0, 2^22 213.4, 2^24 213.7, 2^26 213.8)
+    // K3u (kernels.hip): a batch that locates at least unsample_pct per cent of all text positions rebuilds the whole suffix array from
+    // the samples (n LF steps, no trails, no records) and copies its SA intervals out of it.  0 = never (the default: measured on
+    // BASELINE config 3, 60 % of all positions located -- 76.6 ms against 61.0 ms for sweep + partition + resolve: ~110 sparse rounds
+    // stream the whole wavelet tree each and scatter 4 bytes per step); needs dedup + trail (the options that let the walks of a
+    // batch share LF steps at all) and SA-order samples.
+    uint32_t unsample_pct = 0;
+    uint64_t unsample_min = 1ull << 28;     // ... and at least this many occurrences: ~110 rounds of two launches each are a fixed cost
+    uint64_t unsample_tail = 1ull << 20;    // walkers left when the sorted rounds end and the lanes finish them one by one
+    uint64_t sample_reads = 0;              // SA samples read by the locate stage of the batch in work (algorithmic bytes)
     // trail table of the sorted sweep: it lives at the head of the arena and carries generation stamps, so it is cleared once, not per batch
     uint32_t trail_gen = 0;             // generation of the last sweep that wrote it; 0 = content unknown
     uint64_t trail_n = 0;               // text length it was last used for
@@ -260,6 +269,9 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
         return ws_reserve(ws, b + b / 96 + (256ull << 20));
     }
     if (!strcmp(name, "sweep_tail")) { ws->sweep_tail = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "unsample_pct")) { ws->unsample_pct = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20)); return VLG_OK; }
+    if (!strcmp(name, "unsample_tail")) { ws->unsample_tail = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "unsample_min")) { ws->unsample_min = (uint64_t)value; return VLG_OK; }
     return fail(VLG_E_INVALID, std::string("unknown workspace option ") + name);
 }
 
@@ -664,13 +676,22 @@ __global__ void lists_check_kernel(const T* __restrict__ lists, const uint64_t* 
 
 inline bool check_sort_enabled() { static const bool on = [] { const char* e = getenv("VLG_CHECK_SORT"); return e && e[0] == '1'; }(); return on; }
 
+// K3u (kernels.hip): does a share of `acc` occurrences of this index's text pay for rebuilding the whole suffix array?
+inline bool unsample_applies(const vlg_index* idx, const vlg_workspace* ws, uint64_t acc)
+{
+    if (!ws->unsample_pct || !ws->sweep || !ws->trail || !ws->dedup || idx->is_int) return false;
+    if (idx->hdr.sampling != kSamplingSaOrder || idx->hdr.dens < 2 || idx->hdr.n > (1ull << 32) + 1 || idx->hdr.sigma >= 0x7FFFu) return false;
+    return acc >= ws->sweep_min && acc >= ws->unsample_min && (__uint128_t)acc * 100 >= (__uint128_t)idx->hdr.n * ws->unsample_pct;
+}
+
 // ---- physical pass: locate + sort every distinct interval used by queries [Q0,Q1) -------------------
 template <typename pos_t>
 vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* res, const std::vector<uint32_t>& dlist /* distinct ids */,
                           const Plan& pl, Arena& A, pos_t*& P_out, std::vector<uint32_t>& poff /* per distinct id -> offset (size dl) */,
                           uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats, pos_t*& Pc_out, uint64_t& pc_cap,
                           uint64_t* trail /* n words at the head of the arena when trails are shared, else null */,
-                          bool wide /* SA indices need 33 bits / 64-bit samples (always so for 64-bit positions) */)
+                          bool wide /* SA indices need 33 bits / 64-bit samples (always so for 64-bit positions) */,
+                          bool allow_unsample /* the caller planned the workspace for K3u (no trail table) */)
 {
     hipStream_t st = ws->stream;
     PhaseTrace bt(st);
@@ -714,6 +735,10 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     for (uint32_t i = 0; i < nd; ++i) lh[i] = pl.dl[dlist[sl + i]];
     const uint64_t acc = off64[nd];
     const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (wide ? 33 : 32)) && !idx->is_int;
+    // K3u: the whole suffix array from the samples, inside the sweep's scratch (n x 4 B + 20 B per sample <= 20 B per occurrence)
+    const uint64_t n_walkers = idx->is_int ? 0 : idx->view.n_samples;
+    const bool use_unsample = allow_unsample && use_sweep && sizeof(pos_t) == 4 && unsample_applies(idx, ws, acc) &&
+                              align_up(idx->hdr.n * 4, 256) + n_walkers * 20 + 1024 <= gacc * kPhysScratchPerElem<pos_t>();
     pos_t* Pg = A.take<pos_t>(gacc);
     // scratch of the sweep (20 B per element); the sorted lists Pb reuse it once locate is done
     uint8_t* scratch = A.take<uint8_t>(gacc * kPhysScratchPerElem<pos_t>());
@@ -748,6 +773,26 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     };
     if (!acc) {
         // (a rank without a share: nothing to locate or sort, the exchange below still takes place)
+    } else if (use_unsample) {
+        uint32_t* sa_full = reinterpret_cast<uint32_t*>(scratch);
+        uint64_t* val_a = reinterpret_cast<uint64_t*>(scratch + align_up(idx->hdr.n * 4, 256));
+        uint64_t* val_b = val_a + n_walkers;
+        uint16_t* key_a = reinterpret_cast<uint16_t*>(val_b + n_walkers);
+        uint16_t* key_b = key_a + n_walkers;
+        svec<unsigned long long> h_done(1, 0);
+        SweepTimer timer(ws);
+        bt.mark("  physical: tables + sort plan");
+        vlg_status s = VLG_OK;
+        if constexpr (sizeof(pos_t) == 4) {
+            if (wide) s = launch_unsample<true>(idx->view, d_lh, d_off64, nd, acc, Pa, sa_full, val_a, val_b, key_a, key_b, d_tmp, sort_tmp, d_counter, h_done.data(),
+                                                d_stats, ws->unsample_tail, st, &timer, &plan_sort);
+            else s = launch_unsample<false>(idx->view, d_lh, d_off64, nd, acc, Pa, sa_full, val_a, val_b, key_a, key_b, d_tmp, sort_tmp, d_counter, h_done.data(),
+                                            d_stats, ws->unsample_tail, st, &timer, &plan_sort);
+        }
+        if (s) return s;
+        ws->sample_reads += n_walkers;
+        res->sum.locate_mode = VLG_LOCATE_UNSAMPLE;
+        bt.mark("  physical: unsampling");
     } else if (use_sweep) {
         const uint64_t cap = std::min<uint64_t>(acc, wide ? sweep_batch_max<true>() : sweep_batch_max<false>());
         uint64_t* val_a = reinterpret_cast<uint64_t*>(scratch);
@@ -765,9 +810,13 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
                                                      ws->sweep_tail, st, &timer, trail, rec, &ws->trail_gen, &plan_sort);
         else s = fail(VLG_E_INTERNAL, "64-bit positions with 32-bit SA indices");
         if (s) return s;
+        ws->sample_reads += acc;
+        res->sum.locate_mode = idx->hdr.dens == 1 && idx->hdr.sampling == kSamplingSaOrder ? VLG_LOCATE_COPY : VLG_LOCATE_SWEEP;
         bt.mark("  physical: sweep");
     } else if (idx->is_int) {
         // integer-alphabet index (int_index.hpp): one lane per occurrence on the wavelet matrix of the BWT
+        ws->sample_reads += acc;
+        res->sum.locate_mode = VLG_LOCATE_WALKS;
         if (vlg_status s = plan_sort()) return s;
         if constexpr (sizeof(pos_t) == 4) {
             {
@@ -779,6 +828,8 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         } else return fail(VLG_E_INTERNAL, "integer-alphabet index with 64-bit positions");
     } else if (wide && sizeof(pos_t) == 4) {
         // few occurrences, 33-bit SA indices, 32-bit positions: the in-place kernel walks in 64-bit words of the scratch, then narrows
+        ws->sample_reads += acc;
+        res->sum.locate_mode = VLG_LOCATE_WALKS;
         if (vlg_status s = plan_sort()) return s;
         uint64_t* io64 = reinterpret_cast<uint64_t*>(scratch);
         {
@@ -791,6 +842,8 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
             if (vlg_status s = launch_narrow<uint32_t>(io64, reinterpret_cast<uint32_t*>(Pa), acc, st)) return s;
         }
     } else {
+        ws->sample_reads += acc;
+        res->sum.locate_mode = VLG_LOCATE_WALKS;
         if (vlg_status s = plan_sort()) return s;
         {
             Timed t(ws, KS_EXPAND, 0);
@@ -1475,7 +1528,9 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         // the trail table (8 B per text position) and the records (8 B per occurrence) must leave room for the joins
         // (an index that keeps the whole suffix array -- SA-order samples of density 1 -- walks nothing: no trails, no records)
         const bool dense_sa = idx->hdr.dens == 1 && idx->hdr.sampling == kSamplingSaOrder;
-        uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup && !dense_sa ? (idx->hdr.n + phys) * 8 + 512 : 0;
+        // (nor does a batch dense enough to rebuild the whole suffix array, K3u: its arrays fit the sweep's scratch)
+        const bool will_unsample = will_sweep && !dense_sa && sizeof(pos_t) == 4 && unsample_applies(idx, ws, phys / (uint64_t)std::max(1, ws->x_ranks));
+        uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup && !dense_sa && !will_unsample ? (idx->hdr.n + phys) * 8 + 512 : 0;
         // (+ fences: < 1 B per element; + the pivot filter's ladder, a third of the lists, when its searches outweigh building it:
         // one pass over the lists against two descents per pivot element)
         ws->want_rungs = pivot_elems && (ws->pivot_rungs == 2 || (pivot_elems >= phys / 16 && pivot_elems >= 4096));
@@ -1539,7 +1594,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         tr.mark("plan super-chunk");
         pos_t* Pc = nullptr;
         uint64_t pc_cap = 0;
-        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, trail, wide)) return s;
+        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, trail, wide, will_unsample)) return s;
         if (launch_first)
             if (vlg_status s = plan_joins(q, pl, ws, qa, qb, join_budget, idx->hdr.n, jp)) return s;
         tr.mark("locate + sort");
@@ -1713,6 +1768,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         d_stats = (unsigned long long*)(head + 2 * lr_bytes);
         uint8_t* plan_mem = head + 2 * lr_bytes + st_bytes;
         VLG_HIP_TRY(hipMemsetAsync(d_stats, 0, kStatsWords * 8, st));
+        ws->sample_reads = 0;
         // ---- K2: every sub-pattern's SA interval ------------------------------------------------------
         {
             Timed t(ws, KS_BSEARCH, 0);
@@ -1792,7 +1848,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         for (uint32_t i = 0; i < kChecksumSlots; ++i) res->sum.checksum += hs[kStatsChecksum + i];      // modulo 2^64, like gm_search.cpp:110-114
         res->sum.wt_levels_bsearch = hs[3];
         // algorithmic bytes: 32 B per super-block read (+ one sample per occurrence)
-        ws->stats[KS_LOCATE].algorithmic_bytes += 32ull * hs[1] + (uint64_t)idx->hdr.sample_bytes * res->sum.located_occurrences;
+        ws->stats[KS_LOCATE].algorithmic_bytes += 32ull * hs[1] + (uint64_t)idx->hdr.sample_bytes * ws->sample_reads;
         ws->stats[KS_BSEARCH].algorithmic_bytes += 32ull * hs[3];
         return VLG_OK;
     };
