@@ -10,6 +10,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+class _Lap:
+    """VLG_TEST_TIMING=1: where a full-size test spends its time (stderr, run with -s)."""
+    def __init__(self, name):
+        import os, time
+        self.on, self.name, self.t0, self.clock = bool(os.environ.get("VLG_TEST_TIMING")), name, time.time(), time.time
+
+    def __call__(self, what):
+        if self.on:
+            import sys
+            t1 = self.clock()
+            print("[lap] %s: %-40s %7.1f s" % (self.name, what, t1 - self.t0), file=sys.stderr, flush=True)
+            self.t0 = t1
+
+
 @pytest.fixture(scope="module")
 def c2():
     import vlg_matching_amd as V
@@ -72,7 +86,7 @@ def test_c2_sample_equals_oracle(c2, oracle):
     res = idx.search(queries)
     rng = np.random.default_rng(99)
     light = rng.choice(cfg["nq"], 300, replace=False)
-    heavy = cfg["nq"] + rng.choice(len(queries) - cfg["nq"], 12, replace=False)
+    heavy = cfg["nq"] + rng.choice(len(queries) - cfg["nq"], 6, replace=False)
     for qi in list(light) + list(heavy):
         assert res.tuples(int(qi)).tolist() == o.search(queries[int(qi)]).tolist(), queries[int(qi)]
     # SA samples of the device build: csa[i] == true suffix position for sampled i (csa_byte_test.cpp:136-147 restated)
@@ -212,9 +226,12 @@ def test_c5_one_gib_dna_rrr_full_size(oracle):
     from vlg_matching_amd import workload
     from vlg_matching_amd.index import Queries, Workspace
     cfg = workload.config("C5")
+    lap = _Lap("C5")
     text = workload.gen_text(cfg["kind"], cfg["n"], cfg["seed"])
+    lap("text")
     plain = V.VlgIndex.build(text)
     rrr = plain.compress()
+    lap("build + compress")
     ip, ir = plain.info(), rrr.info()
     assert ir["bv_kind"] == 1 and ip["bv_kind"] == 0 and ir["n"] == ip["n"] == cfg["n"] + 1
     parts = workload.gen_query_parts(text, cfg["nq"], cfg["k"], cfg["m"], cfg["qseed"])
@@ -225,11 +242,13 @@ def test_c5_one_gib_dna_rrr_full_size(oracle):
     queries = [g.join(sp.decode() for sp in subs) for subs in parts] + [g.join(sp.decode() for sp in subs) for subs in heavy_parts]
     parts = parts + heavy_parts
     q = Queries(queries)
+    lap("queries")
     ws = Workspace(100 << 30)
     base = rrr.search(q, workspace=ws)
     s = base.summary
     assert s["n_queries"] == len(queries) and s["n_matches"] > 1000 and s["located_occurrences"] > 10 ** 7
     counts, offsets, first, tuples = base.fetch()
+    lap("base search + fetch")
     # ---- structural properties of every match --------------------------------------------------------------------------------
     t = tuples.reshape(-1, 2)
     lens = np.array([len(parts[qi][0]) for qi in range(len(queries))], dtype=np.uint64)
@@ -248,6 +267,7 @@ def test_c5_one_gib_dna_rrr_full_size(oracle):
         for i in range(2):
             p0 = int(t[mi, i])
             assert text[p0: p0 + len(subs[i])].tobytes() == subs[i]
+    lap("properties")
     # ---- identical results: plain index, and the rrr index under every execution strategy -------------------------------------
     pl = plain.search(q, workspace=ws)
     assert pl.summary["n_matches"] == s["n_matches"] and pl.summary["checksum"] == s["checksum"]
@@ -264,15 +284,20 @@ def test_c5_one_gib_dna_rrr_full_size(oracle):
         assert r.summary["n_matches"] == s["n_matches"] and r.summary["checksum"] == s["checksum"], opts
         f2 = r.fetch()
         assert (f2[0] == counts).all() and (f2[3] == tuples).all(), opts
+        lap("mode %r" % (opts,))
     # ---- >= 200 sampled queries (and some heavy ones) equal the CPU oracle tuple for tuple -----------------------------------------
     o = oracle.Index.from_parts(plain.export_parts())
-    sample = list(rng.choice(cfg["nq"], 260, replace=False)) + list(cfg["nq"] + rng.choice(300, 12, replace=False))
+    lap("oracle from parts")
+    # (a heavy query -- two 6-mers of 2.6 * 10^5 occurrences each -- costs the one-core oracle ~17 s: two of them; the heavy lists are
+    # checked in full by the plain-vs-rrr and mode comparisons above, and at C2 size against the oracle)
+    sample = list(rng.choice(cfg["nq"], 260, replace=False)) + list(cfg["nq"] + rng.choice(300, 2, replace=False))
     nonempty = 0
     for qi in sample:
         want = o.search(queries[int(qi)])
         assert base.tuples(int(qi)).tolist() == want.tolist(), queries[int(qi)]
         nonempty += len(want) > 0
     assert nonempty >= 5
+    lap("oracle sample")
 
 
 def test_c4_four_gib_text_64bit_positions(oracle):

@@ -428,6 +428,48 @@ __device__ __forceinline__ void block_add(unsigned long long (&v)[N], unsigned l
     if (threadIdx.x < N && s_acc[threadIdx.x] && dst[threadIdx.x]) atomicAdd(dst[threadIdx.x], s_acc[threadIdx.x]);
 }
 
+// ---- member bit-vector: which SA indices are elements of the batch, and which (sweep_element explains what for) ----------------
+// bit i = one of the lists [l[d], l[d] + off[d + 1] - off[d]), d < n_lists, holds SA index i; the lists are pairwise disjoint and
+// ascend, and list d owns the slots [off[d], off[d + 1]) -- so the number of set bits before i IS the slot of index i.  Same 256-bit
+// super-blocks as the wavelet tree (224 bits + the count before them), built block by block: no clearing pass, no atomics.
+__global__ void __launch_bounds__(256) member_build_kernel(const uint64_t* __restrict__ l, const uint64_t* __restrict__ off, uint32_t n_lists,
+                                                           uint64_t n_blocks, Block* __restrict__ out)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t B0 = b * kBlockBits, B1 = B0 + kBlockBits;
+        uint32_t lo = 0, hi = n_lists;                       // first list that ends behind B0
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (l[mid] + (off[mid + 1] - off[mid]) <= B0) lo = mid + 1; else hi = mid;
+        }
+        uint32_t d = lo;
+        Block B;
+#pragma unroll
+        for (uint32_t w = 0; w < 7; ++w) B.w[w] = 0;
+        B.cnt = (uint32_t)(d < n_lists ? off[d] + (B0 > l[d] ? B0 - l[d] : 0) : off[n_lists]);
+        for (; d < n_lists && l[d] < B1; ++d) {
+            const uint64_t end = l[d] + (off[d + 1] - off[d]);
+            const uint32_t a = (uint32_t)((l[d] > B0 ? l[d] : B0) - B0), e = (uint32_t)((end < B1 ? end : B1) - B0);
+#pragma unroll
+            for (uint32_t w = 0; w < 7; ++w) {
+                const uint32_t x = a > 32 * w ? a : 32 * w, y = e < 32 * w + 32 ? e : 32 * w + 32;
+                if (x < y) B.w[w] |= (y - x == 32 ? ~0u : ((1u << (y - x)) - 1u)) << (x - 32 * w);
+            }
+        }
+        out[b] = B;
+    }
+}
+
+__device__ __forceinline__ bool member_probe(const Block* __restrict__ member, uint64_t i, uint32_t& slot)
+{
+    uint32_t blk, off, bit;
+    split224(i, blk, off);
+    const BlockRegs r = load_block(member, blk);
+    slot = block_rank_bit(r, off, bit);
+    return bit != 0;
+}
+
+
 // =============================================================================================
 // K3: csa[i] = LF iteration to the next sampled SA index (include/sdsl/csa_wt.hpp:335-348,
 //     LF = C[c] + inverse_select(i): suffix_array_helper.hpp:336-349, wt_pc.hpp:385-402).
@@ -439,8 +481,8 @@ __device__ __forceinline__ void block_add(unsigned long long (&v)[N], unsigned l
 // of LF steps and whatever the code lengths.
 // =============================================================================================
 // kTail: the same walk for the stragglers of the sorted sweep (K3s below): the elements are val[] = slot << kShift | SA index, they
-// have walked `step` steps already, positions go to out[slot] -- or to rec[slot0 + slot] when trails are shared, and then a walk
-// also ends on the first index another element stood on during the sweep (sweep_step_kernel explains the records).
+// have walked `step` steps already, positions go to out[slot] -- or to rec[slot0 + slot] when LF steps are shared, and then a walk
+// also ends on the first index that is an element of the batch itself (sweep_element explains the records and `member`).
 // kWide: SA indices need 33 bits and the samples are 64-bit words (n > 2^32, or VLG_FORCE_POS64); the positions written may still be
 // 32-bit (pos_t) when the text has at most 2^32 characters -- only the tail mode can split the two, the in-place mode keeps the SA
 // index in io[] itself.
@@ -449,7 +491,7 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
                                                      unsigned long long* __restrict__ stats /* [2]: lf steps, levels */,
                                                      const uint64_t* __restrict__ val = nullptr, uint32_t step = 0,
                                                      uint64_t* __restrict__ rec = nullptr, uint64_t slot0 = 0,
-                                                     const uint64_t* __restrict__ trail = nullptr, uint64_t gen = 0)
+                                                     const Block* __restrict__ member = nullptr)
 {
     static_assert(kTail || kWide == (sizeof(pos_t) == 8), "in place, io[] holds the SA index: its width is the index width");
     using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
@@ -491,6 +533,7 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
         if (!__any(active)) break;
         if (active) {
             uint64_t sv = 0;
+            uint32_t owner = 0;
             if (v == 0 && sampling.probe(i, sv)) {         // csa_sampling_strategy.hpp:102-111 / :185-194
                 uint64_t r = sv + off;
                 if (r >= iv.n) r -= iv.n;                  // csa_wt.hpp:343-347
@@ -498,11 +541,9 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
                 else io[t] = (pos_t)r;
                 need = true;
                 active = false;
-            } else if (kTail && trail && v == 0 && (trail[i] >> 48 << 48) == gen && (uint32_t)(trail[i] & 0xFFFFu) < off) {
-                // someone stood here earlier in this sweep: take its trail (a straggler writes no marks itself any more: whoever it
-                // could meet from now on is a straggler too and walks at the same pace)
-                const uint64_t mk = trail[i];
-                const uint64_t owner = ((mk >> 16) & 0xFFFFFFFFull) - 1, delta = off - (mk & 0xFFFFu);
+            } else if (kTail && member && v == 0 && off != 0 && member_probe(member, i, owner)) {
+                // this index is where element `owner` started: the rest of the walk is that element's (sweep_element)
+                const uint64_t delta = off;
                 const uint64_t ro = rec[owner];
                 uint64_t r;
                 if (ro == ~0ull) r = (delta << kShift) | owner;               // still walking: follow it
@@ -671,22 +712,30 @@ __global__ void __launch_bounds__(256) sa_dense_copy_kernel(const sample_t* __re
     }
 }
 
-// kTrail: LF trails are shared.  trail[i] = generation << 48 | (element + 1) << 16 | step remembers the first element that stood on
-// SA index i in THIS sweep and at which step (the generation stamp spares clearing 8 bytes per text position for every batch); an
-// element that arrives there later has the same future, so it stops and records (that element, steps apart) in rec -- or,
-// when that element has a record already, the record one hop further.  rec[slot]: a position (high bits 0), or
-// delta << kShift | slot of the element it follows; ~0 while the element is still walking.  slot0 = first slot of the sweep.
+// kTrail: LF steps are shared inside the batch.  An LF walk from SA index i visits the indices of the text positions SA[i] - 1,
+// SA[i] - 2, ...; when it stands on an index that is ITSELF an element of the batch (the start of another occurrence's walk: text
+// position SA[i] - k is an occurrence too) the rest of the walk is that element's walk, so it stops there and records
+// (that element, k): csa[i] = csa[LF^k(i)] + k (csa_wt.hpp:335-348 applied to a value another lane computes).  Which indices are
+// elements is known before the sweep starts -- the batch's lists are SA intervals -- and kept as a rank-enabled bit-vector over
+// the SA indices in the usual 256-bit super-blocks (`member`, member_build_kernel): one 32-byte read says whether index i is an
+// element AND which one (its slot = the number of member indices before it: the lists lie in SA order in the slot space).
+// This replaces the table of round 2 / 3 (8 bytes per text position, written and read at random by every step, told apart by
+// generation stamps) with n / 7 bytes that are only read; a walk also stops wherever it can, not only where another one has passed
+// EARLIER, so every non-member index is visited by at most one walk.
+// rec[slot]: a position (high bits 0), or delta << kShift | slot of the element it follows; ~0 while the element is still walking.
+// slot0 = first slot of the sweep.
 // one element of one round: v64 = its word (slot << kShift | SA index), e = its place in val / key
 template <class BV, typename pos_t, bool kTrail, bool kWide, bool kFirst = false, class Sampling>
 __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds<BV>& s, const Sampling& sampling, uint64_t e, uint64_t v64,
                                               uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint32_t step, pos_t* __restrict__ out,
-                                              uint64_t* __restrict__ trail, uint64_t* __restrict__ rec, uint64_t slot0, uint64_t gen,
+                                              const Block* __restrict__ member, uint64_t* __restrict__ rec, uint64_t slot0,
                                               uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin)
 {
     constexpr uint32_t kShift = kWide ? 33 : 32;
     constexpr uint64_t kPosMask = (1ull << kShift) - 1;
     uint64_t i = v64 & kPosMask;
     uint64_t sv = 0;
+    uint32_t owner = 0;
     if (sampling.probe(i, sv)) {
         uint64_t r = sv + step;
         if (r >= iv.n) r -= iv.n;                        // csa_wt.hpp:343-347
@@ -694,12 +743,10 @@ __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds
         else out[v64 >> kShift] = (pos_t)r;
         key[e] = (uint16_t)iv.sigma;
         ++n_fin;
-    } else if (kTrail && step != 0 && (trail[i] >> 48 << 48) == gen && (trail[i] & 0xFFFFu) != step) {
-        // (round 0: nobody has walked yet; an entry of another generation is left over from an earlier sweep; an equal step is a
-        // twin -- the same index in two lists.)  Someone stood here `delta` steps ago: same text trail, `delta` positions further
-        // left when it started
-        const uint64_t m = trail[i];
-        const uint64_t owner = ((m >> 16) & 0xFFFFFFFFull) - 1, delta = step - (m & 0xFFFFu);
+    } else if (kTrail && !kFirst && member_probe(member, i, owner)) {
+        // (round 0: every element stands on its own index.)  Index i is where element `owner` started: same text trail, `step`
+        // positions further left
+        const uint64_t delta = step;
         const uint64_t ro = rec[owner];
         uint64_t r;
         if (ro == ~0ull) r = (delta << kShift) | owner;                       // still walking: follow it
@@ -709,7 +756,6 @@ __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds
         key[e] = (uint16_t)iv.sigma;
         ++n_fin;
     } else {
-        if (kTrail) trail[i] = gen | ((slot0 + (v64 >> kShift) + 1) << 16) | step;
         if (kTrail && kFirst) rec[slot0 + (v64 >> kShift)] = ~0ull;               // still walking (no pass clears the records beforehand)
         uint32_t v = 0, c;
         using walk_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;      // node-relative positions: < n
@@ -735,8 +781,8 @@ template <class BV, typename pos_t, bool kTrail, bool kWide, bool kTextOrder>
 __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count,
                                                          uint32_t step, pos_t* __restrict__ out,
                                                          unsigned long long* __restrict__ stats /* lf, levels */,
-                                                         unsigned long long* __restrict__ n_done, uint64_t* __restrict__ trail,
-                                                         uint64_t* __restrict__ rec, uint64_t slot0, uint64_t gen /* << 48 */)
+                                                         unsigned long long* __restrict__ n_done, const Block* __restrict__ member,
+                                                         uint64_t* __restrict__ rec, uint64_t slot0)
 {
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
@@ -746,7 +792,7 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
     const Sampling sampling(iv);
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x)
-        sweep_element<BV, pos_t, kTrail, kWide>(iv, s, sampling, e, val[e], val, key, step, out, trail, rec, slot0, gen, n_lv, n_lf, n_fin);
+        sweep_element<BV, pos_t, kTrail, kWide>(iv, s, sampling, e, val[e], val, key, step, out, member, rec, slot0, n_lv, n_lf, n_fin);
     unsigned long long v[3] = {n_lf, n_lv, n_fin};
     unsigned long long* const dst[3] = {&stats[0], &stats[1], n_done};
     block_add<3>(v, dst);
@@ -759,8 +805,8 @@ template <class BV, typename pos_t, bool kTrail, bool kWide, bool kTextOrder>
 __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat,
                                                           uint64_t t0, uint64_t total, uint64_t* __restrict__ val, uint16_t* __restrict__ key,
                                                           pos_t* __restrict__ out, unsigned long long* __restrict__ stats,
-                                                          unsigned long long* __restrict__ n_done, uint64_t* __restrict__ trail,
-                                                          uint64_t* __restrict__ rec, uint64_t gen /* << 48 */)
+                                                          unsigned long long* __restrict__ n_done, const Block* __restrict__ member,
+                                                          uint64_t* __restrict__ rec)
 {
     __shared__ WalkLds<BV> s;
     __shared__ uint64_t s_first;
@@ -797,7 +843,7 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
                     sai = l[p] + (t - out_off[p]);
                 }
                 const uint64_t v64 = ((t - t0) << kShift) | sai;
-                sweep_element<BV, pos_t, kTrail, kWide, true>(iv, s, sampling, t - t0, v64, val, key, 0u, out, trail, rec, t0, gen, n_lv, n_lf, n_fin);
+                sweep_element<BV, pos_t, kTrail, kWide, true>(iv, s, sampling, t - t0, v64, val, key, 0u, out, member, rec, t0, n_lv, n_lf, n_fin);
             }
         }
     }
@@ -1136,8 +1182,9 @@ template <typename pos_t, bool kWide>
 vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
                                pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
-                               hipStream_t stream, LaunchTimer* timer, uint64_t* trail /* n words, or null */, uint64_t* rec /* total words */,
-                               uint32_t* trail_gen /* generation of the last sweep that used this table; 0 = unknown content */,
+                               hipStream_t stream, LaunchTimer* timer, Block* member /* member_blocks(n) super-blocks, or null: no LF step is shared */,
+                               uint32_t n_member_lists /* the first so many lists are pairwise disjoint and ascend: they make up `member` */,
+                               uint64_t* rec /* total words */,
                                const std::function<vlg_status()>* while_first_step /* host work to do while the first step runs, or null */)
 {
     bool hook_due = while_first_step != nullptr;
@@ -1159,22 +1206,22 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     }
     const unsigned bits = bit_width64(iv.sigma);            // keys 0..sigma (sigma = finished, sorts last)
     const uint64_t batch_max = sweep_batch_max<kWide>();
+    if (member) {
+        if (total > 0xFFFFFF00ull) return fail(VLG_E_INTERNAL, "member bit-vector: slots need 32 bits");
+        if (timer) timer->begin(0);
+        hipLaunchKernelGGL(member_build_kernel, dim3(grid_for(member_blocks(iv.n), 16384)), dim3(256), 0, stream, d_l, d_out_off, n_member_lists,
+                           member_blocks(iv.n), member);
+        if (timer) timer->end(0);
+        VLG_HIP_TRY(hipGetLastError());
+        // more than one sweep: an element may stop at an element of a LATER sweep, whose record must read "still walking" until then
+        if (total > batch_max) VLG_HIP_TRY(hipMemsetAsync(rec, 0xFF, total * 8, stream));
+    }
     for (uint64_t t0 = 0; t0 < total; t0 += batch_max) {
         const uint64_t t1 = std::min(total, t0 + batch_max);
-        uint64_t gen = 0;
-        if (trail) {                                             // steps are counted per sweep: trails are not shared across sweeps
-            if (total > 0xFFFFFFFFull) return fail(VLG_E_INTERNAL, "trail table: element numbers need 32 bits");
-            if (!trail_gen || *trail_gen == 0 || *trail_gen >= 0xFFFFu) {
-                VLG_HIP_TRY(hipMemsetAsync(trail, 0, iv.n * 8, stream));
-                gen = 1;
-            } else gen = *trail_gen + 1;
-            if (trail_gen) *trail_gen = (uint32_t)gen;
-            gen <<= 48;
-        }
         // (a sweep too short for a single round hands its elements to the stragglers' kernel, which reads their words)
         const bool fused_first = t1 - t0 > tail_threshold && [] { const char* e = getenv("VLG_NO_FUSED_FIRST_ROUND"); return !(e && e[0] == '1'); }();
         if (!fused_first) {
-            if (trail) VLG_HIP_TRY(hipMemsetAsync(rec + t0, 0xFF, (t1 - t0) * 8, stream));      // "still walking" (sweep_first_kernel writes it itself)
+            if (member) VLG_HIP_TRY(hipMemsetAsync(rec + t0, 0xFF, (t1 - t0) * 8, stream));     // "still walking" (sweep_first_kernel writes it itself)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for((t1 - t0 + 7) / 8, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
                                t0, t1, val_a);
         }
@@ -1182,20 +1229,20 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
         uint64_t alive = t1 - t0;
         uint32_t step = 0;
         pos_t* out = d_out + t0;
-        while (alive > tail_threshold && step < 0xFFFFu) {       // the trail table keeps 16 bits of the step
+        while (alive > tail_threshold && step < 0xFFFFFFu) {
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
             if (timer) timer->begin(0);
             const dim3 grid(grid_for(alive, 4096));
             const bool first = fused_first && step == 0;                       // round 0 makes the elements' words itself (sweep_first_kernel)
             const dim3 grid_first(grid_for((alive + 7) / 8, 8192));
-#define VLG_STEP(BV, TR, TO) do { if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val_a, key_a, out, d_stats, d_counter, trail, rec, gen); \
-                                   else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<BV, pos_t, TR, kWide, TO>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, step, out, d_stats, d_counter, trail, rec, t0, gen); } while (0)
+#define VLG_STEP(BV, TR, TO) do { if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val_a, key_a, out, d_stats, d_counter, member, rec); \
+                                   else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<BV, pos_t, TR, kWide, TO>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, step, out, d_stats, d_counter, member, rec, t0); } while (0)
 #define VLG_STEP_BV(TR, TO) do { if (rrr) VLG_STEP(RrrBV, TR, TO); else VLG_STEP(PlainBV, TR, TO); } while (0)
             if constexpr (!kWide) {
-                if (text_order) { if (trail) VLG_STEP_BV(true, true); else VLG_STEP_BV(false, true); }
-                else { if (trail) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false); }
+                if (text_order) { if (member) VLG_STEP_BV(true, true); else VLG_STEP_BV(false, true); }
+                else { if (member) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false); }
             } else {
-                if (trail) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false);
+                if (member) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false);
             }
 #undef VLG_STEP_BV
 #undef VLG_STEP
@@ -1227,7 +1274,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             const uint64_t waves = (alive + per_wave - 1) / per_wave;
             const dim3 grid((uint32_t)((waves + 3) / 4));
             if (timer) timer->begin(0);
-#define VLG_TAIL(BV, TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, BV, true, kWide, TO>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave, d_stats, val_a, step, trail ? rec : nullptr, t0, trail, gen)
+#define VLG_TAIL(BV, TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, BV, true, kWide, TO>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave, d_stats, val_a, step, member ? rec : nullptr, t0, member)
             if constexpr (!kWide) {
                 if (text_order) { if (rrr) VLG_TAIL(RrrBV, true); else VLG_TAIL(PlainBV, true); }
                 else { if (rrr) VLG_TAIL(RrrBV, false); else VLG_TAIL(PlainBV, false); }
@@ -1240,7 +1287,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
         }
     }
     if (hook_due) { hook_due = false; if (vlg_status hs = (*while_first_step)()) return hs; }
-    if (trail) {
+    if (member) {
         // every element has a record now; jump pointers until all of them are positions
         for (uint32_t round = 0;; ++round) {
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
@@ -1350,7 +1397,7 @@ template vlg_status launch_unsample<true>(const IndexView&, const uint64_t*, con
 #define VLG_SWEEP_INST(P, W)                                                                                                          \
     template vlg_status launch_locate_sweep<P, W>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, P*, uint64_t*, \
                                                   uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, \
-                                                  uint64_t, hipStream_t, LaunchTimer*, uint64_t*, uint64_t*, uint32_t*,                   \
+                                                  uint64_t, hipStream_t, LaunchTimer*, Block*, uint32_t, uint64_t*,                       \
                                                   const std::function<vlg_status()>*);
 VLG_SWEEP_INST(uint32_t, false)
 VLG_SWEEP_INST(uint32_t, true)        // n = 2^32 + 1 (BASELINE config 4): 33-bit SA indices, 32-bit text positions

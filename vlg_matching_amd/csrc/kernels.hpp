@@ -29,8 +29,10 @@ template <typename pos_t, bool kWide>
 vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
                                pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
-                               hipStream_t stream, LaunchTimer* timer, uint64_t* trail, uint64_t* rec, uint32_t* trail_gen,
+                               hipStream_t stream, LaunchTimer* timer, Block* member, uint32_t n_member_lists, uint64_t* rec,
                                const std::function<vlg_status()>* while_first_step = nullptr);
+// super-blocks of the member bit-vector over the SA indices of a text of n - 1 characters (kernels.hip: sweep_element)
+inline uint64_t member_blocks(uint64_t n) { return n / kBlockBits + 1; }
 // K3u: the whole suffix array reconstructed from the samples (one LF walker per sample, n LF steps in all) into sa_full (n x 4 B),
 // then the SA intervals of the lists copied into d_out.  For batches that locate a large part of all text positions.
 // Scratch: val_a / val_b (8 B) and key_a / key_b (2 B) for n_samples walkers, temp as for the sweep, counter 8 B.

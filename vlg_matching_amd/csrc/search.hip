@@ -52,8 +52,9 @@ struct vlg_workspace {
     bool sweep = true;          // sorted-sweep locate (n <= 2^32) instead of the random-access persistent kernel
     bool tuples = true;         // materialise every sub-pattern position of every match (sdsl::locate); off: first positions only, which
                                 // is all the benchmark's gapped_search_result holds (index_sasearch.hpp:58-118)
-    bool trail = true;          // sorted-sweep locate: elements that step onto an SA index another element has visited share its LF trail
-                                // (needs dedup; with dedup off every occurrence walks its own LF steps like the reference)
+    bool trail = true;          // sorted-sweep locate: a walk that steps onto an SA index which is itself an element of the batch stops there
+                                // and shares that element's LF steps (kernels.hip: sweep_element; needs dedup -- with dedup off every
+                                // occurrence walks its own LF steps like the reference)
     bool filter = true;         // window filter: drop the list elements that can be in no match before the join
     uint64_t filter_min = 1ull << 12;   // queries with fewer join slots are joined as they are (C3, ms per batch: 2^18 271, 2^16 247, 2^14 240,
                                         // 2^12 237.7, 2^10 237.6, 2^7 239)
@@ -83,9 +84,6 @@ struct vlg_workspace {
     uint64_t unsample_min = 1ull << 28;     // ... and at least this many occurrences: ~110 rounds of two launches each are a fixed cost
     uint64_t unsample_tail = 1ull << 20;    // walkers left when the sorted rounds end and the lanes finish them one by one
     uint64_t sample_reads = 0;              // SA samples read by the locate stage of the batch in work (algorithmic bytes)
-    // trail table of the sorted sweep: it lives at the head of the arena and carries generation stamps, so it is cleared once, not per batch
-    uint32_t trail_gen = 0;             // generation of the last sweep that wrote it; 0 = content unknown
-    uint64_t trail_n = 0;               // text length it was last used for
     // one process per GPU: a collective search shards the DISTINCT LISTS of a batch over the ranks for locate + sort,
     // exchanges the sorted lists (all-gather) and shards the QUERIES for filter + join
     // device memory of a batch's first steps (SA intervals, the interval plan's arrays, counters): kept from batch to batch -- a
@@ -199,7 +197,6 @@ vlg_status ws_head(vlg_workspace* ws, uint64_t bytes, uint8_t** out)
 vlg_status ws_reserve(vlg_workspace* ws, uint64_t bytes)
 {
     if (bytes <= ws->arena_bytes) return VLG_OK;
-    ws->trail_gen = 0;
     if (ws->arena) { (void)hipFree(ws->arena); ws->arena = nullptr; ws->arena_bytes = 0; }
     if (hipMalloc((void**)&ws->arena, bytes) != hipSuccess) {        // parked result buffers may be in the way
         (void)hipGetLastError();
@@ -686,17 +683,45 @@ inline bool unsample_applies(const vlg_index* idx, const vlg_workspace* ws, uint
 
 // ---- physical pass: locate + sort every distinct interval used by queries [Q0,Q1) -------------------
 template <typename pos_t>
-vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* res, const std::vector<uint32_t>& dlist /* distinct ids */,
+vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* res, const std::vector<uint32_t>& dlist_in /* distinct ids */,
                           const Plan& pl, Arena& A, pos_t*& P_out, std::vector<uint32_t>& poff /* per distinct id -> offset (size dl) */,
                           uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats, pos_t*& Pc_out, uint64_t& pc_cap,
-                          uint64_t* trail /* n words at the head of the arena when trails are shared, else null */,
+                          bool share_steps /* the sweep's walks stop at elements of the batch (room for the member bit-vector and the records) */,
                           bool wide /* SA indices need 33 bits / 64-bit samples (always so for 64-bit positions) */,
                           bool allow_unsample /* the caller planned the workspace for K3u (no trail table) */)
 {
     hipStream_t st = ws->stream;
     PhaseTrace bt(st);
-    // all lists of the super-chunk ("g": global), laid out one after the other in SA order of their intervals
-    const uint32_t gnd = (uint32_t)dlist.size();
+    // all lists of the super-chunk ("g": global), laid out one after the other in SA order of their intervals -- first the ones that
+    // are pairwise disjoint ("outer"), then the ones nested inside another list of the chunk (the interval of a pattern that continues
+    // another pattern; SA intervals of patterns nest or are disjoint, they never overlap in part).  With the outer lists in SA order
+    // at the front, the slot of an SA index inside one of them is the number of such indices before it: what the sweep's member
+    // bit-vector returns (kernels.hip: sweep_element).
+    const uint32_t gnd = (uint32_t)dlist_in.size();
+    std::vector<uint32_t> dlist(dlist_in);
+    bool ascending = true;
+    for (uint32_t i = 1; i < gnd && ascending; ++i) ascending = pl.dl[dlist[i - 1]] <= pl.dl[dlist[i]];
+    if (!ascending)                                                        // (a plan made on the host numbers the intervals as they come)
+        std::sort(dlist.begin(), dlist.end(), [&](uint32_t a, uint32_t b) { return pl.dl[a] != pl.dl[b] ? pl.dl[a] < pl.dl[b] : pl.docc[a] < pl.docc[b]; });
+    uint32_t n_outer = gnd;
+    {
+        std::vector<uint32_t> inner;
+        uint64_t cover_end = 0;
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < gnd;) {
+            uint32_t j = i, longest = i;                                   // lists that start at the same index: the longest holds the others
+            for (; j < gnd && pl.dl[dlist[j]] == pl.dl[dlist[i]]; ++j) if (pl.docc[dlist[j]] > pl.docc[dlist[longest]]) longest = j;
+            const bool outer = pl.dl[dlist[i]] >= cover_end;
+            for (uint32_t t = i; t < j; ++t) {
+                if (t == longest && outer) continue;
+                inner.push_back(dlist[t]);
+            }
+            if (outer) { const uint32_t d = dlist[longest]; cover_end = pl.dl[d] + pl.docc[d]; dlist[w++] = d; }
+            i = j;
+        }
+        n_outer = w;
+        for (uint32_t d : inner) dlist[w++] = d;
+    }
     svec<uint64_t> goff64(gnd + 1);
     uint64_t gacc = 0;
     for (uint32_t i = 0; i < gnd; ++i) {
@@ -756,9 +781,12 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     if (nd) VLG_HIP_TRY(hipMemcpyAsync(d_lh, lh.data(), nd * 8, hipMemcpyHostToDevice, st));
     if (d_goff64) VLG_HIP_TRY(hipMemcpyAsync(d_goff64, goff64.data(), (gnd + 1) * 8, hipMemcpyHostToDevice, st));
     uint64_t* rec = nullptr;
-    if (use_sweep && trail) {                                                     // (trails are shared inside one sweep)
+    Block* member = nullptr;
+    const uint32_t n_member_lists = n_outer > sl ? std::min(n_outer - sl, nd) : 0u;      // this rank's outer lists: a prefix of its share
+    if (use_sweep && !use_unsample && share_steps && acc <= 0xFFFFFF00ull) {
         rec = A.take<uint64_t>(acc);
-        if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (trail records)");
+        member = A.take<Block>(member_blocks(idx->hdr.n));
+        if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (member bit-vector, records)");
     }
     // the sort's tables only depend on the list lengths: they are built and uploaded while the first step of locate runs
     const uint64_t sort_mark = A.used;
@@ -804,10 +832,10 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         vlg_status s = VLG_OK;
         if (wide)
             s = launch_locate_sweep<pos_t, true>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b, d_tmp, sort_tmp, d_counter, d_stats,
-                                                 ws->sweep_tail, st, &timer, trail, rec, &ws->trail_gen, &plan_sort);
+                                                 ws->sweep_tail, st, &timer, member, n_member_lists, rec, &plan_sort);
         else if constexpr (sizeof(pos_t) == 4)                      // (a 64-bit position type always comes with wide indices)
             s = launch_locate_sweep<uint32_t, false>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b, d_tmp, sort_tmp, d_counter, d_stats,
-                                                     ws->sweep_tail, st, &timer, trail, rec, &ws->trail_gen, &plan_sort);
+                                                     ws->sweep_tail, st, &timer, member, n_member_lists, rec, &plan_sort);
         else s = fail(VLG_E_INTERNAL, "64-bit positions with 32-bit SA indices");
         if (s) return s;
         ws->sample_reads += acc;
@@ -1525,12 +1553,12 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             });
             for (uint32_t t = 0; t < kHostThreads; ++t) { logical_max_query = std::max(logical_max_query, part_max[t]); pivot_elems += part_piv[t]; }
         }
-        // the trail table (8 B per text position) and the records (8 B per occurrence) must leave room for the joins
-        // (an index that keeps the whole suffix array -- SA-order samples of density 1 -- walks nothing: no trails, no records)
+        // the member bit-vector (32 B per 224 SA indices) and the records (8 B per occurrence) must leave room for the joins
+        // (an index that keeps the whole suffix array -- SA-order samples of density 1 -- walks nothing: no shared steps, no records)
         const bool dense_sa = idx->hdr.dens == 1 && idx->hdr.sampling == kSamplingSaOrder;
         // (nor does a batch dense enough to rebuild the whole suffix array, K3u: its arrays fit the sweep's scratch)
         const bool will_unsample = will_sweep && !dense_sa && sizeof(pos_t) == 4 && unsample_applies(idx, ws, phys / (uint64_t)std::max(1, ws->x_ranks));
-        uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup && !dense_sa && !will_unsample ? (idx->hdr.n + phys) * 8 + 512 : 0;
+        uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup && !dense_sa && !will_unsample ? member_blocks(idx->hdr.n) * sizeof(Block) + phys * 8 + 1024 : 0;
         // (+ fences: < 1 B per element; + the pivot filter's ladder, a third of the lists, when its searches outweigh building it:
         // one pass over the lists against two descents per pivot element)
         ws->want_rungs = pivot_elems && (ws->pivot_rungs == 2 || (pivot_elems >= phys / 16 && pivot_elems >= 4096));
@@ -1541,9 +1569,9 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             if (left < std::max<uint64_t>(2 * logical_max_query, budget / 8)) trail_bytes = 0;
         }
         const bool share_trails = trail_bytes != 0;
-        if (tr.on) fprintf(stderr, "[vlg trace] super-chunk: %llu occurrences, %.1f GB physical, trails %s (%.1f GB), budget %.1f GB, largest join %.1f GB\n",
+        if (tr.on) fprintf(stderr, "[vlg trace] super-chunk: %llu occurrences, %.1f GB physical, LF steps %s (%.1f GB), budget %.1f GB, largest join %.1f GB\n",
                            (unsigned long long)phys, phys_plain / 1e9, share_trails ? "shared" : "not shared",
-                           ((idx->hdr.n + phys) * 8) / 1e9, budget / 1e9, logical_max_query / 1e9);
+                           (member_blocks(idx->hdr.n) * sizeof(Block) + phys * 8) / 1e9, budget / 1e9, logical_max_query / 1e9);
         if (tr.on) {                                                          // where the occurrences are: distinct lists by size class
             uint64_t cnt[40] = {0}, sum[40] = {0};
             for (uint32_t d : dlist) { const unsigned b = bit_width64(pl.docc[d]); cnt[b]++; sum[b] += pl.docc[d]; }
@@ -1582,19 +1610,12 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
             if (vlg_status s = ws_reserve(ws, phys_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
         }
         Arena A{ws->arena, ws->arena_bytes};
-        // the trail table first: at a fixed place, so that what earlier sweeps left there is told apart by its generation stamp
-        uint64_t* trail = nullptr;
-        if (share_trails) {
-            if (ws->trail_n != idx->hdr.n) { ws->trail_gen = 0; ws->trail_n = idx->hdr.n; }
-            trail = A.take<uint64_t>(idx->hdr.n);
-            if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (trail table)");
-        } else ws->trail_gen = 0;                                // other data takes the head of the arena
         pos_t* P = nullptr;
         uint64_t Tphys = 0;
         tr.mark("plan super-chunk");
         pos_t* Pc = nullptr;
         uint64_t pc_cap = 0;
-        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, trail, wide, will_unsample)) return s;
+        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, share_trails, wide, will_unsample)) return s;
         if (launch_first)
             if (vlg_status s = plan_joins(q, pl, ws, qa, qb, join_budget, idx->hdr.n, jp)) return s;
         tr.mark("locate + sort");
@@ -1993,7 +2014,6 @@ extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_
         JoinPlan jp;
         if (vlg_status s = plan_joins(&qq, pl, ws, 0, n_joins, budget - list_bytes, n_positions, jp)) return s;
         if (vlg_status s = ws_reserve(ws, list_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
-        ws->trail_gen = 0;                                       // the lists take the head of the arena
         ws->fences = nullptr;
         ws->rungs = nullptr;
         Arena A{ws->arena, ws->arena_bytes};
