@@ -34,6 +34,31 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def host_cpus():
+    """Cores this process may actually use: the smaller of the scheduler affinity and the cgroup's CPU quota (a GPU box hands a
+    container a share of its cores -- os.cpu_count() still reports all of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:                                          # noqa: BLE001
+        pass
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:                                      # noqa: BLE001
+            continue
+    return n, quota
+
+
 def wait_ranks(procs, poll_s=0.2, grace_s=10.0):
     """Wait for the rank processes TOGETHER: a rank that dies (OOM, RCCL init failure) leaves the others blocked in a
     collective, so the first non-zero exit ends the rest (terminate, then kill) and is returned."""
@@ -121,10 +146,11 @@ CLASSES = {
 }
 
 
-def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=1600000, budget_s=45.0, min_queries=100):
+def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=1600000, budget_s=30.0, min_queries=100, threads_budget_s=10.0):
     """The CPU oracle (restatement of the reference path, reference data layout) timed on this host, ONE thread (the
     reference is single-threaded, gm_search.cpp:91), on a bounded seeded sample of the same query batch; then the same
-    code on nproc threads over disjoint query shards, for disclosure."""
+    code on nproc NATIVE threads (oracle/vlg_oracle.c: vlgo_search_many, a pthread pool drawing queries from a shared counter),
+    for disclosure."""
     from oracle import oracle as O
     import numpy as np
     parts = idx.export_parts()
@@ -139,22 +165,22 @@ def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=1600000, budget_s=
             occs = [o.backward_search(sp)[0] for sp in subs]
             occ_of[qi] = 0 if min(occs) == 0 else sum(occs)
         return occ_of[qi]
-    # the sample: queries in random order whose lists fit what is left of the occurrence budget -- at least min_queries of them,
-    # each capped so that no single heavy query eats the budget (a 10^6-occurrence query costs 40 s on one core)
-    stats = np.zeros(4, dtype=np.uint64)
-    done, dt, remaining = 0, 0.0, budget_occ
+    # the sample: queries in random order whose lists fit what is left of the occurrence budget -- min_queries of them, each capped
+    # so that no single heavy query eats the budget (a 10^6-occurrence query costs 40 s on one core); it stops at min_queries
+    # queries or budget_s seconds, whichever comes first
     per_query_cap = budget_occ // min_queries * 2
+    sample, remaining = [], budget_occ
     for qi in order:
         need = need_of(int(qi))
         if need > remaining or need > per_query_cap:
             continue
-        t0 = time.perf_counter()
-        o.search(queries[qi], stats=stats)
-        dt += time.perf_counter() - t0
-        done += 1
+        sample.append(queries[qi])
         remaining -= need
-        if (dt > budget_s and done >= min_queries) or remaining < 1000 or done >= 5000 or dt > 3 * budget_s:
+        if len(sample) >= min_queries or remaining < 1000:
             break
+    t0 = time.perf_counter()
+    done, _, stats = O.search_many(o, sample, threads=1, budget_s=budget_s)
+    dt = time.perf_counter() - t0
     occ_rate = float(stats[0]) / dt if dt > 0 else 0.0
     # a sample's queries/s depends on which heavy queries it happened to draw; the stable figure is located
     # occurrences/s, converted with the exact mean occurrences per query of the full batch
@@ -163,43 +189,36 @@ def cpu_baseline(idx, queries, occ_per_query_mean, budget_occ=1600000, budget_s=
            "located_occ_per_sec": occ_rate, "sample_queries": done, "sample_seconds": dt,
            "sample_located_occ": int(stats[0]), "sample_lf_steps": int(stats[1]),
            "sample": "%d queries of the same batch, drawn in random order (seed 12345) while their occurrence lists fit a "
-                     "%d-occurrence budget (at most %d per query); %.1f s on one core; queries/s = sample occurrences/s / mean "
-                     "occurrences per query of the full batch (%.0f)" % (done, budget_occ, per_query_cap, dt, occ_per_query_mean)}
-    # disclosure: the same restatement on T = nproc threads over disjoint query shards
-    # (the C library is re-entrant and ctypes releases the GIL); the reference itself is single-threaded.
-    T = max(1, os.cpu_count() or 1)
+                     "%d-occurrence budget (at most %d per query; stops after %d queries or %.0f s); %.1f s on one core; queries/s = sample "
+                     "occurrences/s / mean occurrences per query of the full batch (%.0f)"
+                     % (done, budget_occ, per_query_cap, min_queries, budget_s, dt, occ_per_query_mean)}
+    # disclosure: the same restatement on T = nproc native threads; the reference itself is single-threaded
+    T = max(1, host_cpus()[0])
     if T > 1:
-        import concurrent.futures as cf
         light = []
         for qi in order:
             if 0 < need_of(int(qi)) <= 20000:
                 light.append(queries[qi])
-            if len(light) >= 24 * T:
+            if len(light) >= 400 * T:
                 break
-        shards = [light[i::T] for i in range(T)]
-
-        def run(shard):
-            st = np.zeros(4, dtype=np.uint64)
-            t0 = time.perf_counter()
-            for qq in shard:
-                o.search(qq, stats=st)
-                if time.perf_counter() - t0 > 10.0:
-                    break
-            return int(st[0])
         t0 = time.perf_counter()
-        with cf.ThreadPoolExecutor(T) as ex:
-            occ_t = sum(ex.map(run, shards))
+        done_t, _, st_t = O.search_many(o, light, threads=T, budget_s=threads_budget_s)
         dt_t = time.perf_counter() - t0
-        out["threads_T"] = {"threads": T, "located_occ_per_sec": occ_t / dt_t if dt_t > 0 else 0.0,
-                            "queries_per_sec": (occ_t / dt_t) / occ_per_query_mean if dt_t > 0 and occ_per_query_mean > 0 else 0.0,
-                            "sample_seconds": dt_t, "sample_located_occ": occ_t, "sample_queries": sum(len(s) for s in shards)}
+        rate_t = float(st_t[0]) / dt_t if dt_t > 0 else 0.0
+        out["threads_T"] = {"threads": T, "located_occ_per_sec": rate_t,
+                            "queries_per_sec": rate_t / occ_per_query_mean if occ_per_query_mean > 0 else 0.0,
+                            "speedup_over_one_core": rate_t / occ_rate if occ_rate > 0 else None,
+                            "sample_seconds": dt_t, "sample_located_occ": int(st_t[0]), "sample_queries": done_t,
+                            "what": "vlgo_search_many: %d native threads draw queries (each <= 20 000 occurrences) from a shared counter for "
+                                    "%.0f s; the index is only read" % (T, threads_budget_s)}
     return out
 
 
-def cpu_sasearch(text, queries, occ_per_query_mean, budget_occ=60000000, budget_s=12.0):
+def cpu_sasearch(text, queries, occ_per_query_mean, budget_occ=60000000, budget_s=8.0, threads_budget_s=5.0):
     """Disclosure (CPU baseline (3)): the benchmark's plain-suffix-array index -- text + SA, forward_search, sort,
-    join (index_sasearch.hpp) -- restated in the oracle, one thread, same random query order.  The suffix array comes from the
-    device sorter (vlg_suffix_array_device); building it is not part of the figure, as `load` is not in the reference's."""
+    join (index_sasearch.hpp) -- restated in the oracle, one thread and nproc native threads, same random query order.  The suffix
+    array comes from the device sorter (vlg_suffix_array_device); building it is not part of the figure, as `load` is not in the
+    reference's."""
     from oracle import oracle as O
     import numpy as np
     import torch
@@ -219,26 +238,40 @@ def cpu_sasearch(text, queries, occ_per_query_mean, budget_occ=60000000, budget_
     tz = np.concatenate([text, np.zeros(1, dtype=np.uint8)])
     s = O.SaSearch(tz, sa)
     rng = np.random.default_rng(12345)
-    stats = np.zeros(4, dtype=np.uint64)
-    done, dt, remaining = 0, 0.0, budget_occ
-    for qi in rng.permutation(len(queries)):
+    sample, remaining = [], budget_occ
+    order = rng.permutation(len(queries))
+    for qi in order:
         subs, _, _, _ = O.query_fields(O.parse(queries[qi]))
         need = sum(s.count(sp) for sp in subs)
         if need > remaining:
             continue
-        t0 = time.perf_counter()
-        s.search(queries[qi], stats=stats)
-        dt += time.perf_counter() - t0
-        done += 1
+        sample.append(queries[qi])
         remaining -= need
-        if dt > budget_s or remaining < 1000 or done >= 20000:
+        if remaining < 1000 or len(sample) >= 20000:
             break
+    t0 = time.perf_counter()
+    done, _, stats = O.search_many(s, sample, threads=1, budget_s=budget_s)
+    dt = time.perf_counter() - t0
     occ_rate = float(stats[0]) / dt if dt > 0 else 0.0
-    return {"algorithm": "SASEARCH (plain suffix array + text, index_sasearch.hpp)", "cores": 1, "kind": "port",
-            "queries_per_sec": occ_rate / occ_per_query_mean if occ_per_query_mean > 0 else 0.0, "located_occ_per_sec": occ_rate,
-            "sample_queries": done, "sample_seconds": dt, "sample_located_occ": int(stats[0]), "suffix_array_on_device_s": t_sa,
-            "note": "every sub-pattern's SA range is copied and sorted, query by query, as the reference does; "
-                    "queries/s = sample occurrences/s / mean occurrences per query of the full batch"}
+    out = {"algorithm": "SASEARCH (plain suffix array + text, index_sasearch.hpp)", "cores": 1, "kind": "port",
+           "queries_per_sec": occ_rate / occ_per_query_mean if occ_per_query_mean > 0 else 0.0, "located_occ_per_sec": occ_rate,
+           "sample_queries": done, "sample_seconds": dt, "sample_located_occ": int(stats[0]), "suffix_array_on_device_s": t_sa,
+           "note": "every sub-pattern's SA range is copied and sorted, query by query, as the reference does; "
+                   "queries/s = sample occurrences/s / mean occurrences per query of the full batch"}
+    T = max(1, host_cpus()[0])
+    if T > 1:
+        many = [queries[qi] for qi in order[:min(len(order), 200 * T)]]
+        t0 = time.perf_counter()
+        done_t, _, st_t = O.search_many(s, many, threads=T, budget_s=threads_budget_s)
+        dt_t = time.perf_counter() - t0
+        rate_t = float(st_t[0]) / dt_t if dt_t > 0 else 0.0
+        out["threads_T"] = {"threads": T, "located_occ_per_sec": rate_t,
+                            "queries_per_sec": rate_t / occ_per_query_mean if occ_per_query_mean > 0 else 0.0,
+                            "speedup_over_one_core": rate_t / occ_rate if occ_rate > 0 else None,
+                            "sample_seconds": dt_t, "sample_located_occ": int(st_t[0]), "sample_queries": done_t,
+                            "what": "vlgo_sasearch_many: the batch's queries in the same random order on %d native threads for %.0f s "
+                                    "(queries of any weight: a thread that draws a heavy one sorts millions of positions)" % (T, threads_budget_s)}
+    return out
 
 
 STRONG_FAILED_EXIT = 3          # exit code of every rank when the strong-scaling region failed or stalled (the JSON line is printed first)
@@ -317,6 +350,70 @@ def claim_stdout():
     return emit
 
 
+def other_config(name, steps, warmup, workspace_gb, tuples):
+    """One of BASELINE's other configs (C2 100 MiB DNA, C4 4 GiB protein with 10^6 queries, C5 1 GiB DNA on rrr-63
+    bit-vectors) on this GPU: text, index and batch made here, `steps` batches timed as the metric's are (resident batch, synchronize
+    on both sides), results checked against workload.EXPECTED -- the constants tests/test_gpu_fullsize.py asserts for the same batch."""
+    import torch
+    import vlg_matching_amd as V
+    from vlg_matching_amd import workload
+    from vlg_matching_amd.index import Queries, Workspace
+    cfg = workload.config(name)
+    t0 = time.perf_counter()
+    text = workload.gen_text(cfg["kind"], cfg["n"], cfg["seed"])
+    t_gen = time.perf_counter() - t0
+    d_text = torch.from_numpy(text).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx = V.VlgIndex.build_device(d_text.data_ptr(), len(text))
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    del d_text
+    if name == "C5":
+        idx = idx.compress()                                   # csa_wt<wt_huff<rrr_vector<63>>>
+    torch.cuda.empty_cache()
+    queries = workload.gen_queries(text, cfg["nq"], cfg["k"], cfg["m"], cfg["gap"], cfg["qseed"])
+    del text
+    q = Queries(queries)
+    ws = Workspace(int(workspace_gb * (1 << 30)))
+    ws.set_option("tuples", 1 if tuples else 0)
+    for _ in range(warmup):
+        idx.search(q, workspace=ws)
+    ws.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = idx.search(q, workspace=ws)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ks = ws.kernel_stats()
+    ws.profile(False)
+    sm = r.summary
+    info = idx.info()
+    want = workload.EXPECTED.get(name)
+    got = {k: sm[k] for k in ("n_matches", "checksum", "located_occurrences")}
+    if want is not None and got != want:
+        raise AssertionError("%s: %r, expected %r" % (name, got, want))
+    loc = ks["locate"]
+    launches = max(loc["launches"], 1)
+    ach = loc["algorithmic_bytes"] / (loc["total_ms"] * 1e-3) / 1e9 if loc["total_ms"] > 0 else 0.0
+    return {"workload": "%s: %s text n=%d (seed %d), %d queries x k=%d, m=%d, gap .{%d,%d}?, %s bit-vectors"
+                        % (name, cfg["kind"], cfg["n"], cfg["seed"], cfg["nq"], cfg["k"], cfg["m"], cfg["gap"][0], cfg["gap"][1],
+                           "rrr_vector<63>" if info["bv_kind"] else "plain"),
+            "ms_per_step": dt / steps * 1e3, "value": sm["n_queries"] * steps / dt, "unit": "queries/s", "steps": steps,
+            "located_occ_per_sec": sm["located_occurrences"] * steps / dt,
+            "matches_per_step": sm["n_matches"], "checksum": sm["checksum"], "located_occ_per_step": sm["located_occurrences"],
+            "checked_against_expected": want is not None,
+            "lf_steps_per_occ": sm["lf_steps"] / max(sm["located_occurrences"], 1), "chunks_per_step": sm["n_chunks"],
+            "index_hbm_bytes": info["hbm_bytes"], "index_build_s": t_build, "text_gen_s": t_gen,
+            "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in ks.items() if v["total_ms"] > 0},
+            "rank_kernel_roofline": {"bound": "hbm", "kernel_class": "locate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": ach / HBM_PEAK_GBS, "ms_per_step": loc["total_ms"] / steps,
+                                     "avg_launch_ms": loc["total_ms"] / launches, "launches": loc["launches"],
+                                     "algorithmic_bytes_per_launch": loc["algorithmic_bytes"] / launches,
+                                     "algorithmic_bytes_are": CLASSES["locate"][2]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,6 +428,10 @@ def main():
                          "array resident in HBM: 4 B x n, no LF walk in locate). Not the headline config unless 32.")
     ap.add_argument("--no-dense-sa", action="store_true", help="N = 1: skip the secondary run on the index that keeps the whole suffix array")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-configs", default="C2,C5,C4",
+                    help="N = 1, default config only: BASELINE's other single-GPU configs measured behind the metric's regions and reported in "
+                         "`other_configs` (each: ms per batch, matches / checksum checked against the constants the full-size tests assert, "
+                         "roofline of its rank kernel); '' = none")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling region")
     ap.add_argument("--strong-timeout", type=float, default=120.0,
                     help="N > 1: seconds the strong-scaling region may take before the weak-scaling line is printed without it")
@@ -506,7 +607,7 @@ def main():
 
     # ---- end to end, as SURVEY.md 8(d) words it: parse + H2D of the query batch, search, D2H of counts and first positions
     #      (pinned host buffers; the index upload is separate, as `load` is in gm_search.cpp:68-83) ---------------------------
-    e2e = None
+    e2e = r_e = r_p = None
     if not args.no_e2e:
         raws = [r.encode("latin-1") for r in queries]
         off = np.zeros(len(raws) + 1, dtype=np.uint64)
@@ -716,7 +817,8 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic_per_launch,
                     "traffic_detail": None if tr is None else {
                         "read_raw_per_step": rd, "read_if_all_wide_streaming_per_step": 2 * rd, "write_per_step": wr,
-                        "source": "profiles/pmc_traffic.json (%s)" % got[0].get("tag", ""),
+                        "source": "profiles/pmc_traffic.json (%s; counter passes taken at commit %s -- a kernel changed since then "
+                                  "makes its figure stale)" % (got[0].get("tag", ""), pmc.get("_meta", {}).get("commit", "unknown")),
                         "note": "FETCH_SIZE is exact for 64-byte random requests and reads half of a wide coalesced streaming read on "
                                 "gfx950 (MI355X_MICROARCH.md, HBM): both readings are given"},
                     # the other wall of this workload: random 64-byte read requests (K1, profiles/r01_k1_bitrank_kernel.json: 5.0e10 per
@@ -779,6 +881,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(plain_idx if info["bv_kind"] else idx, queries, n_logical / max(n_queries, 1))
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["cpu_baseline"]["host_cores_usable"] = host_cpus()[0]
+            out["cpu_baseline"]["host_cpu_quota_cores"] = host_cpus()[1]   # cgroup CPU quota (None: unlimited): what T threads can really get
             sas = cpu_sasearch(host_text, queries, n_logical / max(n_queries, 1))
             if sas is not None:
                 out["cpu_baseline"]["sasearch"] = sas
@@ -795,6 +899,23 @@ def main():
         strong = guarded_region(strong_region, dist.distributed_c10d._get_default_store(), rank, world, args.strong_timeout, report)
         if rank == 0:
             out["strong_scaling"] = strong
+    # ---- BASELINE's other single-GPU configs, behind everything the metric needs (their failure must not cost the line) ----------
+    if rank == 0 and world == 1 and args.config == "C3" and args.scale == 1.0 and args.sa_dens == 32 and args.other_configs:
+        idx = q = ws = res = plain_idx = r_e = r_p = None          # (the closures above see None from here on: their work is done)
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["other_configs"] = {}
+        for name in [c for c in args.other_configs.split(",") if c]:
+            t0 = time.perf_counter()
+            try:
+                out["other_configs"][name] = other_config(name, max(2, min(args.steps, 5)), 1, args.workspace_gb, bool(args.tuples))
+            except Exception as e:                                 # noqa: BLE001 -- reported in the line
+                import traceback
+                traceback.print_exc()
+                out["other_configs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["other_configs"][name]["wall_s"] = time.perf_counter() - t0
+            torch.cuda.empty_cache()
     if rank == 0:
         emit(out)
     if dist is not None:

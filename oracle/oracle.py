@@ -107,6 +107,11 @@ def lib():
         L.vlgo_search.restype = C.c_uint64
         L.vlgo_sasearch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(Query), C.c_void_p, C.c_uint64, C.c_void_p]
         L.vlgo_sasearch.restype = C.c_uint64
+        L.vlgo_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]
+        L.vlgo_search_many.restype = C.c_uint64
+        L.vlgo_sasearch_many.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_double,
+                                         C.c_void_p, C.c_void_p]
+        L.vlgo_sasearch_many.restype = C.c_uint64
         L.vlgo_sa_forward_search.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.vlgo_sa_forward_search.restype = C.c_uint64
         # integer alphabets / text-order sampling (vlg_oracle_int.c)
@@ -394,6 +399,27 @@ class Index:
         if stats is not None:
             stats += st
         return out[:m]
+
+
+def _blob(queries):
+    raws = [q.encode("latin-1") if isinstance(q, str) else bytes(q) for q in queries]
+    off = np.zeros(len(raws) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in raws])
+    return np.frombuffer(b"".join(raws) + b"\0", dtype=np.uint8), off
+
+
+def search_many(index, queries, threads=1, budget_s=1e9, dialect=0):
+    """The queries on `threads` native threads (vlgo_search_many; an Index or a SaSearch) -> (queries finished, matches, stats[4])."""
+    blob, off = _blob(queries)
+    st = np.zeros(4, dtype=np.uint64)
+    m = C.c_uint64(0)
+    if isinstance(index, SaSearch):
+        done = lib().vlgo_sasearch_many(index.text.ctypes.data, len(index.text), index.sa.ctypes.data, blob.ctypes.data, off.ctypes.data, len(queries),
+                                        dialect, threads, float(budget_s), st.ctypes.data, C.byref(m))
+    else:
+        done = lib().vlgo_search_many(index.h, blob.ctypes.data, off.ctypes.data, len(queries), dialect, threads, float(budget_s), st.ctypes.data,
+                                      C.byref(m))
+    return int(done), int(m.value), st
 
 
 class SaSearch:

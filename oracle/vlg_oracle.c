@@ -729,6 +729,88 @@ uint64_t vlgo_sasearch(const uint8_t* text, uint64_t n, const uint32_t* sa, cons
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Many queries on T threads (bench.py's cpu_baseline, disclosure lines): the reference's driver is one thread
+ * (gm_search.cpp:91-121); this is the same per-query code on a pool that draws queries from a shared counter, for the
+ * "what would all host cores do" figure.  The index / text are only read.  Stops drawing when budget_s of wall time have passed.
+ * stats (4 x u64, summed over the threads): located occurrences, LF steps, WT levels, backward-search ranks; *matches = tuples found.
+ * Returns the number of queries finished. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    const vlgo_index* x;                                    /* FM path ... */
+    const uint8_t* text; uint64_t n; const uint32_t* sa;    /* ... or SASEARCH when x is NULL */
+    const uint8_t* blob; const uint64_t* off; uint64_t nq; int dialect;
+    double budget_s; struct timespec t0;
+    uint64_t next;                                          /* shared cursor (atomic) */
+    pthread_mutex_t mu;
+    uint64_t stats[4], matches, done;
+} many_job;
+
+static double since(const struct timespec* t0)
+{
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0->tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0->tv_nsec);
+}
+
+static void* many_worker(void* arg)
+{
+    many_job* J = (many_job*)arg;
+    uint64_t st[4] = {0, 0, 0, 0}, matches = 0, done = 0;
+    for (;;) {
+        const uint64_t i = __atomic_fetch_add(&J->next, 1, __ATOMIC_RELAXED);
+        if (i >= J->nq || since(&J->t0) > J->budget_s) break;
+        vlgo_query q;
+        if (vlgo_parse(J->blob + J->off[i], J->off[i + 1] - J->off[i], J->dialect, &q) == VLGO_OK)
+            matches += J->x ? vlgo_search(J->x, &q, NULL, 0, st) : vlgo_sasearch(J->text, J->n, J->sa, &q, NULL, 0, st);
+        ++done;
+    }
+    pthread_mutex_lock(&J->mu);
+    for (int k = 0; k < 4; ++k) J->stats[k] += st[k];
+    J->matches += matches;
+    J->done += done;
+    pthread_mutex_unlock(&J->mu);
+    return NULL;
+}
+
+static uint64_t run_many(many_job* J, uint32_t n_threads, uint64_t* stats, uint64_t* matches)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    pthread_t th[1024];
+    uint32_t started = 0;
+    pthread_mutex_init(&J->mu, NULL);
+    clock_gettime(CLOCK_MONOTONIC, &J->t0);
+    for (; started + 1 < n_threads; ++started)
+        if (pthread_create(&th[started], NULL, many_worker, J) != 0) break;
+    many_worker(J);                                         /* the caller's thread is one of the pool */
+    for (uint32_t t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    pthread_mutex_destroy(&J->mu);
+    if (stats) for (int k = 0; k < 4; ++k) stats[k] += J->stats[k];
+    if (matches) *matches += J->matches;
+    return J->done;
+}
+
+uint64_t vlgo_search_many(const vlgo_index* x, const uint8_t* blob, const uint64_t* off, uint64_t nq, int dialect, uint32_t n_threads,
+                          double budget_s, uint64_t* stats, uint64_t* matches)
+{
+    many_job J;
+    memset(&J, 0, sizeof J);
+    J.x = x; J.blob = blob; J.off = off; J.nq = nq; J.dialect = dialect; J.budget_s = budget_s;
+    return run_many(&J, n_threads, stats, matches);
+}
+
+uint64_t vlgo_sasearch_many(const uint8_t* text, uint64_t n, const uint32_t* sa, const uint8_t* blob, const uint64_t* off, uint64_t nq, int dialect,
+                            uint32_t n_threads, double budget_s, uint64_t* stats, uint64_t* matches)
+{
+    many_job J;
+    memset(&J, 0, sizeof J);
+    J.text = text; J.n = n; J.sa = sa; J.blob = blob; J.off = off; J.nq = nq; J.dialect = dialect; J.budget_s = budget_s;
+    return run_many(&J, n_threads, stats, matches);
+}
+
+/* ------------------------------------------------------------------------------------------
  * rrr_vector<63> + rank_support_rrr<1,63>  (SURVEY a-11; BASELINE config 5)
  *   ctor    include/sdsl/rrr_vector.hpp:145-237   (block 63 bits, rank/pointer sample every 32 blocks,
  *                                                  per-superblock inversion of the stored classes)

@@ -125,6 +125,14 @@ uint64_t vlgo_sa_forward_search(const uint8_t* text, uint64_t n, const uint32_t*
 uint64_t vlgo_sasearch(const uint8_t* text, uint64_t n, const uint32_t* sa, const vlgo_query* q, uint64_t* tuples_out, uint64_t cap,
                        uint64_t* stats);
 
+/* Many queries (blob + offsets, nq + 1 of them) on n_threads threads drawing from a shared counter, until budget_s seconds have
+ * passed: what all host cores would make of the reference's single-threaded loop (gm_search.cpp:91-121).  stats / matches are
+ * summed over the threads (may be NULL); returns the number of queries finished. */
+uint64_t vlgo_search_many(const vlgo_index*, const uint8_t* blob, const uint64_t* off, uint64_t nq, int dialect, uint32_t n_threads,
+                          double budget_s, uint64_t* stats, uint64_t* matches);
+uint64_t vlgo_sasearch_many(const uint8_t* text, uint64_t n, const uint32_t* sa, const uint8_t* blob, const uint64_t* off, uint64_t nq,
+                            int dialect, uint32_t n_threads, double budget_s, uint64_t* stats, uint64_t* matches);
+
 /* ---- integer alphabets and text-order SA sampling (vlg_oracle_int.c) --------------------------------------------
  * csa_wt<wt_int<>, dens, ., sa_order | text_order sampling, ., int_alphabet<>> restated in the reference's layout. */
 typedef struct vlgo_int_index vlgo_int_index;

@@ -42,6 +42,8 @@ def c2():
 def test_c2_properties_and_mode_equivalence(c2):
     V, text, idx, queries, parts, cfg = c2
     from vlg_matching_amd.index import Workspace
+    from vlg_matching_amd import workload
+    workload.check_expected("C2", idx.search(queries[:cfg["nq"]]).summary)     # the config's own batch: the constants bench.py asserts too
     base = idx.search(queries)
     s = base.summary
     assert s["n_queries"] == len(queries) and s["n_matches"] > 1000
@@ -132,6 +134,7 @@ def test_c3_headline_config_modes_and_oracle_sample(oracle):
     ws = Workspace(100 << 30)
     a = idx.search(q, workspace=ws)
     sa = a.summary
+    workload.check_expected("C3", sa)                            # what bench.py's metric run returns (its checksum_rank0)
     assert sa["n_queries"] == cfg["nq"] and sa["logical_occurrences"] > 100 * sa["located_occurrences"] > 0
     ws.set_option("sweep", 0)                                    # random-access locate kernel instead of the sorted sweep
     b = idx.search(q, workspace=ws)
@@ -244,6 +247,7 @@ def test_c5_one_gib_dna_rrr_full_size(oracle):
     q = Queries(queries)
     lap("queries")
     ws = Workspace(100 << 30)
+    workload.check_expected("C5", rrr.search(queries[:cfg["nq"]], workspace=ws).summary)      # the config's own batch (bench.py: other_configs)
     base = rrr.search(q, workspace=ws)
     s = base.summary
     assert s["n_queries"] == len(queries) and s["n_matches"] > 1000 and s["located_occurrences"] > 10 ** 7
@@ -338,6 +342,13 @@ def test_c4_four_gib_text_64bit_positions(oracle):
             assert text[p: p + cfg["m"]].tobytes() == subs[i]
     # beyond-2^32 arithmetic: some occurrence must lie in the top half of the text
     assert (t[:, 0] >= (1 << 31)).any()
+    # the config's whole batch (10^6 queries): the constants bench.py's other_configs asserts
+    del res
+    full = workload.gen_queries(text, cfg["nq"], cfg["k"], cfg["m"], cfg["gap"], cfg["qseed"])
+    assert full[:nq] == queries
+    workload.check_expected("C4", idx.search(full, workspace=Workspace(140 << 30)).summary)
+    del full
+    res = idx.search(queries, workspace=Workspace(100 << 30))
     # bounded oracle sample on the device-built parts (CPU algorithm, reference layout)
     o = oracle.Index.from_parts(idx.export_parts())
     done = 0

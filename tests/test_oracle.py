@@ -475,3 +475,34 @@ def test_vlg_iterator_skips_the_odd_twin_of_adjacent_single_symbol_matches(oracl
     assert got == [[1], [2], [4], [6]]        # 5 = the odd twin of 4 is skipped; (1, 2) is not an even-aligned pair
     c, l, r = idx.backward_search(b"CC")
     assert w.vlg_iterate([(l, r)], [], [], 2).tolist() == idx.search("CC").tolist() == [[1], [4]]
+
+
+def test_search_many_threads_equal_the_single_query_calls(oracle):
+    """vlgo_search_many / vlgo_sasearch_many (bench.py's T-thread CPU baseline): a pthread pool drawing queries from a shared counter
+    finds what the per-query calls find -- matches and located occurrences summed over the threads -- on 1, 3 and 8 threads; a
+    zero time budget draws nothing more once it has run out."""
+    O = oracle
+    text = dna_text(20000, 9).tobytes()
+    o = O.Index.from_text(text)
+    rng = np.random.default_rng(3)
+    qs = []
+    for _ in range(150):
+        a, b = (int(x) for x in rng.integers(0, len(text) - 8, 2))
+        qs.append("%s.{0,60}?%s" % (text[a:a + int(rng.integers(2, 6))].decode(), text[b:b + int(rng.integers(2, 6))].decode()))
+    qs += ["A.{5,1}?C", "", "ACGT"]                                          # a query that does not parse is drawn and skipped
+    st = np.zeros(4, dtype=np.uint64)
+    want = 0
+    for q in qs:
+        try:
+            want += len(o.search(q, stats=st))
+        except O.ParseError:
+            pass
+    tz = np.frombuffer(text + b"\0", dtype=np.uint8)
+    sas = O.SaSearch(tz, O.suffix_array(tz))
+    for T in (1, 3, 8):
+        done, m, s2 = O.search_many(o, qs, threads=T)
+        assert (done, m) == (len(qs), want) and (s2 == st).all(), T
+        done, m, s3 = O.search_many(sas, qs, threads=T)
+        assert (done, m) == (len(qs), want) and int(s3[0]) == int(st[0]), T
+    done, m, _ = O.search_many(o, qs * 50, threads=2, budget_s=0.0)
+    assert done <= 2                                                          # each thread notices the budget before its second draw

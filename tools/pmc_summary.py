@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes into profiles/pmc_traffic.json (HBM bytes per launch per kernel).
 
-usage: tools/pmc_summary.py <counter_collection.csv with FETCH_SIZE> <counter_collection.csv with WRITE_SIZE> [tag] [search steps in the run]
+usage: tools/pmc_summary.py <counter_collection.csv with FETCH_SIZE> <counter_collection.csv with WRITE_SIZE> [tag] [search steps in the run] [commit]
+(commit: the tree the passes were taken on -- bench.py quotes it beside every traffic figure, which goes stale when a kernel changes)
 FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3).  gfx950 caveat (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reads half
 the bytes of wide coalesced streaming reads; for the 64-byte random requests of this workload tools/k1_bench.py
 calibrates it at 1.0 (FETCH_SIZE = TCC_EA0_RDREQ x 64 B, one request per 32-byte block read).  Both raw and
@@ -42,7 +43,8 @@ def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     tag = sys.argv[3] if len(sys.argv) > 3 else ""
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-    out = {"_meta": {"tag": tag, "steps_profiled": steps,
+    commit = sys.argv[5] if len(sys.argv) > 5 else os.environ.get("VLG_COMMIT", "unknown")
+    out = {"_meta": {"tag": tag, "steps_profiled": steps, "commit": commit,
                      "note": "launches = launches of the kernel in the whole profiled run (steps_profiled passes of the hot path, warm-up included)"}}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, []), write.get(k, [])

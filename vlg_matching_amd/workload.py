@@ -17,6 +17,22 @@ CONFIGS = {
     "C5": dict(kind="dna_pc", n=1 << 30, seed=5, nq=100000, k=2, m=12, gap=(0, 100), qseed=15),
 }
 
+# What the configs' batches return (gen_queries(text, nq, k, m, gap, qseed) of the config, library dialect) -- exact integers, the
+# same on every run: bench.py's `other_configs` and tests/test_gpu_fullsize.py both assert them.  None = not recorded yet.
+EXPECTED = {
+    "C2": {"n_matches": 144, "checksum": 6970539074, "located_occurrences": 2551964},
+    "C3": {"n_matches": 305002331, "checksum": 163759923662180697, "located_occurrences": 637097700},
+    "C4": {"n_matches": 255088, "checksum": 547974346109916, "located_occurrences": 2798227671},
+    "C5": {"n_matches": 80, "checksum": 42340285501, "located_occurrences": 17372402},
+}
+
+
+def check_expected(name, summary):
+    """The batch of config `name` returned what it always returns (exact integers)."""
+    want = EXPECTED[name]
+    got = {k: summary[k] for k in want}
+    assert got == want, (name, got, want)
+
 _PROTEIN = [("A", 825), ("R", 553), ("N", 406), ("D", 545), ("C", 137), ("Q", 393), ("E", 675), ("G", 707), ("H", 227),
             ("I", 596), ("L", 966), ("K", 584), ("M", 242), ("F", 386), ("P", 470), ("S", 656), ("T", 534), ("W", 108),
             ("Y", 292), ("V", 687)]
