@@ -438,6 +438,9 @@ def main():
     ap.add_argument("--strong-sharding", choices=["lists", "affinity", "work"], default="lists",
                     help="strong-scaling region: 'lists' = collective search (distinct lists sharded for locate + sort, sorted lists "
                          "all-gathered, queries sharded for the joins); 'affinity' / 'work' = only the query loop is sharded")
+    ap.add_argument("--exchange", choices=["needed", "allgather"], default="needed",
+                    help="strong-scaling region with --strong-sharding lists: 'needed' = a sorted list travels only to the ranks whose queries "
+                         "use it, pairwise (vlg_comm_alltoallv); 'allgather' = every list to every rank (vlg_comm_allgatherv)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (parse + H2D + search + D2H) region")
     ap.add_argument("--tuples", action="store_true", help="also materialise every sub-pattern position of every match (sdsl::locate output)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -724,8 +727,11 @@ def main():
                 dist.barrier()
                 t_bx = time.perf_counter() - t0x
                 ws.set_comm(comm_x)
-            else:
+            elif args.exchange == "allgather":
                 ws.set_exchange(world, rank, vdist.host_exchange(dist))
+            else:
+                ws.set_exchange_alltoall(world, rank, vdist.host_alltoall(dist))
+            ws.set_option("exchange_all", 1 if args.exchange == "allgather" else 0)
             idx_s.search(qs, workspace=ws)                         # warm-up
             ws.profile(True)
             dt_s, my_dt_s, r_s = timed(lambda: idx_s.search(qs, workspace=ws), args.steps)
@@ -744,7 +750,10 @@ def main():
                       "per_rank": [{"ms_per_step": p[0], "queries": int(p[1]), "located_occ": int(p[2]), "exchange_ms": p[3],
                                     "exchange_bytes_received": int(p[4])} for p in pr],
                       "sharding": "lists",
-                      "exchange": "vlg_comm_allgatherv (RCCL)" if comm_x is not None else "host (gloo rehearsal)",
+                      "exchange": ("%s, %s" % ("pairwise, needed lists only" if args.exchange == "needed" else "in-place all-gather of every list",
+                                               ("vlg_comm_alltoallv (RCCL)" if args.exchange == "needed" else "vlg_comm_allgatherv (RCCL)")
+                                               if comm_x is not None else "host (gloo rehearsal)")),
+                      "exchange_bytes_all_gather_would_receive": [int(4 * (tocc - p[2])) for p in pr],
                       "index_broadcast_rccl_s": t_bx,
                       "index_broadcast_rccl": None if comm_x is None else
                       "vlg_index_broadcast of %d bytes over %s; ranks > 0 searched the image they received" % (info["hbm_bytes"], comm_x.library()),

@@ -489,6 +489,24 @@ vlg_status vlg_workspace_kernel_stats(vlg_workspace* ws, vlg_kernel_stat* out, u
 typedef int (*vlg_exchange_fn)(void* ctx, void* d_buf, const uint64_t* h_counts, uint32_t elem_bytes, int n_ranks, int rank, void* stream);
 vlg_status vlg_workspace_set_comm(vlg_workspace* ws, void* nccl_comm);
 vlg_status vlg_workspace_set_exchange(vlg_workspace* ws, int n_ranks, int rank, vlg_exchange_fn fn, void* ctx);
+/* The exchange step as it runs by default over a communicator: PAIRWISE and NEEDED-ONLY.  Every rank knows the whole plan of the
+ * batch (which rank sorts which list, which rank joins which queries), so a sorted list travels only to the ranks whose queries
+ * use it: the lists a rank owes a peer are packed into one buffer per peer and sent point to point -- vlg_comm_alltoallv, one
+ * grouped ncclSend / ncclRecv pair per peer, one xGMI link each -- instead of every list visiting every rank in a ring.  Workspace
+ * option "exchange_all" = 1 goes back to the in-place all-gather of everything (vlg_comm_allgatherv).
+ * vlg_workspace_set_exchange_alltoall: the same with the caller moving the bytes (hosts without RCCL between their ranks,
+ * rehearsals on one device): fn sends h_send_counts[r] elements to rank r (packed in rank order at d_send) and receives
+ * h_recv_counts[r] from it (packed at d_recv), its own piece included, ordered with `stream`.
+ * Before the payload moves, the ranks all-gather ONE status word each: a rank whose part of the batch failed up to there (workspace
+ * too small for its share, out of memory, a failed kernel) tells the others, and vlg_search_batch returns an error on EVERY rank --
+ * its own on the failed one, VLG_E_INTERNAL "rank r failed ..." on its peers -- instead of leaving them inside a collective.
+ * An error after the exchange (in a rank's joins) is that rank's alone: the product issues no further collective; a caller that
+ * reduces counters afterwards (vlg_comm_allreduce_sum_u64) has to handle it like any failure of one of its own ranks. */
+vlg_status vlg_comm_alltoallv(void* nccl_comm, const void* d_send, const uint64_t* h_send_counts, void* d_recv,
+                              const uint64_t* h_recv_counts, uint32_t elem_bytes, void* stream);
+typedef int (*vlg_alltoall_fn)(void* ctx, const void* d_send, const uint64_t* h_send_counts, void* d_recv, const uint64_t* h_recv_counts,
+                               uint32_t elem_bytes, int n_ranks, int rank, void* stream);
+vlg_status vlg_workspace_set_exchange_alltoall(vlg_workspace* ws, int n_ranks, int rank, vlg_alltoall_fn fn, void* ctx);
 /* [begin, end) pairs of the queries this rank joined in a collective search (n_ranges = 0: a single-GPU search, all of them) */
 vlg_status vlg_result_owned_queries(const vlg_result* r, uint64_t* h_ranges, uint32_t cap_ranges, uint32_t* n_ranges);
 

@@ -1127,7 +1127,7 @@ def test_replicate_index_two_ranks_on_one_device(V, oracle):
 
 def _nccl_one_rank_worker(port, text, queries, out_q):
     """Everything bench.py does with the `nccl` backend, in a 1-rank process group on cuda:0, plus the product's own RCCL entry
-    points (vlg_comm_*, vlg_index_broadcast, vlg_comm_allgatherv)."""
+    points (vlg_comm_*, vlg_index_broadcast, vlg_comm_allgatherv, vlg_comm_alltoallv)."""
     import torch
     import torch.distributed as dist
     import vlg_matching_amd as V
@@ -1162,6 +1162,8 @@ def _nccl_one_rank_worker(port, text, queries, out_q):
     send = torch.arange(1000, dtype=torch.int32, device=dev)
     recv = torch.zeros(1000, dtype=torch.int32, device=dev)
     comm.allgatherv(send.data_ptr(), [1000], 4, recv.data_ptr())
+    recv2 = torch.zeros(1000, dtype=torch.int32, device=dev)
+    comm.alltoallv(send.data_ptr(), [1000], recv2.data_ptr(), [1000], 4)      # (one rank: its own piece, a device copy inside the group)
     torch.cuda.synchronize()
     r2 = vdist.replicate_index(idx0, dist, dev, src=0, comm=comm).search(queries)
     # collective search over the (one-rank) communicator: list-sharded locate, exchange through vlg_comm_allgatherv, query-sharded joins
@@ -1175,7 +1177,7 @@ def _nccl_one_rank_worker(port, text, queries, out_q):
     comm.close()
     out_q.put({"counts": [int(c) for c in r.counts], "tot": [int(x) for x in tot.tolist()], "max": float(t.item()), "chk": chk,
                "gathered": float(outl[0].item()), "comm": (n_ranks, rank), "same": same is idx0, "sums": sums,
-               "recv_ok": bool((recv == send).all().item()), "counts2": [int(c) for c in r2.counts], "rccl": lib_path,
+               "recv_ok": bool((recv == send).all().item()) and bool((recv2 == send).all().item()), "counts2": [int(c) for c in r2.counts], "rccl": lib_path,
                "counts3": [int(c) for c in r3.counts], "owned": owned, "chk3": int(r3.summary["checksum"]),
                "summary": {k: int(v) for k, v in r.summary.items()}})
     dist.barrier()
@@ -1341,6 +1343,8 @@ def _int_texts():
         "words": (1 + rng.zipf(1.3, 20000) % 3000).astype(np.uint32),          # word-level text: large alphabet, Zipf frequencies
         "one": np.array([42], dtype=np.uint32),
         "run": np.full(300, 9, dtype=np.uint32),
+        # the reference's own integer fixture (test/test_cases/keeper.int, csa_int_test.config:7: 63 symbols of 8 bytes), kept as data
+        "keeper": np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keeper.int"), dtype="<u8").astype(np.uint32),
     }
 
 
@@ -1358,7 +1362,7 @@ def _int_queries(text, rng, nq, kmax=3, mmax=3, gapmax=40):
     return qs
 
 
-@pytest.mark.parametrize("name", ["survey", "abra", "sparse", "words", "one", "run"])
+@pytest.mark.parametrize("name", ["survey", "abra", "sparse", "words", "one", "run", "keeper"])
 def test_integer_alphabet_fm_index(torch_cuda, V, oracle, name):
     """csa_wt<wt_int<>, 32, ., ., ., int_alphabet<>> on the device (vlg_index_build_int) against its restatement in the
     reference's layout (oracle/vlg_oracle_int.c, pinned by the reference's own wt_int<> / int_alphabet<>): alphabet, wt_int::rank
@@ -1462,11 +1466,23 @@ def _collective_worker(rank, world, port, text, queries, opts, out_q):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     idx = vdist.replicate_index(V.VlgIndex.build(text) if rank == 0 else None, dist, torch.device("cuda", 0), src=0)
-    ws = Workspace()
+    opts = dict(opts)
+    mode = opts.pop("_exchange", "alltoall")
+    cap = opts.pop("_cap_of_rank", {}).get(rank, 0)
+    ws = Workspace(cap)
     for k_, v_ in opts.items():
         ws.set_option(k_, v_)
-    ws.set_exchange(world, rank, vdist.host_exchange(dist))
-    r = idx.search(queries, workspace=ws)
+    if mode == "alltoall":
+        ws.set_exchange_alltoall(world, rank, vdist.host_alltoall(dist))       # needed lists only, pairwise (the default over RCCL)
+    else:
+        ws.set_exchange(world, rank, vdist.host_exchange(dist))                # every list to every rank: in-place all-gather
+    try:
+        r = idx.search(queries, workspace=ws)
+    except V.VlgError as e:                                                    # (the agreement test: every rank reports how it failed)
+        out_q.put((rank, "error", e.status, str(e)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     owned = r.owned_queries()
     counts = [int(c) for c in r.counts]
     tuples = {}
@@ -1474,18 +1490,22 @@ def _collective_worker(rank, world, port, text, queries, opts, out_q):
         for i in range(a, b):
             tuples[i] = r.tuples(i).tolist()
     st = ws.kernel_stats()
-    out_q.put((rank, owned, counts, tuples, {k: int(v) for k, v in r.summary.items()}, st["exchange"]["launches"]))
+    out_q.put((rank, owned, counts, tuples, {k: int(v) for k, v in r.summary.items()}, st["exchange"]["launches"], st["exchange"]["algorithmic_bytes"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,opts", [(2, {}), (3, {"sweep_min": 1, "sweep_tail": 64, "filter_min": 0, "filter_stream_min": 0}),
-                                        (2, {"list_sort": 0, "global_sort_min": 1 << 40})])
+                                        (4, {"sweep_min": 1, "sweep_tail": 16}),
+                                        (2, {"list_sort": 0, "global_sort_min": 1 << 40}), (2, {"_exchange": "allgather"}),
+                                        (3, {"_exchange": "allgather", "sweep_min": 1, "sweep_tail": 64, "filter_min": 0, "filter_stream_min": 0})])
 def test_collective_search_shards_lists_and_queries(V, oracle, world, opts):
-    """The exchange step (SURVEY.md 8e strong scaling): `world` ranks on ONE device, the pieces moved through gloo on the host
-    (vlg_workspace_set_exchange) -- every rank locates + sorts only its share of the distinct lists (the shares add up to the 1-GPU
-    figure: nothing is located twice), receives the others' sorted lists, joins its piece of the queries; pieces are disjoint and
-    cover the batch, tuples equal the single-process run and the oracle."""
+    """The exchange step (SURVEY.md 8e strong scaling): `world` ranks on ONE device, the pieces moved through gloo on the host --
+    every rank locates + sorts only its share of the distinct lists (the shares add up to the 1-GPU figure: nothing is located
+    twice), receives sorted lists of the others, joins its piece of the queries; pieces are disjoint and cover the batch, tuples
+    equal the single-process run and the oracle.  Default: the pairwise, needed-only exchange (vlg_workspace_set_exchange_alltoall:
+    a list travels only to the ranks whose queries use it -- fewer bytes received than the all-gather's); "_exchange": "allgather" =
+    every list to every rank (vlg_workspace_set_exchange)."""
     import socket
     import torch.multiprocessing as mp
     text = skewed_text(60000, 41).tobytes()
@@ -1506,8 +1526,15 @@ def test_collective_search_shards_lists_and_queries(V, oracle, world, opts):
         p.join(timeout=120)
         assert p.exitcode == 0
     covered = []
-    for rank, owned, counts, tuples, summ, xl in got:
+    total = one.summary["located_occurrences"]
+    for rank, owned, counts, tuples, summ, xl, xbytes in got:
         assert len(owned) == 1 and xl >= 1
+        # bytes received: everything but the own share with the all-gather, no more than that -- and less, unless the rank's queries
+        # happen to use every list -- with the needed-only exchange
+        if opts.get("_exchange") == "allgather":
+            assert xbytes == 4 * (total - summ["located_occurrences"])
+        else:
+            assert xbytes <= 4 * (total - summ["located_occurrences"])
         a, b = owned[0]
         covered.append((a, b))
         assert all(c == 0 for i, c in enumerate(counts) if not (a <= i < b))
@@ -1521,10 +1548,40 @@ def test_collective_search_shards_lists_and_queries(V, oracle, world, opts):
     assert sum(g[4]["checksum"] for g in got) % (1 << 64) == one.summary["checksum"]
     located = [g[4]["located_occurrences"] for g in got]
     assert sum(located) == one.summary["located_occurrences"]                 # every distinct list located exactly once
+    if opts.get("_exchange") != "allgather":
+        assert sum(g[6] for g in got) < 4 * (world - 1) * total                # (all-gather: (world - 1) x every occurrence)
     assert max(located) <= one.summary["located_occurrences"] / world * 2 + 20000     # shares are cut between lists: balanced up to one list
     o = oracle.Index.from_text(text)
     for i in (0, 99, 250, 399):
         assert one.tuples(i).tolist() == o.search(queries[i]).tolist()
+
+
+@pytest.mark.parametrize("mode", ["alltoall", "allgather"])
+def test_collective_search_agrees_on_a_failed_rank(V, mode):
+    """A rank whose share of a collective search cannot run (here: a workspace cap too small for its plan) says so in the status
+    all-gather that precedes every exchange: vlg_search_batch returns an error on EVERY rank -- VLG_E_WORKSPACE on the one that
+    failed, VLG_E_INTERNAL naming it on its peers -- and nobody is left waiting inside a collective."""
+    import socket
+    import torch.multiprocessing as mp
+    text = skewed_text(60000, 41).tobytes()
+    queries = random_queries(text, np.random.default_rng(43), 400, kmax=4, mmax=3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    opts = {"_exchange": mode, "_cap_of_rank": {1: 17 << 20}}                 # 17 MiB: 16 MiB are fixed overhead, the lists do not fit the rest
+    procs = [ctx.Process(target=_collective_worker, args=(r, 2, port, text, queries, opts, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(out_q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == ["error", "error"], got
+    assert got[1][2] == V.capi.E_WORKSPACE
+    assert got[0][2] == V.capi.E_INTERNAL and "rank 1 failed" in got[0][3]
 
 
 def test_narrow_results_widen_on_fetch(torch_cuda, V, oracle, monkeypatch):

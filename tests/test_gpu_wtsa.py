@@ -178,16 +178,21 @@ def test_integer_alphabet_index_vs_brute_force(V, oracle):
         V.VlgIndex.build(b"abcabc").search(idx.queries(["1 2"]))
 
 
-@pytest.mark.parametrize("name", ["abracadabra", "one_byte", "100a", "dna", "zipf", "ints"])
+@pytest.mark.parametrize("name", ["abracadabra", "one_byte", "100a", "dna", "zipf", "ints", "keeper"])
 def test_tree_equals_reference_wt_int(V, oracle, refmod, name):
     """The device tree against the reference's OWN wt_int<bit_vector_il<>, rank_support_il<>> (oracle/_ref, built by its constructor
     from the same suffix array, as construct(wts, KEY_SA) does, vlg_index.hpp:386-387): number of levels, every level's bits ==
     wt_int::tree, wt[i] for every i (wt_int.hpp:339-361), and count_less / quantile on random suffix-array ranges == what the
     reference's expand(v) / expand(v, range) descent answers (wt_int.hpp:824-939)."""
     import torch
-    if name == "ints":
+    if name in ("ints", "keeper"):
         rng = np.random.default_rng(8)
-        itext = rng.choice(np.array([3, 7, 7, 19, 1000, 70000, 2 ** 31 + 5], dtype=np.uint32), 1500)
+        if name == "keeper":                     # the reference's own integer fixture (test/test_cases/keeper.int; csa_int_test.config:7)
+            import os
+            itext = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keeper.int"), dtype="<u8").astype(np.uint32)
+            assert len(itext) == 63 and int(itext.max()) == 21
+        else:
+            itext = rng.choice(np.array([3, 7, 7, 19, 1000, 70000, 2 ** 31 + 5], dtype=np.uint32), 1500)
         idx = V.WtsaIndex(itext)
         vals = np.concatenate([itext.astype(np.int64) + 1, [0]])                 # the sentinel is smaller than every symbol
         sa = np.array(sorted(range(len(vals)), key=lambda i: vals[i:].tolist()), dtype=np.uint64)

@@ -322,10 +322,12 @@ def _int_texts():
         "sparse": rng.choice(np.array([3, 7, 7, 19, 1000, 70000, 2 ** 31 + 5], dtype=np.uint64), 900),
         "dense": rng.integers(1, 40, 700).astype(np.uint64),                   # continuous alphabet 0..39 (int_alphabet's direct map)
         "one": np.array([42], dtype=np.uint64),
+        # the reference's own integer fixture (test/test_cases/keeper.int, csa_int_test.config:7: 63 symbols of 8 bytes), kept as data
+        "keeper": np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keeper.int"), dtype="<u8"),
     }
 
 
-@pytest.mark.parametrize("name", ["survey", "abra", "sparse", "dense", "one"])
+@pytest.mark.parametrize("name", ["survey", "abra", "sparse", "dense", "one", "keeper"])
 def test_int_fm_oracle_pinned_by_reference_wt_int_and_int_alphabet(oracle, refmod, name):
     """The integer-alphabet FM-index restatement (vlg_oracle_int.c) against the reference's OWN wt_int<> and int_alphabet<> built by
     their constructors over the same BWT (oracle/_ref): tree bits, levels, rank(i, c) for present and absent symbols,

@@ -59,6 +59,8 @@ class KernelStat(C.Structure):
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_int, C.c_int, C.c_void_p)
+ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_int, C.c_int,
+                          C.c_void_p)
 
 # every symbol include/vlg_hip.h declares: (name, restype, argtypes)
 _P, _U64, _I = C.c_void_p, C.c_uint64, C.c_int
@@ -100,6 +102,7 @@ SYMBOLS = [
     ("vlg_index_broadcast", _I, [_P, _P, _I, _P, C.POINTER(_P)]),
     ("vlg_comm_allreduce_sum_u64", _I, [_P, _P, C.c_uint32, _P]),
     ("vlg_comm_allgatherv", _I, [_P, _P, _P, C.c_uint32, _P, _P]),
+    ("vlg_comm_alltoallv", _I, [_P, _P, _P, _P, _P, C.c_uint32, _P]),
     ("vlg_bitvector_create", _I, [_P, _U64, C.POINTER(_P)]),
     ("vlg_bitvector_rank_batch", _I, [_P, _P, _P, _U64, _P]),
     ("vlg_bitvector_hbm_bytes", _U64, [_P]),
@@ -143,6 +146,7 @@ SYMBOLS = [
     ("vlg_workspace_kernel_stats", _I, [_P, C.POINTER(KernelStat), C.c_uint32, C.POINTER(C.c_uint32)]),
     ("vlg_workspace_set_comm", _I, [_P, _P]),
     ("vlg_workspace_set_exchange", _I, [_P, _I, _I, _P, _P]),
+    ("vlg_workspace_set_exchange_alltoall", _I, [_P, _I, _I, _P, _P]),
     ("vlg_result_owned_queries", _I, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
 ]
 

@@ -263,3 +263,41 @@ extern "C" vlg_status vlg_comm_allgatherv(void* nccl_comm, const void* d_send, c
     VLG_NCCL_TRY(rc2);
     return VLG_OK;
 }
+
+// All-to-all-v of device buffers over the xGMI mesh: this rank sends h_send_counts[r] elements to rank r -- packed one after the other
+// in rank order at d_send -- and receives h_recv_counts[r] elements from rank r, packed likewise at d_recv; its own piece is a
+// device copy.  One grouped ncclSend / ncclRecv pair per peer: every pair of GPUs has its own xGMI link, so the N - 1 transfers of a
+// rank run side by side at link rate instead of queueing behind each other on a ring (what a group of broadcasts does).
+extern "C" vlg_status vlg_comm_alltoallv(void* nccl_comm, const void* d_send, const uint64_t* h_send_counts, void* d_recv,
+                                         const uint64_t* h_recv_counts, uint32_t elem_bytes, void* stream)
+{
+    int n = 0, rank = 0;
+    if (vlg_status s = comm_shape(nccl_comm, n, rank)) return s;
+    if (!h_send_counts || !h_recv_counts || !elem_bytes) return fail(VLG_E_INVALID, "null argument");
+    if (h_send_counts[rank] != h_recv_counts[rank]) return fail(VLG_E_INVALID, "a rank sends itself as much as it receives from itself");
+    uint64_t ts = 0, tr = 0;
+    for (int r = 0; r < n; ++r) { ts += h_send_counts[r]; tr += h_recv_counts[r]; }
+    if ((ts && !d_send) || (tr && !d_recv)) return fail(VLG_E_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    VLG_NCCL_TRY(rccl().GroupStart());
+    uint64_t so = 0, ro = 0;
+    int rc = ncclSuccess;
+    hipError_t he = hipSuccess;
+    for (int r = 0; r < n && rc == ncclSuccess && he == hipSuccess; ++r) {
+        const uint8_t* sp = (const uint8_t*)d_send + so * elem_bytes;
+        uint8_t* rp = (uint8_t*)d_recv + ro * elem_bytes;
+        if (r == rank) {
+            if (h_send_counts[r]) he = hipMemcpyAsync(rp, sp, h_send_counts[r] * (uint64_t)elem_bytes, hipMemcpyDeviceToDevice, st);
+        } else {
+            if (h_send_counts[r]) rc = rccl().Send(sp, h_send_counts[r] * (uint64_t)elem_bytes, ncclUint8, r, (ncclComm_t)nccl_comm, st);
+            if (rc == ncclSuccess && h_recv_counts[r]) rc = rccl().Recv(rp, h_recv_counts[r] * (uint64_t)elem_bytes, ncclUint8, r, (ncclComm_t)nccl_comm, st);
+        }
+        so += h_send_counts[r];
+        ro += h_recv_counts[r];
+    }
+    const int rc2 = rccl().GroupEnd();
+    VLG_NCCL_TRY(rc);
+    VLG_NCCL_TRY(rc2);
+    VLG_HIP_TRY(he);
+    return VLG_OK;
+}

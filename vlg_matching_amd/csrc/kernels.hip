@@ -725,11 +725,14 @@ __global__ void __launch_bounds__(256) sa_dense_copy_kernel(const sample_t* __re
 // rec[slot]: a position (high bits 0), or delta << kShift | slot of the element it follows; ~0 while the element is still walking.
 // slot0 = first slot of the sweep.
 // one element of one round: v64 = its word (slot << kShift | SA index), e = its place in val / key
-template <class BV, typename pos_t, bool kTrail, bool kWide, bool kFirst = false, class Sampling>
+// kAhead (round 0): the index an element steps ONTO is looked up at once -- six in ten elements of a dense batch stand next to
+// another occurrence in the text -- so that they leave the sweep before its largest partition instead of after it; `probed` tells
+// round 1 that its elements have been looked up already.
+template <class BV, typename pos_t, bool kTrail, bool kWide, bool kFirst = false, bool kAhead = false, class Sampling>
 __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds<BV>& s, const Sampling& sampling, uint64_t e, uint64_t v64,
                                               uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint32_t step, pos_t* __restrict__ out,
                                               const Block* __restrict__ member, uint64_t* __restrict__ rec, uint64_t slot0,
-                                              uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin)
+                                              uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin, bool probed = false)
 {
     constexpr uint32_t kShift = kWide ? 33 : 32;
     constexpr uint64_t kPosMask = (1ull << kShift) - 1;
@@ -743,7 +746,7 @@ __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds
         else out[v64 >> kShift] = (pos_t)r;
         key[e] = (uint16_t)iv.sigma;
         ++n_fin;
-    } else if (kTrail && !kFirst && member_probe(member, i, owner)) {
+    } else if (kTrail && !kFirst && !probed && member_probe(member, i, owner)) {
         // (round 0: every element stands on its own index.)  Index i is where element `owner` started: same text trail, `step`
         // positions further left
         const uint64_t delta = step;
@@ -772,8 +775,17 @@ __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds
             v = ch;
         }
         ++n_lf;
-        val[e] = (v64 & ~kPosMask) | (s.C[c] + pos);                          // LF: suffix_array_helper.hpp:341-348
-        key[e] = (uint16_t)c;
+        const uint64_t j = s.C[c] + pos;                                      // LF: suffix_array_helper.hpp:341-348
+        if (kTrail && kAhead && member_probe(member, j, owner)) {
+            // (the owner is in its own round 0 right now: its record reads "still walking" or is not written yet -- either way this
+            // element follows it)
+            rec[slot0 + (v64 >> kShift)] = ((uint64_t)(step + 1) << kShift) | owner;
+            key[e] = (uint16_t)iv.sigma;
+            ++n_fin;
+        } else {
+            val[e] = (v64 & ~kPosMask) | j;
+            key[e] = (uint16_t)c;
+        }
     }
 }
 
@@ -782,7 +794,7 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
                                                          uint32_t step, pos_t* __restrict__ out,
                                                          unsigned long long* __restrict__ stats /* lf, levels */,
                                                          unsigned long long* __restrict__ n_done, const Block* __restrict__ member,
-                                                         uint64_t* __restrict__ rec, uint64_t slot0)
+                                                         uint64_t* __restrict__ rec, uint64_t slot0, bool probed)
 {
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
@@ -792,7 +804,7 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
     const Sampling sampling(iv);
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x)
-        sweep_element<BV, pos_t, kTrail, kWide>(iv, s, sampling, e, val[e], val, key, step, out, member, rec, slot0, n_lv, n_lf, n_fin);
+        sweep_element<BV, pos_t, kTrail, kWide>(iv, s, sampling, e, val[e], val, key, step, out, member, rec, slot0, n_lv, n_lf, n_fin, probed);
     unsigned long long v[3] = {n_lf, n_lv, n_fin};
     unsigned long long* const dst[3] = {&stats[0], &stats[1], n_done};
     block_add<3>(v, dst);
@@ -801,7 +813,7 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
 // Round 0 without the pass that would write the elements' words first and the read that would fetch them again: an element's word
 // follows from its place -- slot t - t0, SA index l[list] + (t - first slot of the list) -- so a workgroup looks its list up once per
 // 2048 consecutive elements (as sweep_init_kernel does) and walks them at once.
-template <class BV, typename pos_t, bool kTrail, bool kWide, bool kTextOrder>
+template <class BV, typename pos_t, bool kTrail, bool kWide, bool kTextOrder, bool kAhead>
 __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat,
                                                           uint64_t t0, uint64_t total, uint64_t* __restrict__ val, uint16_t* __restrict__ key,
                                                           pos_t* __restrict__ out, unsigned long long* __restrict__ stats,
@@ -843,7 +855,7 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
                     sai = l[p] + (t - out_off[p]);
                 }
                 const uint64_t v64 = ((t - t0) << kShift) | sai;
-                sweep_element<BV, pos_t, kTrail, kWide, true>(iv, s, sampling, t - t0, v64, val, key, 0u, out, member, rec, t0, n_lv, n_lf, n_fin);
+                sweep_element<BV, pos_t, kTrail, kWide, true, kAhead>(iv, s, sampling, t - t0, v64, val, key, 0u, out, member, rec, t0, n_lv, n_lf, n_fin);
             }
         }
     }
@@ -1220,6 +1232,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
         const uint64_t t1 = std::min(total, t0 + batch_max);
         // (a sweep too short for a single round hands its elements to the stragglers' kernel, which reads their words)
         const bool fused_first = t1 - t0 > tail_threshold && [] { const char* e = getenv("VLG_NO_FUSED_FIRST_ROUND"); return !(e && e[0] == '1'); }();
+        static const bool ahead = [] { const char* e = getenv("VLG_SWEEP_LOOKAHEAD"); return !(e && e[0] == '0'); }();
         if (!fused_first) {
             if (member) VLG_HIP_TRY(hipMemsetAsync(rec + t0, 0xFF, (t1 - t0) * 8, stream));     // "still walking" (sweep_first_kernel writes it itself)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for((t1 - t0 + 7) / 8, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
@@ -1235,8 +1248,9 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             const dim3 grid(grid_for(alive, 4096));
             const bool first = fused_first && step == 0;                       // round 0 makes the elements' words itself (sweep_first_kernel)
             const dim3 grid_first(grid_for((alive + 7) / 8, 8192));
-#define VLG_STEP(BV, TR, TO) do { if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val_a, key_a, out, d_stats, d_counter, member, rec); \
-                                   else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<BV, pos_t, TR, kWide, TO>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, step, out, d_stats, d_counter, member, rec, t0); } while (0)
+#define VLG_STEP(BV, TR, TO) do { if (first && ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, TR>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val_a, key_a, out, d_stats, d_counter, member, rec); \
+                                   else if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, false>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val_a, key_a, out, d_stats, d_counter, member, rec); \
+                                   else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<BV, pos_t, TR, kWide, TO>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, step, out, d_stats, d_counter, member, rec, t0, ahead && fused_first && step == 1); } while (0)
 #define VLG_STEP_BV(TR, TO) do { if (rrr) VLG_STEP(RrrBV, TR, TO); else VLG_STEP(PlainBV, TR, TO); } while (0)
             if constexpr (!kWide) {
                 if (text_order) { if (member) VLG_STEP_BV(true, true); else VLG_STEP_BV(false, true); }

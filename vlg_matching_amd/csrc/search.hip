@@ -94,8 +94,12 @@ struct vlg_workspace {
     size_t tmp_bytes = 0;
     int x_ranks = 1, x_rank = 0;
     vlg_exchange_fn x_fn = nullptr;     // in-place all-gather of device pieces; null with x_comm set = vlg_comm_allgatherv
+    vlg_alltoall_fn x_a2a = nullptr;    // pairwise exchange of packed pieces; null with x_comm set = vlg_comm_alltoallv
     void* x_ctx = nullptr;
     void* x_comm = nullptr;
+    bool exchange_all = false;          // every sorted list to every rank (in-place all-gather) instead of needed lists, pairwise
+    uint64_t* x_status = nullptr;       // device: one status word per rank (the agreement before every exchange)
+    uint32_t x_agreed = 0;              // agreements made by the batch in work
     vlg_kernel_stat stats[KS_COUNT];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KS_COUNT];
     std::vector<hipEvent_t> free_events;
@@ -231,6 +235,7 @@ extern "C" void vlg_workspace_destroy(vlg_workspace* ws)
     for (hipEvent_t e : ws->free_events) (void)hipEventDestroy(e);
     if (ws->arena) (void)hipFree(ws->arena);
     if (ws->head) (void)hipFree(ws->head);
+    if (ws->x_status) (void)hipFree(ws->x_status);
     ws->host.release();
     delete ws;
 }
@@ -266,27 +271,48 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
         return ws_reserve(ws, b + b / 96 + (256ull << 20));
     }
     if (!strcmp(name, "sweep_tail")) { ws->sweep_tail = (uint64_t)value; return VLG_OK; }
+    if (!strcmp(name, "exchange_all")) { ws->exchange_all = value != 0; return VLG_OK; }
     if (!strcmp(name, "unsample_pct")) { ws->unsample_pct = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20)); return VLG_OK; }
     if (!strcmp(name, "unsample_tail")) { ws->unsample_tail = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "unsample_min")) { ws->unsample_min = (uint64_t)value; return VLG_OK; }
     return fail(VLG_E_INVALID, std::string("unknown workspace option ") + name);
 }
 
+namespace {
+vlg_status ws_exchange_reset(vlg_workspace* ws, int n_ranks)
+{
+    ws->x_comm = nullptr; ws->x_fn = nullptr; ws->x_a2a = nullptr; ws->x_ctx = nullptr; ws->x_ranks = 1; ws->x_rank = 0;
+    if (n_ranks > 1 && !ws->x_status) VLG_HIP_TRY(hipMalloc((void**)&ws->x_status, 8 * 1024));      // (room for 1024 ranks)
+    return VLG_OK;
+}
+}  // namespace
+
 extern "C" vlg_status vlg_workspace_set_comm(vlg_workspace* ws, void* nccl_comm)
 {
     if (!ws) return fail(VLG_E_INVALID, "null argument");
-    ws->x_comm = nullptr; ws->x_fn = nullptr; ws->x_ctx = nullptr; ws->x_ranks = 1; ws->x_rank = 0;
+    if (vlg_status s = ws_exchange_reset(ws, 1)) return s;
     if (!nccl_comm) return VLG_OK;
     int n = 0, r = 0;
     if (vlg_status s = vlg_comm_info(nccl_comm, &n, &r)) return s;
+    if (n > 1024) return fail(VLG_E_UNSUPPORTED, "more than 1024 ranks");
+    if (vlg_status s = ws_exchange_reset(ws, n)) return s;
     ws->x_comm = nccl_comm; ws->x_ranks = n; ws->x_rank = r;
     return VLG_OK;
 }
 
 extern "C" vlg_status vlg_workspace_set_exchange(vlg_workspace* ws, int n_ranks, int rank, vlg_exchange_fn fn, void* ctx)
 {
-    if (!ws || n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !fn)) return fail(VLG_E_INVALID, "bad exchange arguments");
-    ws->x_comm = nullptr; ws->x_fn = n_ranks > 1 ? fn : nullptr; ws->x_ctx = ctx; ws->x_ranks = n_ranks; ws->x_rank = rank;
+    if (!ws || n_ranks < 1 || n_ranks > 1024 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !fn)) return fail(VLG_E_INVALID, "bad exchange arguments");
+    if (vlg_status s = ws_exchange_reset(ws, n_ranks)) return s;
+    ws->x_fn = n_ranks > 1 ? fn : nullptr; ws->x_ctx = ctx; ws->x_ranks = n_ranks; ws->x_rank = rank;
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_workspace_set_exchange_alltoall(vlg_workspace* ws, int n_ranks, int rank, vlg_alltoall_fn fn, void* ctx)
+{
+    if (!ws || n_ranks < 1 || n_ranks > 1024 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !fn)) return fail(VLG_E_INVALID, "bad exchange arguments");
+    if (vlg_status s = ws_exchange_reset(ws, n_ranks)) return s;
+    ws->x_a2a = n_ranks > 1 ? fn : nullptr; ws->x_ctx = ctx; ws->x_ranks = n_ranks; ws->x_rank = rank;
     return VLG_OK;
 }
 
@@ -673,6 +699,79 @@ __global__ void lists_check_kernel(const T* __restrict__ lists, const uint64_t* 
 
 inline bool check_sort_enabled() { static const bool on = [] { const char* e = getenv("VLG_CHECK_SORT"); return e && e[0] == '1'; }(); return on; }
 
+// ---- collective search: agreement before every exchange ------------------------------------------------------------------------
+// Every rank all-gathers ONE status word before the payload of an exchange step moves: a rank whose share of the batch failed up to
+// there says so and all ranks return an error, instead of the healthy ones waiting inside a collective for a peer that has left.
+// An Agreement lives for one super-chunk of the batch; leaving its scope without having settled (an early error return anywhere
+// between the plan and the exchange) settles with the error on the way out.
+struct Agreement {
+    vlg_workspace* ws;
+    bool done = false;
+    vlg_status mine = VLG_E_INTERNAL;          // what a silent exit reports
+    explicit Agreement(vlg_workspace* w) : ws(w) {}
+    Agreement(const Agreement&) = delete;
+    // -> VLG_OK when every rank said OK; this rank's own status when it failed; VLG_E_INTERNAL naming the first failed peer otherwise
+    vlg_status settle(vlg_status status)
+    {
+        if (done || ws->x_ranks <= 1) { done = true; return status; }
+        done = true;
+        ++ws->x_agreed;
+        const int n = ws->x_ranks, me = ws->x_rank;
+        hipStream_t st = ws->stream;
+        std::vector<uint64_t> ones((size_t)n, 1), words((size_t)n, 0);
+        uint64_t word = (uint64_t)status;
+        uint64_t* d = ws->x_status;                                     // [0, n): all ranks' words, mine at [me]; [n, 2n): my word n times (all-to-all)
+        if (!d) return fail(VLG_E_INTERNAL, "collective search: no status buffer");
+        VLG_HIP_TRY(hipMemcpyAsync(d + me, &word, 8, hipMemcpyHostToDevice, st));
+        int rc = 0;
+        if (ws->x_fn) rc = ws->x_fn(ws->x_ctx, d, ones.data(), 8u, n, me, st);
+        else if (ws->x_a2a) {
+            std::vector<uint64_t> mine_n((size_t)n, word);
+            VLG_HIP_TRY(hipMemcpyAsync(d + n, mine_n.data(), 8 * (size_t)n, hipMemcpyHostToDevice, st));
+            VLG_HIP_TRY(hipStreamSynchronize(st));                    // (mine_n is read by the copy)
+            rc = ws->x_a2a(ws->x_ctx, d + n, ones.data(), d, ones.data(), 8u, n, me, st);
+        } else if (ws->x_comm) rc = (int)vlg_comm_allgatherv(ws->x_comm, d + me, ones.data(), 8u, d, st);
+        else return fail(VLG_E_INTERNAL, "collective search without a communicator");
+        if (rc) return fail(VLG_E_INTERNAL, "collective search: the status exchange failed with code " + std::to_string(rc));
+        VLG_HIP_TRY(hipMemcpyAsync(words.data(), d, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+        VLG_HIP_TRY(hipStreamSynchronize(st));
+        if (status) return status;                                     // (the message of the failure is already set)
+        for (int r = 0; r < n; ++r)
+            if (words[r]) return fail(VLG_E_INTERNAL, "collective search: rank " + std::to_string(r) + " failed with status " + std::to_string(words[r]) +
+                                                      " before the exchange; nothing was exchanged");
+        return VLG_OK;
+    }
+    ~Agreement() { if (!done) { const std::string keep = vlg_last_error(); (void)settle(mine); set_error(keep); } }
+};
+
+// packed[dst_off[k] + j] <-> base[src_off[k] + j] for the segments k < n_seg (dst_off has n_seg + 1 entries); kGather: base -> packed
+template <typename pos_t, bool kGather>
+__global__ void __launch_bounds__(256) segments_copy_kernel(pos_t* __restrict__ base, pos_t* __restrict__ packed, const uint64_t* __restrict__ src_off,
+                                                            const uint64_t* __restrict__ dst_off, uint64_t n_seg, uint64_t total)
+{
+    constexpr uint32_t kPer = 8;
+    __shared__ uint64_t s_first;
+    for (uint64_t b0 = (uint64_t)blockIdx.x * 256 * kPer; b0 < total; b0 += (uint64_t)gridDim.x * 256 * kPer) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t lo = 0, hi = n_seg;                       // last segment with dst_off[k] <= b0
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (dst_off[mid] <= b0) lo = mid; else hi = mid; }
+            s_first = lo;
+        }
+        __syncthreads();
+        uint64_t k = s_first;
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint64_t t = b0 + i * 256 + threadIdx.x;
+            if (t < total) {
+                while (dst_off[k + 1] <= t) ++k;               // (empty segments are skipped too)
+                const uint64_t at = src_off[k] + (t - dst_off[k]);
+                if (kGather) packed[t] = base[at]; else base[at] = packed[t];
+            }
+        }
+    }
+}
+
 // K3u (kernels.hip): does a share of `acc` occurrences of this index's text pay for rebuilding the whole suffix array?
 inline bool unsample_applies(const vlg_index* idx, const vlg_workspace* ws, uint64_t acc)
 {
@@ -688,7 +787,9 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
                           uint64_t& Tphys, size_t sort_tmp, unsigned long long* d_stats, pos_t*& Pc_out, uint64_t& pc_cap,
                           bool share_steps /* the sweep's walks stop at elements of the batch (room for the member bit-vector and the records) */,
                           bool wide /* SA indices need 33 bits / 64-bit samples (always so for 64-bit positions) */,
-                          bool allow_unsample /* the caller planned the workspace for K3u (no trail table) */)
+                          bool allow_unsample /* the caller planned the workspace for K3u (no trail table) */,
+                          const vlg_queries* q = nullptr, const std::vector<uint64_t>* xq = nullptr /* collective search: the ranks' query cuts */,
+                          Agreement* ag = nullptr /* collective search: settled here, right before the exchange */)
 {
     hipStream_t st = ws->stream;
     PhaseTrace bt(st);
@@ -736,13 +837,13 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     pc_cap = 0;
     ws->fences = nullptr;
     ws->rungs = nullptr;
-    if (!gacc) return VLG_OK;
+    if (!gacc) return ag ? ag->settle(VLG_OK) : VLG_OK;              // (every rank sees the same empty plan and settles too)
     // Collective search: this rank locates and sorts a contiguous share [sl, sh) of the lists -- cut so that every rank gets the
     // same number of occurrences, identically on every rank -- and the ranks exchange their sorted pieces afterwards.
     uint32_t sl = 0, sh = gnd;
     std::vector<uint64_t> xcounts;
+    std::vector<uint32_t> cut(ws->x_ranks + 1, gnd);
     if (ws->x_ranks > 1) {
-        std::vector<uint32_t> cut(ws->x_ranks + 1, gnd);
         cut[0] = 0;
         for (int r = 1; r < ws->x_ranks; ++r) {
             const uint64_t target = gacc / (uint64_t)ws->x_ranks * (uint64_t)r;
@@ -921,18 +1022,85 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
             P_out = Pa;
         }
     }
-    // ---- the exchange step: every rank contributes the sorted lists of its share, all ranks end up with all lists -----------------------
+    // ---- the exchange step: the ranks' sorted shares meet ----------------------------------------------------------------------------------
     const uint64_t* d_check_off = d_off64;
     uint64_t check_nd = nd, check_acc = acc;
+    const pos_t* check_base = nullptr;                                  // (null: P_out)
     if (ws->x_ranks > 1) {
-        Timed t(ws, KS_EXCHANGE, (gacc - acc) * sizeof(pos_t));
-        int rc = 0;
-        if (ws->x_fn) rc = ws->x_fn(ws->x_ctx, Pg, xcounts.data(), (uint32_t)sizeof(pos_t), ws->x_ranks, ws->x_rank, st);
-        else if (ws->x_comm) rc = (int)vlg_comm_allgatherv(ws->x_comm, Pa, xcounts.data(), (uint32_t)sizeof(pos_t), Pg, st);
-        else return fail(VLG_E_INTERNAL, "collective search without a communicator");
-        if (rc) return ws->x_fn ? fail(VLG_E_INTERNAL, "the exchange callback failed with code " + std::to_string(rc)) : (vlg_status)rc;
+        // every rank has come this far, or says so now (Agreement): nothing moves unless all of them are ready
+        if (ag) if (vlg_status as = ag->settle(VLG_OK)) return as;
+        const int n = ws->x_ranks, me = ws->x_rank;
+        const bool pairwise = !ws->exchange_all && !ws->x_fn && (ws->x_a2a || ws->x_comm) && q && xq && (int)xq->size() == n + 1;
+        if (!pairwise) {
+            // every list to every rank: one in-place all-gather of the shares
+            Timed t(ws, KS_EXCHANGE, (gacc - acc) * sizeof(pos_t));
+            int rc = 0;
+            if (ws->x_fn) rc = ws->x_fn(ws->x_ctx, Pg, xcounts.data(), (uint32_t)sizeof(pos_t), n, me, st);
+            else if (ws->x_comm) rc = (int)vlg_comm_allgatherv(ws->x_comm, Pa, xcounts.data(), (uint32_t)sizeof(pos_t), Pg, st);
+            else return fail(VLG_E_INTERNAL, "collective search without a communicator (or an all-to-all callback with \"exchange_all\")");
+            if (rc) return ws->x_fn ? fail(VLG_E_INTERNAL, "the exchange callback failed with code " + std::to_string(rc)) : (vlg_status)rc;
+            d_check_off = d_goff64; check_nd = gnd; check_acc = gacc;
+        } else {
+            // needed lists only, pairwise.  Every rank computes the same table: need[r] = the lists the queries of rank r use; rank s
+            // owes rank r the lists of ITS share among them.  Lists that follow each other in the layout travel as one segment.
+            std::vector<uint32_t> place(pl.dl.size(), 0);               // distinct id -> place in the layout
+            for (uint32_t i = 0; i < gnd; ++i) place[dlist[i]] = i;
+            std::vector<uint8_t> need((size_t)n * gnd, 0);
+            for (int r = 0; r < n; ++r) {
+                uint8_t* nr = need.data() + (size_t)r * gnd;
+                for (uint64_t qi = (*xq)[r]; qi < (*xq)[r + 1]; ++qi)
+                    for (uint64_t sidx = q->qsub[qi]; sidx < q->qsub[qi + 1]; ++sidx)
+                        if (pl.occ[sidx]) nr[place[pl.did[sidx]]] = 1;
+            }
+            // segments (first element in Pg, length) of what `from` owes `to`, in layout order
+            auto segments = [&](int from, int to, svec<uint64_t>& src, svec<uint64_t>& dst, uint64_t& at) {
+                const uint8_t* nt = need.data() + (size_t)to * gnd;
+                for (uint32_t i = cut[from]; i < cut[from + 1];) {
+                    if (!nt[i] || goff64[i + 1] == goff64[i]) { ++i; continue; }
+                    uint32_t j = i;
+                    while (j < cut[from + 1] && nt[j]) ++j;
+                    src.push_back(goff64[i]);
+                    dst.push_back(at);
+                    at += goff64[j] - goff64[i];
+                    i = j;
+                }
+            };
+            svec<uint64_t> s_src, s_dst, r_src, r_dst;
+            std::vector<uint64_t> scount((size_t)n, 0), rcount((size_t)n, 0);
+            uint64_t s_at = 0, r_at = 0;
+            for (int r = 0; r < n; ++r) {
+                if (r == me) continue;                                   // (a rank's own lists are where they belong already)
+                uint64_t b = s_at;
+                segments(me, r, s_src, s_dst, s_at);
+                scount[r] = s_at - b;
+                b = r_at;
+                segments(r, me, r_src, r_dst, r_at);
+                rcount[r] = r_at - b;
+            }
+            s_dst.push_back(s_at);
+            r_dst.push_back(r_at);
+            const uint64_t ns = s_src.size(), nr_ = r_src.size();
+            pos_t* d_send = A.take<pos_t>(s_at + 1);
+            pos_t* d_recv = A.take<pos_t>(r_at + 1);
+            uint64_t* d_seg = A.take<uint64_t>(2 * (ns + nr_) + 4);
+            if (A.failed) return fail(VLG_E_WORKSPACE, "collective search: no room for the exchange buffers");
+            uint64_t* d_s_src = d_seg; uint64_t* d_s_dst = d_s_src + ns; uint64_t* d_r_src = d_s_dst + ns + 1; uint64_t* d_r_dst = d_r_src + nr_;
+            if (ns) VLG_HIP_TRY(hipMemcpyAsync(d_s_src, s_src.data(), ns * 8, hipMemcpyHostToDevice, st));
+            VLG_HIP_TRY(hipMemcpyAsync(d_s_dst, s_dst.data(), (ns + 1) * 8, hipMemcpyHostToDevice, st));
+            if (nr_) VLG_HIP_TRY(hipMemcpyAsync(d_r_src, r_src.data(), nr_ * 8, hipMemcpyHostToDevice, st));
+            VLG_HIP_TRY(hipMemcpyAsync(d_r_dst, r_dst.data(), (nr_ + 1) * 8, hipMemcpyHostToDevice, st));
+            Timed t(ws, KS_EXCHANGE, r_at * sizeof(pos_t));
+            if (s_at) hipLaunchKernelGGL(HIP_KERNEL_NAME(segments_copy_kernel<pos_t, true>), dim3(grid_for((s_at + 7) / 8, 16384)), dim3(256), 0, st, Pg, d_send, d_s_src, d_s_dst, ns, s_at);
+            VLG_HIP_TRY(hipGetLastError());
+            int rc = 0;
+            if (ws->x_a2a) rc = ws->x_a2a(ws->x_ctx, d_send, scount.data(), d_recv, rcount.data(), (uint32_t)sizeof(pos_t), n, me, st);
+            else rc = (int)vlg_comm_alltoallv(ws->x_comm, d_send, scount.data(), d_recv, rcount.data(), (uint32_t)sizeof(pos_t), st);
+            if (rc) return ws->x_a2a ? fail(VLG_E_INTERNAL, "the exchange callback failed with code " + std::to_string(rc)) : (vlg_status)rc;
+            if (r_at) hipLaunchKernelGGL(HIP_KERNEL_NAME(segments_copy_kernel<pos_t, false>), dim3(grid_for((r_at + 7) / 8, 16384)), dim3(256), 0, st, Pg, d_recv, d_r_src, d_r_dst, nr_, r_at);
+            VLG_HIP_TRY(hipGetLastError());
+            check_base = Pa;                                           // (lists no query of this rank uses hold nothing: only the own share is checked)
+        }
         P_out = Pg;
-        d_check_off = d_goff64; check_nd = gnd; check_acc = gacc;
     }
     if (P_out == Pb) dead_bytes = gacc * kPhysScratchPerElem<pos_t>() - gacc * sizeof(pos_t);
     else dead_bytes = (uint64_t)(scratch - reinterpret_cast<uint8_t*>(Pg)) + gacc * kPhysScratchPerElem<pos_t>() - gacc * sizeof(pos_t);
@@ -944,7 +1112,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         if (!d_flags) return fail(VLG_E_INTERNAL, "arena carve failed (sort check)");
         unsigned long long flags[2] = {0, 0};
         VLG_HIP_TRY(hipMemsetAsync(d_flags, 0, 16, st));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(lists_check_kernel<pos_t>), dim3(grid_for((check_acc + 7) / 8, 8192)), dim3(256), 0, st, P_out, d_check_off, check_nd, check_acc, d_flags);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(lists_check_kernel<pos_t>), dim3(grid_for((check_acc + 7) / 8, 8192)), dim3(256), 0, st, check_base ? check_base : P_out, d_check_off, check_nd, check_acc, d_flags);
         VLG_HIP_TRY(hipGetLastError());
         VLG_HIP_TRY(hipMemcpyAsync(flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         VLG_HIP_TRY(hipStreamSynchronize(st));
@@ -1589,6 +1757,8 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         // collective search: the queries of the super-chunk are cut into one contiguous piece per rank of equal join work (slots of the
         // non-final lists, from the list lengths every rank knows); this rank filters and joins its piece [qa, qb) only
         uint64_t qa = Q0, qb = Q1;
+        std::vector<uint64_t> xq;
+        Agreement ag(ws);
         if (ws->x_ranks > 1) {
             std::vector<uint64_t> cum(Q1 - Q0 + 1, 0);
             for (uint64_t qi = Q0; qi < Q1; ++qi)
@@ -1599,15 +1769,18 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
                 const uint64_t target = cum.back() / (uint64_t)ws->x_ranks * (uint64_t)r;
                 return Q0 + (uint64_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
             };
-            qa = std::min(cut_at(ws->x_rank), Q1);
-            qb = std::max(qa, std::min(cut_at(ws->x_rank + 1), Q1));
+            xq.resize(ws->x_ranks + 1);
+            xq[0] = Q0;
+            for (int r = 1; r <= ws->x_ranks; ++r) xq[r] = std::max(xq[r - 1], std::min(cut_at(r), Q1));
+            qa = xq[ws->x_rank];
+            qb = xq[ws->x_rank + 1];
             res->owned.push_back(qa);
             res->owned.push_back(qb);
         }
         JoinPlan jp;
         if (!launch_first) {
-            if (vlg_status s = plan_joins(q, pl, ws, qa, qb, join_budget, idx->hdr.n, jp)) return s;
-            if (vlg_status s = ws_reserve(ws, phys_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) return s;
+            if (vlg_status s = plan_joins(q, pl, ws, qa, qb, join_budget, idx->hdr.n, jp)) { ag.mine = s; return s; }
+            if (vlg_status s = ws_reserve(ws, phys_bytes + jp.filter_need + jp.want_bytes + jp.meta + fixed)) { ag.mine = s; return s; }
         }
         Arena A{ws->arena, ws->arena_bytes};
         pos_t* P = nullptr;
@@ -1615,7 +1788,8 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         tr.mark("plan super-chunk");
         pos_t* Pc = nullptr;
         uint64_t pc_cap = 0;
-        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, share_trails, wide, will_unsample)) return s;
+        if (vlg_status s = build_physical<pos_t>(idx, ws, res, dlist, pl, A, P, poff, Tphys, sort_tmp, d_stats, Pc, pc_cap, share_trails, wide, will_unsample, q,
+                                                   ws->x_ranks > 1 ? &xq : nullptr, ws->x_ranks > 1 ? &ag : nullptr)) return s;
         if (launch_first)
             if (vlg_status s = plan_joins(q, pl, ws, qa, qb, join_budget, idx->hdr.n, jp)) return s;
         tr.mark("locate + sort");
@@ -1790,6 +1964,7 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
         uint8_t* plan_mem = head + 2 * lr_bytes + st_bytes;
         VLG_HIP_TRY(hipMemsetAsync(d_stats, 0, kStatsWords * 8, st));
         ws->sample_reads = 0;
+        ws->x_agreed = 0;
         // ---- K2: every sub-pattern's SA interval ------------------------------------------------------
         {
             Timed t(ws, KS_BSEARCH, 0);
@@ -1882,6 +2057,13 @@ extern "C" vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* 
     tr.mark("statistics");
     tr.mark("free");
     last_end = std::chrono::steady_clock::now();
+    if (stt && ws->x_ranks > 1 && ws->x_agreed == 0 && q->nq) {
+        // a collective search that failed before its first super-chunk: the other ranks wait in that chunk's agreement
+        const std::string keep = vlg_last_error();
+        Agreement early(ws);
+        (void)early.settle(stt);
+        set_error(keep);
+    }
     if (stt) { vlg_result_destroy(res); return stt; }
     *out = res;
     return VLG_OK;

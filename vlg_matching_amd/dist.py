@@ -134,6 +134,14 @@ class Comm:
         assert len(c) == self.n_ranks
         check(lib().vlg_comm_allgatherv(self._h, d_send_ptr, c.ctypes.data, int(elem_bytes), d_recv_ptr, stream))
 
+    def alltoallv(self, d_send_ptr, send_counts, d_recv_ptr, recv_counts, elem_bytes, stream=None):
+        """vlg_comm_alltoallv: grouped ncclSend / ncclRecv, one pair per peer"""
+        from .capi import check, lib
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.uint64)
+        assert len(sc) == len(rc) == self.n_ranks
+        check(lib().vlg_comm_alltoallv(self._h, d_send_ptr, sc.ctypes.data, d_recv_ptr, rc.ctypes.data, int(elem_bytes), stream))
+
     def close(self):
         if self._h:
             from .capi import lib
@@ -174,6 +182,45 @@ def host_exchange(dist):
         for r in range(n_ranks):
             if r != rank and sizes[r] and hip.hipMemcpy(d_buf + offs[r], parts[r].data_ptr(), sizes[r], 1):   # host -> device
                 return 4
+        return 0
+    return exchange
+
+
+def host_alltoall(dist):
+    """An exchange callback for Workspace.set_exchange_alltoall that moves the packed pieces through torch.distributed on the HOST
+    (D2H, point-to-point isend / irecv of uint8 tensors -- gloo has no all-to-all --, H2D): rehearsals of the pairwise exchange with
+    several gloo ranks on one device.  The production path is Workspace.set_comm (vlg_comm_alltoallv: RCCL over xGMI)."""
+    import ctypes as C
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def exchange(d_send, send_counts, d_recv, recv_counts, elem_bytes, n_ranks, rank, stream):
+        if hip.hipStreamSynchronize(stream):
+            return 2
+        ssz = [c * elem_bytes for c in send_counts]
+        rsz = [c * elem_bytes for c in recv_counts]
+        out = torch.zeros(max(sum(ssz), 1), dtype=torch.uint8)
+        inn = torch.zeros(max(sum(rsz), 1), dtype=torch.uint8)
+        if sum(ssz) and hip.hipMemcpy(out.data_ptr(), d_send, sum(ssz), 2):                       # device -> host
+            return 3
+        reqs, so, ro = [], 0, 0
+        for r in range(n_ranks):
+            if r == rank:
+                inn[ro: ro + rsz[r]] = out[so: so + ssz[r]]
+            else:
+                if ssz[r]:
+                    reqs.append(dist.isend(out[so: so + ssz[r]], dst=r))
+                if rsz[r]:
+                    reqs.append(dist.irecv(inn[ro: ro + rsz[r]], src=r))
+            so += ssz[r]
+            ro += rsz[r]
+        for q in reqs:
+            q.wait()
+        if sum(rsz) and hip.hipMemcpy(d_recv, inn.data_ptr(), sum(rsz), 1):                       # host -> device
+            return 4
         return 0
     return exchange
 

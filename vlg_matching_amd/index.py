@@ -151,6 +151,21 @@ class Workspace:
         self._exchange_cb = capi.EXCHANGE_FN(trampoline)
         check(lib().vlg_workspace_set_exchange(self._h, int(n_ranks), int(rank), self._exchange_cb, None))
 
+    def set_exchange_alltoall(self, n_ranks, rank, callback):
+        """The pairwise exchange with the caller moving the bytes (vlg_workspace_set_exchange_alltoall):
+        callback(d_send, send_counts, d_recv, recv_counts, elem_bytes, n_ranks, rank, stream) -> 0 sends send_counts[r] elements to rank r
+        (packed in rank order at d_send) and receives recv_counts[r] from it (packed at d_recv)."""
+        def trampoline(ctx, d_send, sc, d_recv, rc, elem_bytes, n, r, stream):
+            try:
+                return int(callback(d_send or 0, [int(sc[i]) for i in range(n)], d_recv or 0, [int(rc[i]) for i in range(n)], int(elem_bytes),
+                                    int(n), int(r), stream) or 0)
+            except Exception as e:                                   # an exception must not cross the C frame
+                import sys
+                print("exchange callback failed: %r" % (e,), file=sys.stderr)
+                return 1
+        self._exchange_cb = capi.ALLTOALL_FN(trampoline)
+        check(lib().vlg_workspace_set_exchange_alltoall(self._h, int(n_ranks), int(rank), self._exchange_cb, None))
+
     def profile(self, enable=True):
         check(lib().vlg_workspace_profile(self._h, 1 if enable else 0))
 
