@@ -881,27 +881,54 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
 // neighbours in SA order are not neighbours in slot order; (3) following the chains on a second stream beside the sweep's late rounds:
 // this kernel 18.0 -> 13.3 ms, but the rounds and their partitions slow down by 7 ms: the requests are conserved, not hidden.
 constexpr uint32_t kResolveHops = 64;
+// A workgroup takes kResolveChunk CONSECUTIVE records per turn (not every gridDim-th group of 256): consecutive elements of a list
+// that read the same symbol in front of them follow consecutive elements of another list, so the lines a wave fetches for its hops
+// are the lines the next waves of the same chunk need -- through the CU's own L1 when they belong to one workgroup.
+constexpr uint32_t kResolveChunk = 4096;
 template <typename pos_t, bool kWide>
 __global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict__ rec, uint64_t count, pos_t* __restrict__ out,
-                                                            unsigned long long* __restrict__ n_open, uint32_t round)
+                                                            unsigned long long* __restrict__ n_open, uint32_t round, bool diag)
 {
     constexpr uint32_t kShift = kWide ? 33 : 32;
     constexpr uint64_t kLow = (1ull << kShift) - 1;
     uint32_t open = 0;
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t r = rec[e];
-        if (r >> kShift) {
-            for (uint32_t h = 0; h < kResolveHops && (r >> kShift); ++h) {
-                const uint64_t ro = rec[r & kLow];
-                const uint64_t delta = r >> kShift;
-                r = (ro >> kShift) == 0 ? ro + delta : ro + (delta << kShift);
+    unsigned long long n_hops = 0, n_lines = 0, n_ptr = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * kResolveChunk; base < count; base += (uint64_t)gridDim.x * kResolveChunk) {
+        const uint64_t end = base + kResolveChunk < count ? base + kResolveChunk : count;
+        for (uint64_t e = base + threadIdx.x; e < end; e += 256) {
+            uint64_t r = rec[e];
+            if (r >> kShift) {
+                ++n_ptr;
+                for (uint32_t h = 0; h < kResolveHops && (r >> kShift); ++h) {
+                    if (diag) {                                               // hops, and distinct 64-byte lines per wave-wide hop
+                        ++n_hops;
+                        const uint64_t line = (r & kLow) >> 3;
+                        bool first = true;
+                        const unsigned long long act = __ballot(true);
+                        for (int o = 1; o < 64; ++o) {
+                            const int src = (int)((threadIdx.x & 63) - o);
+                            const uint64_t other = __shfl(line, src & 63);
+                            if (src >= 0 && ((act >> src) & 1) && other == line) first = false;
+                        }
+                        if (first) ++n_lines;
+                    }
+                    const uint64_t ro = rec[r & kLow];
+                    const uint64_t delta = r >> kShift;
+                    r = (ro >> kShift) == 0 ? ro + delta : ro + (delta << kShift);
+                }
+                rec[e] = r;
+                if ((r >> kShift) == 0) out[e] = (pos_t)r;
+                else ++open;
+            } else if (round == 0) {
+                out[e] = (pos_t)r;                                                // elements that never followed anyone
             }
-            rec[e] = r;
-            if ((r >> kShift) == 0) out[e] = (pos_t)r;
-            else ++open;
-        } else if (round == 0) {
-            out[e] = (pos_t)r;                                                    // elements that never followed anyone
         }
+    }
+    if (diag) {
+        unsigned long long v[4] = {open, n_hops, n_lines, n_ptr};
+        unsigned long long* const dst[4] = {n_open, n_open + 1, n_open + 2, n_open + 3};
+        block_add<4>(v, dst);
+        return;
     }
     unsigned long long v[1] = {open};
     unsigned long long* const dst[1] = {n_open};
@@ -1303,16 +1330,23 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     if (hook_due) { hook_due = false; if (vlg_status hs = (*while_first_step)()) return hs; }
     if (member) {
         // every element has a record now; jump pointers until all of them are positions
+        static const bool diag = [] { const char* e = getenv("VLG_RESOLVE_STATS"); return e && e[0] == '1'; }();
         for (uint32_t round = 0;; ++round) {
-            VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
+            VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, diag ? 32 : 8, stream));
             if (timer) timer->begin(2, round == 0 ? total * (8ull + sizeof(pos_t)) : 0);     // every record read, every position written
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_kernel<pos_t, kWide>), dim3(grid_for(total, 16384)), dim3(256), 0, stream, rec, total, d_out,
-                               d_counter, round);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_kernel<pos_t, kWide>), dim3((uint32_t)std::min<uint64_t>((total + kResolveChunk - 1) / kResolveChunk, 65536)),
+                               dim3(256), 0, stream, rec, total, d_out, d_counter, round, diag);
             if (timer) timer->end(2);
             VLG_HIP_TRY(hipGetLastError());
             unsigned long long open = 0;
             VLG_HIP_TRY(hipMemcpyAsync(&open, d_counter, 8, hipMemcpyDeviceToHost, stream));
             VLG_HIP_TRY(hipStreamSynchronize(stream));
+            if (diag) {
+                unsigned long long c[4] = {0, 0, 0, 0};
+                VLG_HIP_TRY(hipMemcpy(c, d_counter, 32, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[vlg resolve] round %u: %llu records, %llu pointers, %llu hops, %llu distinct lines (per wave-wide hop), %llu still open\n", round,
+                        (unsigned long long)total, c[3], c[1], c[2], c[0]);
+            }
             if (!open) break;
             if (round > 64) return fail(VLG_E_INTERNAL, "trail records did not resolve");
         }

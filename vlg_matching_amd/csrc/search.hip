@@ -873,7 +873,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     uint64_t* d_off64 = A.take<uint64_t>(nd + 1);
     uint32_t* d_off32 = A.take<uint32_t>(nd + 1);
     uint64_t* d_lh = A.take<uint64_t>(nd);
-    unsigned long long* d_counter = A.take<unsigned long long>(1);
+    unsigned long long* d_counter = A.take<unsigned long long>(4);     // [0] the sweep's counter, [1..3] diagnostics (VLG_RESOLVE_STATS)
     void* d_tmp = A.take<uint8_t>(sort_tmp + 256);
     if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (physical)");
     pos_t* Pb = reinterpret_cast<pos_t*>(scratch);
