@@ -156,6 +156,19 @@ vlg_status vlg_index_get_info(const vlg_index* idx, vlg_index_info* info);
  * by vlg_queries_parse_int), vlg_queries_intervals / _occurrences, vlg_backward_search_batch (patterns = little-endian uint32_t
  * symbols), vlg_sa_batch, vlg_locate_batch, blob export / attach / broadcast take it; the byte-only entry points refuse it. */
 vlg_status vlg_index_build_int(const uint32_t* h_text, uint64_t n_symbols, uint32_t sa_sample_dens, vlg_index** out);
+/* 64-bit symbols.  gapped_pattern_query<int_alphabet_tag> reads uint64_t tokens (vlg_index.hpp:57-69) and int_vector<64> texts hold
+ * 64-bit symbols; the device indexes (vlg_index_build_int, vlg_wtsa_build_int) hold uint32_t.  A symbol map carries the sorted
+ * distinct symbols of a 64-bit text and sends a symbol to its rank + 1: dense, order-preserving, never 0 -- so the suffix order, every
+ * SA interval and every result of the mapped text are those of the original.  vlg_symbol_map_apply maps a text (or any symbols:
+ * one that does not occur in the map's text becomes sigma + 1, which occurs nowhere in the mapped text), the mapped text goes to
+ * vlg_index_build_int / vlg_wtsa_build_int, and vlg_queries_parse_int_mapped parses a batch as vlg_queries_parse_int does -- tokens
+ * of any 64-bit value -- through the same map.  Host only (no GPU needed for the map itself). */
+typedef struct vlg_symbol_map vlg_symbol_map;
+vlg_status vlg_symbol_map_create(const uint64_t* h_text, uint64_t n_symbols, vlg_symbol_map** out);
+uint64_t vlg_symbol_map_sigma(const vlg_symbol_map* map);
+vlg_status vlg_symbol_map_symbols(const vlg_symbol_map* map, uint64_t* h_out /* [sigma] ascending */);
+vlg_status vlg_symbol_map_apply(const vlg_symbol_map* map, const uint64_t* h_in, uint64_t n, uint32_t* h_out);
+void vlg_symbol_map_destroy(vlg_symbol_map* map);
 /* int_alphabet of such an index: *sigma symbols (comp 0 = the sentinel), h_C[sigma + 1], h_comp2char[sigma]; null buffers: sigma only */
 vlg_status vlg_index_export_int_alphabet(const vlg_index* idx, uint64_t* sigma, uint64_t* h_C, uint64_t* h_comp2char);
 /* wt_int::rank(i, c) (include/sdsl/wt_int.hpp:370-395) on its BWT: out[j] = #d_sym[j] in BWT[0, d_i[j]) */
@@ -435,6 +448,9 @@ vlg_status vlg_wtsa_ranges(const vlg_wtsa* idx, const vlg_queries* q, uint64_t* 
 /* Integer-alphabet query batch: like vlg_queries_parse with VLG_DIALECT_LIBRARY, sub-patterns parsed as the reference parses them
  * for int_alphabet_tag (whitespace-separated decimals; gaps count symbols).  Only vlg_wtsa_* entry points accept such a batch. */
 vlg_status vlg_queries_parse_int(const char* h_text, const uint64_t* h_off, uint64_t n_queries, int* h_status, vlg_queries** out);
+/* the same through a symbol map (above): tokens are the ORIGINAL 64-bit symbols, the batch holds their mapped values */
+vlg_status vlg_queries_parse_int_mapped(const vlg_symbol_map* map, const char* h_text, const uint64_t* h_off, uint64_t n_queries,
+                                        int* h_status, vlg_queries** out);
 /* sdsl::locate / count on the batch, at most max_matches_per_query matches each (0 = all). */
 vlg_status vlg_wtsa_search_batch(const vlg_wtsa* idx, const vlg_queries* q, uint64_t max_matches_per_query, vlg_workspace* ws,
                                  vlg_result** out);

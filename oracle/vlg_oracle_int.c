@@ -19,6 +19,8 @@
  * wavelet_trees.hpp -> construct.hpp -> construct_sa.hpp -> divsufsort.h, an empty submodule), so the text-order sampling is
  * pinned by its defining property only: csa[i] == SA[i] for every i, marked[i] <=> SA[i] % dens == 0.  The byte-alphabet variant
  * of text-order sampling reuses vlg_oracle.c's index (vlgo_text_order_* below).
+ * Limit of this restatement (not of the reference): the suffix sorter ranks symbols as text[i] + 1 with 0 = "behind the end", so a
+ * text must not hold the symbol 2^64 - 1 (it would wrap to 0); every other 64-bit symbol is fine (tests go up to 2^64 - 3).
  */
 #include "vlg_oracle.h"
 #include <stdlib.h>

@@ -227,3 +227,25 @@ print("status2", s2)
     assert lines["status"].startswith("%d " % V.capi.E_UNSUPPORTED), r.stdout
     assert "RCCL not found" in lines["status"] and "librccl_bogus" in lines["status"]
     assert lines["status2"].strip() == str(V.capi.E_UNSUPPORTED)
+
+
+def test_symbol_map_is_dense_and_order_preserving(V):
+    """vlg_symbol_map (64-bit symbols for the uint32 integer indexes): symbol -> rank + 1 among the text's distinct symbols -- dense,
+    ascending with the symbol (so the mapped text has the original's suffix order), never 0; a symbol the text does not hold maps to
+    sigma + 1.  Host-only: works without a GPU."""
+    rng = np.random.default_rng(2)
+    vocab = np.array([0, 1, 7, 2 ** 32 - 1, 2 ** 32, 2 ** 40 + 3, 2 ** 63, 2 ** 64 - 1], dtype=np.uint64)
+    text = vocab[rng.integers(0, len(vocab), 5000)]
+    m = V.SymbolMap(text)
+    assert m.sigma == len(vocab) and m.symbols().tolist() == sorted(vocab.tolist())
+    mapped = m.apply(text)
+    assert mapped.dtype == np.uint32 and mapped.min() == 1 and mapped.max() == m.sigma
+    order = np.argsort(vocab)
+    rank = {int(vocab[i]): r + 1 for r, i in enumerate(order)}
+    assert mapped.tolist() == [rank[int(x)] for x in text]
+    assert m.apply(np.array([5, 2 ** 50, 2 ** 64 - 2], dtype=np.uint64)).tolist() == [m.sigma + 1] * 3
+    big = rng.integers(0, 2 ** 63, 3_000_000, dtype=np.uint64)                 # the threaded path
+    mb = V.SymbolMap(big)
+    got = mb.apply(big)
+    assert (mb.symbols()[got.astype(np.int64) - 1] == big).all()
+    assert V.SymbolMap(np.zeros(0, dtype=np.uint64)).sigma == 0

@@ -1434,6 +1434,52 @@ def test_integer_alphabet_fm_index(torch_cuda, V, oracle, name):
     assert (r3.counts == res.counts).all() and r3.summary["checksum"] == res.summary["checksum"]
 
 
+def test_integer_alphabet_64bit_symbols_through_a_symbol_map(V, oracle):
+    """gapped_pattern_query<int_alphabet_tag> reads uint64_t tokens (vlg_index.hpp:57-69).  A text whose symbols need more than 32 bits
+    goes through vlg_symbol_map (rank + 1 of every symbol: dense, order-preserving), the mapped text into vlg_index_build_int and
+    vlg_wtsa_build_int, and queries -- written with the ORIGINAL 64-bit symbols -- through vlg_queries_parse_int_mapped: same tuples
+    as the restated reference structure built over the 64-bit text itself, for both indexes; symbols the text does not hold match
+    nothing; without a map a token above 2^32 - 1 is refused."""
+    from vlg_matching_amd.index import Queries, WtsaIndex
+    rng = np.random.default_rng(77)
+    # (2^64 - 1 itself is left out: the oracle's suffix sorter ranks symbols as x + 1 -- oracle/vlg_oracle_int.c)
+    vocab = np.array([3, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 45 + 9, 2 ** 63 + 5, 2 ** 64 - 3, 12], dtype=np.uint64)
+    text = vocab[rng.choice(len(vocab), 4000, p=np.array([6, 5, 4, 4, 3, 2, 1, 5]) / 30.0)]
+    o = oracle.IntIndex(text, dens=32)                                           # the oracle's symbols are 64-bit
+    m = V.SymbolMap(text)
+    mapped = m.apply(text)
+    idx = V.VlgIndex.build_int(mapped)
+    t = [int(x) for x in text]
+    qs = []
+    for _ in range(150):
+        k = int(rng.integers(1, 4))
+        subs = [t[s:s + int(rng.integers(1, 4))] for s in rng.integers(0, len(t) - 4, k)]
+        q = " ".join(map(str, subs[0]))
+        for sp in subs[1:]:
+            a = int(rng.integers(0, 10))
+            q += " .{%d,%d}? %s" % (a, a + int(rng.integers(0, 40)), " ".join(map(str, sp)))
+        qs.append(q)
+    qs += ["%d .{0,9}? 4242" % t[0], "18446744073709551614", "%d %d" % (2 ** 63 + 5, 2 ** 64 - 3)]      # absent symbols; a rare pair
+    want = [o.search(q).tolist() for q in qs]
+    assert sum(len(w) for w in want) > 500
+    batch = m.queries(qs)
+    res = idx.search(batch)
+    wres = WtsaIndex(mapped).search(batch)
+    for i in range(len(qs)):
+        assert res.tuples(i).tolist() == want[i], qs[i]
+        assert wres.tuples(i).tolist() == want[i], qs[i]
+    # intervals are those of the 64-bit text: the map preserves the suffix order
+    l, r, _ = idx.intervals(batch)
+    import re
+    pats = [[int(x) for x in part.split()] for qq in qs for part in re.split(r"\.\{\d+,\d+\}\?", qq)]
+    for p_, a, b in zip(pats, l, r):
+        cnt, ol, orr = o.backward_search(p_)
+        assert int(b) + 1 - int(a) == cnt and (not cnt or (int(a), int(b)) == (ol, orr)), p_
+    with pytest.raises(V.VlgError) as e:
+        Queries.from_int(["5 4294967296"])
+    assert e.value.status == V.capi.E_INVALID and "vlg_symbol_map" in str(e.value)
+
+
 def test_integer_alphabet_fm_index_known_answers_and_refusals(V):
     gold = json.load(open(GOLD))
     for case in gold["int_cases"]:

@@ -5,4 +5,4 @@ include/vlg_hip.h).  There is no CPU fallback: importing works anywhere, but eve
 VlgError when the library or a HIP device is missing.
 """
 from .capi import VlgError, lib, library_path, build_library  # noqa: F401
-from .index import VlgIndex, WtsaIndex, BitVector, RrrBitVector, SearchResult, count, locate, parse_query  # noqa: F401
+from .index import VlgIndex, WtsaIndex, BitVector, RrrBitVector, SearchResult, SymbolMap, count, locate, parse_query  # noqa: F401

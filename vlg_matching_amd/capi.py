@@ -140,6 +140,12 @@ SYMBOLS = [
     ("vlg_wtsa_range_walk_batch", _I, [_P, _P, _P, _P, _I, _P, _U64, _P]),
     ("vlg_wtsa_export_level", _I, [_P, C.c_uint32, _P]),
     ("vlg_queries_parse_int", _I, [C.c_char_p, _P, _U64, _P, C.POINTER(_P)]),
+    ("vlg_queries_parse_int_mapped", _I, [_P, _P, _P, _U64, _P, C.POINTER(_P)]),
+    ("vlg_symbol_map_create", _I, [_P, _U64, C.POINTER(_P)]),
+    ("vlg_symbol_map_sigma", _U64, [_P]),
+    ("vlg_symbol_map_symbols", _I, [_P, _P]),
+    ("vlg_symbol_map_apply", _I, [_P, _P, _U64, _P]),
+    ("vlg_symbol_map_destroy", None, [_P]),
     ("vlg_wtsa_search_batch", _I, [_P, _P, _U64, _P, C.POINTER(_P)]),
     ("vlg_workspace_profile", _I, [_P, _I]),
     ("vlg_workspace_set_option", _I, [_P, C.c_char_p, C.c_int64]),

@@ -229,7 +229,63 @@ extern "C" vlg_status vlg_queries_parse(const char* h_text, const uint64_t* h_of
 
 // Integer alphabet (gapped_pattern_query<int_alphabet_tag>, include/sdsl/vlg_index.hpp:57-69): a sub-pattern is read with
 // `istringstream >> uint64_t` until the first token that is not a number; gaps count symbols (:95).
-extern "C" vlg_status vlg_queries_parse_int(const char* h_text, const uint64_t* h_off, uint64_t n_queries, int* h_status, vlg_queries** out)
+// The device indexes hold uint32_t symbols.  Tokens are read as the reference reads them -- 64 bits -- and then either must fit 32
+// bits (no map) or go through a vlg_symbol_map: the sorted distinct 64-bit symbols of the text, symbol -> rank + 1.
+struct vlg_symbol_map {
+    std::vector<uint64_t> symbols;                             // ascending, distinct
+    // rank + 1 of a symbol of the text; a symbol that does not occur maps to sigma + 1, which occurs nowhere in a mapped text
+    uint32_t map(uint64_t x) const
+    {
+        const auto it = std::lower_bound(symbols.begin(), symbols.end(), x);
+        if (it == symbols.end() || *it != x) return (uint32_t)symbols.size() + 1u;
+        return (uint32_t)(it - symbols.begin()) + 1u;
+    }
+};
+
+extern "C" vlg_status vlg_symbol_map_create(const uint64_t* h_text, uint64_t n_symbols, vlg_symbol_map** out)
+{
+    if (!out || (n_symbols && !h_text)) return fail(VLG_E_INVALID, "null argument");
+    *out = nullptr;
+    try {
+        std::vector<uint64_t> v(h_text, h_text + n_symbols);
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        if (v.size() >= 0xFFFFFFF0ull) return fail(VLG_E_UNSUPPORTED, "more than 2^32 - 16 distinct symbols");
+        vlg_symbol_map* m = new vlg_symbol_map();
+        m->symbols.swap(v);
+        *out = m;
+    } catch (const std::bad_alloc&) { return fail(VLG_E_OOM, "out of host memory while collecting the alphabet"); }
+    return VLG_OK;
+}
+
+extern "C" uint64_t vlg_symbol_map_sigma(const vlg_symbol_map* m) { return m ? m->symbols.size() : 0; }
+
+extern "C" vlg_status vlg_symbol_map_symbols(const vlg_symbol_map* m, uint64_t* h_out)
+{
+    if (!m || (!h_out && !m->symbols.empty())) return fail(VLG_E_INVALID, "null argument");
+    if (!m->symbols.empty()) memcpy(h_out, m->symbols.data(), m->symbols.size() * 8);
+    return VLG_OK;
+}
+
+extern "C" vlg_status vlg_symbol_map_apply(const vlg_symbol_map* m, const uint64_t* h_in, uint64_t n, uint32_t* h_out)
+{
+    if (!m || (n && (!h_in || !h_out))) return fail(VLG_E_INVALID, "null argument");
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const uint64_t nt = n >= (1u << 20) ? hw : 1;
+    auto work = [&](uint64_t a, uint64_t b) { for (uint64_t i = a; i < b; ++i) h_out[i] = m->map(h_in[i]); };
+    if (nt == 1) { work(0, n); return VLG_OK; }
+    std::vector<std::thread> th;
+    uint64_t started = 0;
+    try { for (; started < nt; ++started) th.emplace_back(work, n * started / nt, n * (started + 1) / nt); } catch (...) {}
+    for (auto& t : th) t.join();
+    if (started < nt) work(n * started / nt, n);               // no more threads to be had: the rest on this one
+    return VLG_OK;
+}
+
+extern "C" void vlg_symbol_map_destroy(vlg_symbol_map* m) { delete m; }
+
+namespace {
+vlg_status parse_int_batch(const vlg_symbol_map* map, const char* h_text, const uint64_t* h_off, uint64_t n_queries, int* h_status, vlg_queries** out)
 {
     if (!out || (n_queries && (!h_text || !h_off))) return fail(VLG_E_INVALID, "null argument");
     *out = nullptr;
@@ -259,8 +315,11 @@ extern "C" vlg_status vlg_queries_parse_int(const char* h_text, const uint64_t* 
                     bool over = false;
                     while (c < e && *c >= '0' && *c <= '9') { if (x > (0xFFFFFFFFFFFFFFFFull - 9) / 10) over = true; x = x * 10 + (uint64_t)(*c - '0'); ++c; }
                     if (over) break;                                                    // the stream extraction fails: the rest is ignored
-                    if (x > 0xFFFFFFFFull) { st = VLG_E_INVALID; why = "symbol does not fit 32 bits"; break; }
-                    v.push_back((uint32_t)x);
+                    if (map) v.push_back(map->map(x));
+                    else {
+                        if (x > 0xFFFFFFFFull) { st = VLG_E_INVALID; why = "symbol does not fit 32 bits (larger symbols: vlg_symbol_map_create + vlg_queries_parse_int_mapped)"; break; }
+                        v.push_back((uint32_t)x);
+                    }
                 }
                 if (!st && v.empty()) { st = VLG_E_INVALID; why = "empty sub-pattern"; }
                 if (st) break;
@@ -291,6 +350,19 @@ extern "C" vlg_status vlg_queries_parse_int(const char* h_text, const uint64_t* 
     if (vlg_status st = upload_queries(q)) { vlg_queries_destroy(q); return st; }
     *out = q;
     return VLG_OK;
+}
+}  // namespace
+
+extern "C" vlg_status vlg_queries_parse_int(const char* h_text, const uint64_t* h_off, uint64_t n_queries, int* h_status, vlg_queries** out)
+{
+    return parse_int_batch(nullptr, h_text, h_off, n_queries, h_status, out);
+}
+
+extern "C" vlg_status vlg_queries_parse_int_mapped(const vlg_symbol_map* map, const char* h_text, const uint64_t* h_off, uint64_t n_queries,
+                                                   int* h_status, vlg_queries** out)
+{
+    if (!map) return fail(VLG_E_INVALID, "null argument");
+    return parse_int_batch(map, h_text, h_off, n_queries, h_status, out);
 }
 
 extern "C" vlg_status vlg_queries_create(const uint8_t* h_blob, const uint64_t* h_suboff, const uint64_t* h_qsub, const uint64_t* h_lo,

@@ -177,6 +177,44 @@ class Workspace:
                                            algorithmic_bytes=int(arr[i].algorithmic_bytes)) for i in range(min(n.value, 32))}
 
 
+class SymbolMap:
+    """vlg_symbol_map: the sorted distinct symbols of a 64-bit integer text, symbol -> rank + 1 (dense, order-preserving, never 0).
+    The device indexes hold uint32 symbols; a text with larger ones is mapped, indexed, and queried through the same map."""
+
+    def __init__(self, text):
+        t = np.ascontiguousarray(text, dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib().vlg_symbol_map_create(t.ctypes.data if len(t) else None, len(t), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vlg_symbol_map_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def sigma(self):
+        return int(lib().vlg_symbol_map_sigma(self._h))
+
+    def symbols(self):
+        out = np.zeros(self.sigma, dtype=np.uint64)
+        check(lib().vlg_symbol_map_symbols(self._h, out.ctypes.data if len(out) else None))
+        return out
+
+    def apply(self, symbols):
+        """-> uint32 array: rank + 1 of every symbol (sigma + 1 for a symbol the map's text does not hold)"""
+        t = np.ascontiguousarray(symbols, dtype=np.uint64)
+        out = np.zeros(len(t), dtype=np.uint32)
+        check(lib().vlg_symbol_map_apply(self._h, t.ctypes.data if len(t) else None, len(t), out.ctypes.data if len(t) else None))
+        return out
+
+    def queries(self, regexps, strict=True):
+        return Queries.from_int(regexps, strict=strict, symbol_map=self)
+
+
 def parse_query(regexp, dialect=capi.DIALECT_LIBRARY):
     """gapped_pattern_query / gapped_pattern on the host: -> (sub-patterns, lo[], hi[], end_len).  Raises VlgError(E_PARSE)."""
     raw = regexp.encode("latin-1") if isinstance(regexp, str) else bytes(regexp)
@@ -214,16 +252,21 @@ class Queries:
         return self
 
     @classmethod
-    def from_int(cls, regexps, strict=True):
+    def from_int(cls, regexps, strict=True, symbol_map=None):
         """Integer-alphabet batch (gapped_pattern_query<int_alphabet_tag>): sub-patterns are whitespace-separated decimals, gaps count
-        symbols -- for an integer-alphabet index (VlgIndex.build_int) or WtsaIndex over an integer text."""
+        symbols -- for an integer-alphabet index (VlgIndex.build_int) or WtsaIndex over an integer text.  symbol_map: the SymbolMap
+        the index's text went through (64-bit symbols): tokens are the original symbols."""
         raws = [r.encode("latin-1") if isinstance(r, str) else bytes(r) for r in regexps]
         off = np.zeros(len(raws) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(r) for r in raws])
         self = cls.__new__(cls)
         h = C.c_void_p()
         status = np.zeros(max(len(raws), 1), dtype=np.int32)
-        check(lib().vlg_queries_parse_int(b"".join(raws), off.ctypes.data, len(raws), None if strict else status.ctypes.data, C.byref(h)))
+        st = None if strict else status.ctypes.data
+        if symbol_map is not None:
+            check(lib().vlg_queries_parse_int_mapped(symbol_map._h, b"".join(raws), off.ctypes.data, len(raws), st, C.byref(h)))
+        else:
+            check(lib().vlg_queries_parse_int(b"".join(raws), off.ctypes.data, len(raws), st, C.byref(h)))
         self._h, self.n, self.status = h, len(raws), status[: len(raws)]
         return self
 
