@@ -136,7 +136,8 @@ vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out
  *   VLG_SAMPLING_TEXT_ORDER  the SA values that are multiples of d, found through a marked bit-vector over the SA indices:
  *                            is_sampled(i) = marked[i], csa[i] = samples[rank_marked(i)] * d   text_order_sa_sampling (:127-246) --
  *                            the locate indexes of benchmark/indexing_locate/index.config:9-12; a walk takes SA[i] % d LF steps
- * Every search entry point accepts it and returns identical results.  `src` must be SA-order sampled (plain or rrr) with n <= 2^32;
+ * Every search entry point accepts it and returns identical results.  `src` must be SA-order sampled (plain or rrr); the new index keeps
+ * its samples as wide as the source does (8 bytes when SA indices need 33 bits: n > 2^32, or VLG_FORCE_POS64);
  * VLG_SAMPLING_SA_ORDER with d = 1 (also vlg_index_build* with sa_sample_dens = 1, any n) keeps the whole suffix array in HBM
  * (csa_wt<wt_huff<>, 1, .>: 4 B per text character up to 4 GiB of text, 8 B beyond): csa[i] is one read (csa_wt.hpp:335-348 with
  * zero LF steps), vlg_search_batch's locate stage becomes a coalesced copy of the SA intervals and keeps no trail table;

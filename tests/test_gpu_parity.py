@@ -1218,14 +1218,19 @@ def test_rccl_branch_runs_with_one_rank(V, oracle):
         assert got["counts"][i] == len(o.search(queries[i]))
 
 
-@pytest.mark.parametrize("name,dens", [("dna_50k", 32), ("zipf40", 8), ("100a", 4), ("abracadabra", 1), ("dna_skew", 64)])
-def test_text_order_sa_sampling(torch_cuda, V, oracle, name, dens):
+@pytest.mark.parametrize("name,dens,force", [("dna_50k", 32, ""), ("zipf40", 8, ""), ("100a", 4, ""), ("abracadabra", 1, ""), ("dna_skew", 64, ""),
+                                             ("zipf40", 16, "2"), ("dna_50k", 5, "1"), ("abracadabra", 2, "2")])
+def test_text_order_sa_sampling(torch_cuda, V, oracle, monkeypatch, name, dens, force):
     """text_order_sa_sampling (include/sdsl/csa_sampling_strategy.hpp:127-246) as an index variant made by
     vlg_index_resample: the marked bit-vector and the condensed samples equal the oracle's restatement, csa[i] == SA[i] for every i
     through vlg_sa_batch, every search mode returns the tuples of the SA-order index and the oracle -- with exactly
-    sum(SA[i] % dens) LF steps when nothing is shared (the strategy's defining property) -- and it stacks on the rrr variant."""
+    sum(SA[i] % dens) LF steps when nothing is shared (the strategy's defining property) -- and it stacks on the rrr variant.
+    force: VLG_FORCE_POS64 -- the strategy is width-agnostic in the reference; "2" runs it on the kernels of BASELINE config 4 (33-bit
+    SA indices and 64-bit samples inside locate, 32-bit positions behind it), "1" on 64-bit positions throughout."""
     torch = torch_cuda
     from vlg_matching_amd.index import Workspace
+    if force:
+        monkeypatch.setenv("VLG_FORCE_POS64", force)
     text = TEXTS[name]()
     o = oracle.Index.from_text(text)
     sa = oracle.suffix_array(np.frombuffer(text + bytes(1), np.uint8)).astype(np.int64)
@@ -1233,6 +1238,7 @@ def test_text_order_sa_sampling(torch_cuda, V, oracle, name, dens):
     idx = base.resample(text_order=True, dens=dens)
     info = idx.info()
     assert info["sampling"] == 1 and info["sa_sample_dens"] == dens and info["n_samples"] == (len(sa) + dens - 1) // dens
+    assert info["pos_bytes"] == (8 if force else 4)
     to = oracle.TextOrder(o, dens)
     assert (idx.marked() == to.marked()).all() and (idx.marked() == (sa % dens == 0)).all()
     want_samples = to.samples()

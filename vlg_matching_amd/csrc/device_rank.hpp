@@ -183,12 +183,15 @@ struct SaOrderSampling {
 };
 // TextOrder: _text_order_sampling (csa_sampling_strategy.hpp:127-246): is_sampled(i) = marked[i] (:185-188), value =
 // samples[rank_marked(i)] * dens (:191-194).  The mark and the rank come out of the same 32-byte super-block.
+// (sample_t: 4-byte condensed values for n <= 2^32, 8-byte ones for an index with wide SA indices -- the width the index keeps its
+// samples in, csa_sampling_strategy.hpp:127-246 is width-agnostic)
+template <typename sample_t>
 struct TextOrderSampling {
     uint32_t dens;
     const Block* marked;
-    const uint32_t* samples;
+    const sample_t* samples;
     __device__ __forceinline__ explicit TextOrderSampling(const IndexView& iv)
-        : dens(iv.dens), marked(iv.marked), samples(reinterpret_cast<const uint32_t*>(iv.samples)) {}
+        : dens(iv.dens), marked(iv.marked), samples(reinterpret_cast<const sample_t*>(iv.samples)) {}
     __device__ __forceinline__ bool probe(uint64_t i, uint64_t& value) const
     {
         uint32_t blk, off;

@@ -684,8 +684,9 @@ namespace {
 
 // every SA value from the SA-order samples: a lane starts at one sample (i, SA[i]) and walks LF -- (LF(i), SA[i] - 1) -- up to the next
 // sampled index, so that every SA index is visited exactly once with its value
+// (sample_t = sa_t: 32-bit values for n <= 2^32, 64-bit ones for an index with wide SA indices -- SA[0] = n - 1 can be 2^32)
 template <class BV, typename sample_t>
-__global__ void __launch_bounds__(256) sa_expand_kernel(IndexView iv, uint32_t* __restrict__ sa)
+__global__ void __launch_bounds__(256) sa_expand_kernel(IndexView iv, sample_t* __restrict__ sa)
 {
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
@@ -693,7 +694,7 @@ __global__ void __launch_bounds__(256) sa_expand_kernel(IndexView iv, uint32_t* 
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < iv.n_samples; j += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t i = j * iv.dens, v = samples[j];
         do {
-            sa[i] = (uint32_t)v;
+            sa[i] = (sample_t)v;
             uint32_t node = 0, c = 0;
             uint64_t pos = i;
             if (iv.sigma > 1) {
@@ -715,7 +716,8 @@ __global__ void __launch_bounds__(256) sa_expand_kernel(IndexView iv, uint32_t* 
 }
 
 // marks of one super-block: bit = (SA[i] % dens == 0); pops[b] = its ones
-__global__ void marked_pack_kernel(const uint32_t* __restrict__ sa, uint64_t n, uint32_t dens, Block* __restrict__ blocks, uint64_t nb,
+template <typename sa_t>
+__global__ void marked_pack_kernel(const sa_t* __restrict__ sa, uint64_t n, uint32_t dens, Block* __restrict__ blocks, uint64_t nb,
                                    uint32_t* __restrict__ pops)
 {
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) {
@@ -738,11 +740,12 @@ __global__ void marked_counts_kernel(Block* __restrict__ blocks, const uint32_t*
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x) blocks[b].cnt = before[b];
 }
 // samples[rank_marked(i)] = SA[i] / dens for the marked i (csa_sampling_strategy.hpp:158-164)
-__global__ void text_order_samples_kernel(const uint32_t* __restrict__ sa, uint64_t n, uint32_t dens, const Block* __restrict__ blocks,
-                                          uint32_t* __restrict__ samples)
+template <typename sa_t>
+__global__ void text_order_samples_kernel(const sa_t* __restrict__ sa, uint64_t n, uint32_t dens, const Block* __restrict__ blocks,
+                                          sa_t* __restrict__ samples)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t v = sa[i];
+        const sa_t v = sa[i];
         if (v % dens) continue;
         const uint64_t blk = i / kBlockBits;
         const uint32_t off = (uint32_t)(i - blk * kBlockBits);
@@ -753,7 +756,8 @@ __global__ void text_order_samples_kernel(const uint32_t* __restrict__ sa, uint6
         samples[r] = v / dens;
     }
 }
-__global__ void sa_order_samples_kernel(const uint32_t* __restrict__ sa, uint64_t n_samples, uint32_t dens, uint32_t* __restrict__ samples)
+template <typename sa_t>
+__global__ void sa_order_samples_kernel(const sa_t* __restrict__ sa, uint64_t n_samples, uint32_t dens, sa_t* __restrict__ samples)
 {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_samples; j += (uint64_t)gridDim.x * blockDim.x) samples[j] = sa[j * dens];
 }
@@ -775,6 +779,64 @@ __global__ void marked_words_kernel(const Block* __restrict__ blocks, uint64_t n
 
 }  // namespace
 
+namespace {
+// sa_t = the width the source keeps its samples in (and the new index keeps its own in): uint32_t for n <= 2^32, uint64_t for wide SA indices
+template <typename sa_t>
+vlg_status resample_run(const vlg_index* src, int sampling, uint32_t dens, vlg_index* idx, hipStream_t stream)
+{
+    const uint64_t n = src->hdr.n;
+    DevBuf d_sa, d_pops, d_tmp;
+    VLG_HIP_TRY(d_sa.alloc(n * sizeof(sa_t)));
+    const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((src->view.n_samples + 255) / 256, 8192)));
+    if (src->view.bv_kind == kBvRrr63) hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_expand_kernel<RrrBV, sa_t>), grid, dim3(256), 0, stream, src->view, d_sa.as<sa_t>());
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_expand_kernel<PlainBV, sa_t>), grid, dim3(256), 0, stream, src->view, d_sa.as<sa_t>());
+    VLG_HIP_TRY(hipGetLastError());
+    BlobHeader& h = idx->hdr;
+    h = src->hdr;
+    h.dens = dens;
+    h.sampling = (uint32_t)sampling;
+    h.n_samples = (n + dens - 1) / dens;
+    layout_blob(h);
+    VLG_HIP_TRY(hipMalloc(&idx->d_blob, h.total_bytes));
+    idx->owns_blob = true;
+    uint8_t* b = reinterpret_cast<uint8_t*>(idx->d_blob);
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(src->d_blob);
+    VLG_HIP_TRY(hipMemcpyAsync(b, &h, sizeof h, hipMemcpyHostToDevice, stream));
+    BlobSection sec[11], old[11];
+    blob_sections(h, sec);
+    blob_sections(src->hdr, old);
+    for (int i = 0; i < 11; ++i) {
+        if (sec[i].off == &BlobHeader::off_samples || sec[i].off == &BlobHeader::off_marked || !sec[i].bytes) continue;
+        if (old[i].bytes != sec[i].bytes) return fail(VLG_E_INTERNAL, "blob sections changed size");
+        VLG_HIP_TRY(hipMemcpyAsync(b + h.*(sec[i].off), sb + src->hdr.*(old[i].off), sec[i].bytes, hipMemcpyDeviceToDevice, stream));
+    }
+    sa_t* samples = reinterpret_cast<sa_t*>(b + h.off_samples);
+    if (sampling == VLG_SAMPLING_SA_ORDER) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_order_samples_kernel<sa_t>), dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((h.n_samples + 255) / 256, 8192))), dim3(256), 0, stream,
+                           d_sa.as<sa_t>(), h.n_samples, dens, samples);
+    } else {
+        const uint64_t nb = n / kBlockBits + 1;
+        if (h.n_samples > 0xFFFFFFF0ull) return fail(VLG_E_UNSUPPORTED, "text-order sampling: more than 2^32 marked indices (choose a larger density)");
+        Block* mk = reinterpret_cast<Block*>(b + h.off_marked);
+        VLG_HIP_TRY(d_pops.alloc((nb + 1) * 4));
+        const dim3 gb((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((nb + 255) / 256, 8192)));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(marked_pack_kernel<sa_t>), gb, dim3(256), 0, stream, d_sa.as<sa_t>(), n, dens, mk, nb, d_pops.as<uint32_t>());
+        size_t tb = 0;
+        VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_pops.as<uint32_t>(), d_pops.as<uint32_t>(), 0u, nb, rocprim::plus<uint32_t>(), stream));
+        VLG_HIP_TRY(d_tmp.alloc(tb + 16));
+        VLG_HIP_TRY(rocprim::exclusive_scan(d_tmp.p, tb, d_pops.as<uint32_t>(), d_pops.as<uint32_t>(), 0u, nb, rocprim::plus<uint32_t>(), stream));
+        hipLaunchKernelGGL(marked_counts_kernel, gb, dim3(256), 0, stream, mk, d_pops.as<uint32_t>(), nb);
+        VLG_HIP_TRY(hipMemsetAsync(samples, 0, h.n_samples * sizeof(sa_t), stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(text_order_samples_kernel<sa_t>), dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 16384))), dim3(256), 0, stream,
+                           d_sa.as<sa_t>(), n, dens, mk, samples);
+    }
+    VLG_HIP_TRY(hipGetLastError());
+    VLG_HIP_TRY(hipStreamSynchronize(stream));
+    bind_view(idx);
+    return VLG_OK;
+}
+}  // namespace
+
 extern "C" vlg_status vlg_index_resample(const vlg_index* src, int sampling, uint32_t dens, vlg_index** out)
 {
     release_cached_device_memory();
@@ -784,62 +846,12 @@ extern "C" vlg_status vlg_index_resample(const vlg_index* src, int sampling, uin
     if (!dens) dens = 32;
     if (src->is_int) return fail(VLG_E_UNSUPPORTED, "resampling is built for byte-alphabet indexes");
     if (src->hdr.sampling != kSamplingSaOrder) return fail(VLG_E_INVALID, "the source index must be sampled in SA order");
-    if (src->hdr.sample_bytes != 4) return fail(VLG_E_UNSUPPORTED, "resampling is built for n <= 2^32 (32-bit SA indices)");
-    const uint64_t n = src->hdr.n;
+    if (src->hdr.sample_bytes != 4 && src->hdr.sample_bytes != 8) return fail(VLG_E_INTERNAL, "unknown sample width");
     vlg_index* idx = new vlg_index();
     idx->tree = src->tree;
     hipStream_t stream = nullptr;
-    auto run = [&]() -> vlg_status {
-        DevBuf d_sa, d_pops, d_tmp;
-        VLG_HIP_TRY(d_sa.alloc(n * 4));
-        const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((src->view.n_samples + 255) / 256, 8192)));
-        if (src->view.bv_kind == kBvRrr63) hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_expand_kernel<RrrBV, uint32_t>), grid, dim3(256), 0, stream, src->view, d_sa.as<uint32_t>());
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_expand_kernel<PlainBV, uint32_t>), grid, dim3(256), 0, stream, src->view, d_sa.as<uint32_t>());
-        VLG_HIP_TRY(hipGetLastError());
-        BlobHeader& h = idx->hdr;
-        h = src->hdr;
-        h.dens = dens;
-        h.sampling = (uint32_t)sampling;
-        h.n_samples = (n + dens - 1) / dens;
-        layout_blob(h);
-        VLG_HIP_TRY(hipMalloc(&idx->d_blob, h.total_bytes));
-        idx->owns_blob = true;
-        uint8_t* b = reinterpret_cast<uint8_t*>(idx->d_blob);
-        const uint8_t* sb = reinterpret_cast<const uint8_t*>(src->d_blob);
-        VLG_HIP_TRY(hipMemcpyAsync(b, &h, sizeof h, hipMemcpyHostToDevice, stream));
-        BlobSection sec[11], old[11];
-        blob_sections(h, sec);
-        blob_sections(src->hdr, old);
-        for (int i = 0; i < 11; ++i) {
-            if (sec[i].off == &BlobHeader::off_samples || sec[i].off == &BlobHeader::off_marked || !sec[i].bytes) continue;
-            if (old[i].bytes != sec[i].bytes) return fail(VLG_E_INTERNAL, "blob sections changed size");
-            VLG_HIP_TRY(hipMemcpyAsync(b + h.*(sec[i].off), sb + src->hdr.*(old[i].off), sec[i].bytes, hipMemcpyDeviceToDevice, stream));
-        }
-        uint32_t* samples = reinterpret_cast<uint32_t*>(b + h.off_samples);
-        if (sampling == VLG_SAMPLING_SA_ORDER) {
-            hipLaunchKernelGGL(sa_order_samples_kernel, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((h.n_samples + 255) / 256, 8192))), dim3(256), 0, stream,
-                               d_sa.as<uint32_t>(), h.n_samples, dens, samples);
-        } else {
-            const uint64_t nb = n / kBlockBits + 1;
-            Block* mk = reinterpret_cast<Block*>(b + h.off_marked);
-            VLG_HIP_TRY(d_pops.alloc((nb + 1) * 4));
-            const dim3 gb((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((nb + 255) / 256, 8192)));
-            hipLaunchKernelGGL(marked_pack_kernel, gb, dim3(256), 0, stream, d_sa.as<uint32_t>(), n, dens, mk, nb, d_pops.as<uint32_t>());
-            size_t tb = 0;
-            VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_pops.as<uint32_t>(), d_pops.as<uint32_t>(), 0u, nb, rocprim::plus<uint32_t>(), stream));
-            VLG_HIP_TRY(d_tmp.alloc(tb + 16));
-            VLG_HIP_TRY(rocprim::exclusive_scan(d_tmp.p, tb, d_pops.as<uint32_t>(), d_pops.as<uint32_t>(), 0u, nb, rocprim::plus<uint32_t>(), stream));
-            hipLaunchKernelGGL(marked_counts_kernel, gb, dim3(256), 0, stream, mk, d_pops.as<uint32_t>(), nb);
-            VLG_HIP_TRY(hipMemsetAsync(samples, 0, h.n_samples * 4, stream));
-            hipLaunchKernelGGL(text_order_samples_kernel, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 16384))), dim3(256), 0, stream,
-                               d_sa.as<uint32_t>(), n, dens, mk, samples);
-        }
-        VLG_HIP_TRY(hipGetLastError());
-        VLG_HIP_TRY(hipStreamSynchronize(stream));
-        bind_view(idx);
-        return VLG_OK;
-    };
-    const vlg_status st = run();
+    // (the new index keeps the source's sample width: 8 bytes when SA indices are wide -- n > 2^32, or VLG_FORCE_POS64)
+    const vlg_status st = src->hdr.sample_bytes == 8 ? resample_run<uint64_t>(src, sampling, dens, idx, stream) : resample_run<uint32_t>(src, sampling, dens, idx, stream);
     if (st) { vlg_index_destroy(idx); return st; }
     *out = idx;
     return VLG_OK;

@@ -503,8 +503,7 @@ __global__ void __launch_bounds__(256) locate_kernel(IndexView iv, pos_t* __rest
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint64_t next = wave * per_wave;                       // wave-uniform cursor into the slice
     const uint64_t slice_end = next + per_wave < total ? next + per_wave : total;
-    static_assert(!kTextOrder || !kWide, "text-order sampling is built for n <= 2^32");
-    using Sampling = typename std::conditional<kTextOrder, TextOrderSampling, SaOrderSampling<sample_t>>::type;
+    using Sampling = typename std::conditional<kTextOrder, TextOrderSampling<sample_t>, SaOrderSampling<sample_t>>::type;
     const Sampling sampling(iv);
 
     uint64_t t = 0;          // slot being worked on
@@ -798,9 +797,8 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
 {
     __shared__ WalkLds<BV> s;
     stage_walk(s, iv);
-    static_assert(!kTextOrder || !kWide, "text-order sampling is built for n <= 2^32");
     using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
-    using Sampling = typename std::conditional<kTextOrder, TextOrderSampling, SaOrderSampling<sample_t>>::type;
+    using Sampling = typename std::conditional<kTextOrder, TextOrderSampling<sample_t>, SaOrderSampling<sample_t>>::type;
     const Sampling sampling(iv);
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x)
@@ -825,7 +823,7 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
     __shared__ ListStage s_lists;
     stage_walk(s, iv);
     using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
-    using Sampling = typename std::conditional<kTextOrder, TextOrderSampling, SaOrderSampling<sample_t>>::type;
+    using Sampling = typename std::conditional<kTextOrder, TextOrderSampling<sample_t>, SaOrderSampling<sample_t>>::type;
     const Sampling sampling(iv);
     constexpr uint32_t kShift = kWide ? 33 : 32;
     constexpr uint32_t kPer = 8;
@@ -1194,8 +1192,8 @@ vlg_status launch_locate(const IndexView& iv, pos_t* d_io, uint64_t total, unsig
         if (text_order) { if (rrr) VLG_LOCATE(RrrBV, true); else VLG_LOCATE(PlainBV, true); }
         else { if (rrr) VLG_LOCATE(RrrBV, false); else VLG_LOCATE(PlainBV, false); }
     } else {
-        if (text_order) return fail(VLG_E_UNSUPPORTED, "text-order sampling with 64-bit SA indices");
-        if (rrr) VLG_LOCATE(RrrBV, false); else VLG_LOCATE(PlainBV, false);
+        if (text_order) { if (rrr) VLG_LOCATE(RrrBV, true); else VLG_LOCATE(PlainBV, true); }
+        else { if (rrr) VLG_LOCATE(RrrBV, false); else VLG_LOCATE(PlainBV, false); }
     }
 #undef VLG_LOCATE
     VLG_HIP_TRY(hipGetLastError());
@@ -1232,7 +1230,6 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     if (iv.sample_bytes != (kWide ? 8u : 4u)) return fail(VLG_E_INTERNAL, "sorted sweep: sample width does not match the instantiation");
     if (sizeof(pos_t) == 4 && iv.n > (1ull << 32) + 1) return fail(VLG_E_INTERNAL, "sorted sweep: positions do not fit 32 bits");
     const bool rrr = iv.bv_kind == kBvRrr63, text_order = iv.sampling == kSamplingTextOrder;
-    if (kWide && text_order) return fail(VLG_E_UNSUPPORTED, "text-order sampling with 64-bit SA indices");
     if (iv.dens == 1 && !text_order && total) {                  // every SA index is sampled: no walk, no trails, no records
         using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
         if (timer) timer->begin(0);
@@ -1279,12 +1276,8 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
                                    else if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, false>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val_a, key_a, out, d_stats, d_counter, member, rec); \
                                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<BV, pos_t, TR, kWide, TO>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, step, out, d_stats, d_counter, member, rec, t0, ahead && fused_first && step == 1); } while (0)
 #define VLG_STEP_BV(TR, TO) do { if (rrr) VLG_STEP(RrrBV, TR, TO); else VLG_STEP(PlainBV, TR, TO); } while (0)
-            if constexpr (!kWide) {
-                if (text_order) { if (member) VLG_STEP_BV(true, true); else VLG_STEP_BV(false, true); }
-                else { if (member) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false); }
-            } else {
-                if (member) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false);
-            }
+            if (text_order) { if (member) VLG_STEP_BV(true, true); else VLG_STEP_BV(false, true); }
+            else { if (member) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false); }
 #undef VLG_STEP_BV
 #undef VLG_STEP
             if (timer) timer->end(0);
@@ -1316,12 +1309,8 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             const dim3 grid((uint32_t)((waves + 3) / 4));
             if (timer) timer->begin(0);
 #define VLG_TAIL(BV, TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, BV, true, kWide, TO>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave, d_stats, val_a, step, member ? rec : nullptr, t0, member)
-            if constexpr (!kWide) {
-                if (text_order) { if (rrr) VLG_TAIL(RrrBV, true); else VLG_TAIL(PlainBV, true); }
-                else { if (rrr) VLG_TAIL(RrrBV, false); else VLG_TAIL(PlainBV, false); }
-            } else {
-                if (rrr) VLG_TAIL(RrrBV, false); else VLG_TAIL(PlainBV, false);
-            }
+            if (text_order) { if (rrr) VLG_TAIL(RrrBV, true); else VLG_TAIL(PlainBV, true); }
+            else { if (rrr) VLG_TAIL(RrrBV, false); else VLG_TAIL(PlainBV, false); }
 #undef VLG_TAIL
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());

@@ -313,7 +313,12 @@ vlg_status parse_int_batch(const vlg_symbol_map* map, const char* h_text, const 
                     if (c >= e || *c < '0' || *c > '9') break;
                     uint64_t x = 0;
                     bool over = false;
-                    while (c < e && *c >= '0' && *c <= '9') { if (x > (0xFFFFFFFFFFFFFFFFull - 9) / 10) over = true; x = x * 10 + (uint64_t)(*c - '0'); ++c; }
+                    while (c < e && *c >= '0' && *c <= '9') {
+                        const uint64_t dgt = (uint64_t)(*c - '0');
+                        if (x > 0xFFFFFFFFFFFFFFFFull / 10 || (x == 0xFFFFFFFFFFFFFFFFull / 10 && dgt > 0xFFFFFFFFFFFFFFFFull % 10)) over = true;      // beyond 2^64 - 1
+                        x = x * 10 + dgt;
+                        ++c;
+                    }
                     if (over) break;                                                    // the stream extraction fails: the rest is ignored
                     if (map) v.push_back(map->map(x));
                     else {
