@@ -1423,8 +1423,27 @@ def test_integer_alphabet_fm_index(torch_cuda, V, oracle, name):
     wres = WtsaIndex(text).search(qs)
     for i in range(len(qs)):
         assert wres.tuples(i).tolist() == want[i], qs[i]
-    # LF-step parity with the restated reference (no interval sharing: every occurrence walks to its own sample)
+    # the sorted sweep on the wavelet matrix (sigma <= 65534: a 16-bit partition key), with walks that stop at elements of the batch,
+    # finished by the sorted rounds or by the stragglers' kernel: same tuples; with nothing shared, the reference's LF steps
     from vlg_matching_amd.index import Workspace
+    st0 = np.zeros(4, dtype=np.uint64)
+    for qq in qs:
+        o.search(qq, stats=st0)
+    for opts in ({"sweep_min": 1, "sweep_tail": 16}, {"sweep_min": 1, "sweep_tail": 1 << 30}, {"sweep_min": 1, "sweep_tail": 4, "trail": 0},
+                 {"sweep_min": 1, "sweep_tail": 16, "dedup": 0}):
+        wsx = Workspace()
+        for k_, v_ in opts.items():
+            wsx.set_option(k_, v_)
+        rx = idx.search(qs, workspace=wsx)
+        assert rx.summary["locate_mode"] == V.capi.LOCATE_SWEEP or rx.summary["located_occurrences"] == 0, opts
+        for i in range(len(qs)):
+            assert rx.tuples(i).tolist() == want[i], (qs[i], opts)
+        if opts.get("dedup", 1) == 0:
+            assert rx.summary["lf_steps"] == int(st0[1]), opts             # (the matrix reads one block per level and step: levels are its own count)
+            assert rx.summary["wt_levels_locate"] == int(st0[1]) * idx.info()["max_code_len"]
+        elif opts.get("trail", 1):
+            assert rx.summary["lf_steps"] <= int(st0[1])
+    # LF-step parity with the restated reference (no interval sharing: every occurrence walks to its own sample)
     ws = Workspace()
     ws.set_option("dedup", 0)
     st = np.zeros(4, dtype=np.uint64)

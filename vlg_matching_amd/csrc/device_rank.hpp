@@ -68,6 +68,17 @@ __device__ __forceinline__ uint64_t node_rank1(const Block* blocks, uint32_t bas
     return block_rank(r, off);
 }
 
+// the sweep's member bit-vector (kernels.hip: sweep_element): is SA index i an element of the batch, and which -- its slot is the
+// number of member bits before it
+__device__ __forceinline__ bool member_probe(const Block* __restrict__ member, uint64_t i, uint32_t& slot)
+{
+    uint32_t blk, off, bit;
+    split224(i, blk, off);
+    const BlockRegs r = load_block(member, blk);
+    slot = block_rank_bit(r, off, bit);
+    return bit != 0;
+}
+
 // ---- bit-vector policies: how one node-relative (rank1, bit) pair is obtained -----------------------------------
 // Plain: one 256-bit super-block read (K1).
 struct PlainBV {

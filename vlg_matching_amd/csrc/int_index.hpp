@@ -155,6 +155,175 @@ __global__ void __launch_bounds__(256) int_locate_kernel(IntView v, uint32_t* __
     }
 }
 
+// ---- the sorted sweep on the wavelet matrix (round 4; kernels.hip: K3s explains the sweep, sweep_element the records) ---------------
+// An LF step reads one super-block per matrix level and the symbol's D entry; the symbol read (its compact number, < sigma <= 65534) is
+// the partition key.  Everything else -- rounds, partition, member bit-vector, records, resolution -- is run_locate_sweep's.
+__device__ __forceinline__ uint64_t int_lf(const IntView& v, const uint64_t* __restrict__ sZ, uint64_t i, uint32_t& c, uint32_t& n_lv)
+{
+    uint64_t p = i;
+    c = 0;
+    for (uint32_t l = 0; l < v.n_levels; ++l) {
+        uint32_t blk, o, bit;
+        split224(p, blk, o);
+        const BlockRegs r = load_block(v.levels, (uint32_t)(l * v.nb) + blk);
+        const uint64_t r1 = block_rank_bit(r, o, bit);
+        ++n_lv;
+        p = bit ? sZ[l] + r1 : p - r1;
+        c = (c << 1) | bit;
+    }
+    return v.D[c] + p;                                               // LF: suffix_array_helper.hpp:341-348
+}
+
+__device__ __forceinline__ void int_counters_add(unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long* __restrict__ stats,
+                                                 unsigned long long* __restrict__ n_done)
+{
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); c += __shfl_down(c, o); }
+    if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&stats[0], a); if (b) atomicAdd(&stats[1], b); if (c && n_done) atomicAdd(n_done, c); }
+}
+
+template <bool kTrail, bool kFirst, bool kAhead>
+__device__ __forceinline__ void int_sweep_element(const IntView& v, const uint64_t* __restrict__ sZ, uint64_t e, uint64_t v64, uint64_t* __restrict__ val,
+                                                  uint16_t* __restrict__ key, uint32_t step, uint32_t* __restrict__ out, const Block* __restrict__ member,
+                                                  uint64_t* __restrict__ rec, uint64_t slot0, bool probed, uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin)
+{
+    const uint64_t i = v64 & 0xFFFFFFFFull, slot = v64 >> 32;
+    uint32_t owner = 0;
+    if (i % v.dens == 0) {                                           // csa_sampling_strategy.hpp:102-111
+        uint64_t r = (uint64_t)v.samples[i / v.dens] + step;
+        if (r >= v.n) r -= v.n;                                      // csa_wt.hpp:343-347
+        if (kTrail) rec[slot0 + slot] = r; else out[slot] = (uint32_t)r;
+        key[e] = (uint16_t)v.sigma;
+        ++n_fin;
+    } else if (kTrail && !kFirst && !probed && member_probe(member, i, owner)) {
+        const uint64_t delta = step;
+        const uint64_t ro = rec[owner];
+        uint64_t r;
+        if (ro == ~0ull) r = (delta << 32) | owner;                  // still walking: follow it
+        else if ((ro >> 32) == 0) r = ro + delta;                    // its position is known
+        else r = ro + (delta << 32);                                 // it follows someone itself: follow that one
+        rec[slot0 + slot] = r;
+        key[e] = (uint16_t)v.sigma;
+        ++n_fin;
+    } else {
+        if (kTrail && kFirst) rec[slot0 + slot] = ~0ull;
+        uint32_t c;
+        const uint64_t j = int_lf(v, sZ, i, c, n_lv);
+        ++n_lf;
+        if (kTrail && kAhead && member_probe(member, j, owner)) {
+            rec[slot0 + slot] = ((uint64_t)(step + 1) << 32) | owner;
+            key[e] = (uint16_t)v.sigma;
+            ++n_fin;
+        } else {
+            val[e] = (v64 & ~0xFFFFFFFFull) | j;
+            key[e] = (uint16_t)c;
+        }
+    }
+}
+
+template <bool kTrail>
+__global__ void __launch_bounds__(256) int_sweep_step_kernel(IntView v, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count, uint32_t step,
+                                                             uint32_t* __restrict__ out, unsigned long long* __restrict__ stats, unsigned long long* __restrict__ n_done,
+                                                             const Block* __restrict__ member, uint64_t* __restrict__ rec, uint64_t slot0, bool probed)
+{
+    __shared__ uint64_t sZ[kMaxIntLevels];
+    if (threadIdx.x < v.n_levels) sZ[threadIdx.x] = v.Z[threadIdx.x];
+    __syncthreads();
+    uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x)
+        int_sweep_element<kTrail, false, false>(v, sZ, e, val[e], val, key, step, out, member, rec, slot0, probed, n_lv, n_lf, n_fin);
+    int_counters_add(n_lf, n_lv, n_fin, stats, n_done);
+}
+
+template <bool kTrail, bool kAhead>
+__global__ void __launch_bounds__(256) int_sweep_first_kernel(IntView v, const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t t0,
+                                                              uint64_t total, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint32_t* __restrict__ out,
+                                                              unsigned long long* __restrict__ stats, unsigned long long* __restrict__ n_done,
+                                                              const Block* __restrict__ member, uint64_t* __restrict__ rec)
+{
+    constexpr uint32_t kPer = 8;
+    __shared__ uint64_t sZ[kMaxIntLevels];
+    __shared__ uint64_t s_first;
+    if (threadIdx.x < v.n_levels) sZ[threadIdx.x] = v.Z[threadIdx.x];
+    uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
+    for (uint64_t base = t0 + (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t lo = 0, hi = n_pat;                             // last list with out_off[p] <= base
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (out_off[mid] <= base) lo = mid; else hi = mid; }
+            s_first = lo;
+        }
+        __syncthreads();
+        uint64_t p = s_first;
+#pragma unroll 1
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint64_t t = base + i * 256 + threadIdx.x;
+            if (t < total) {
+                while (out_off[p + 1] <= t) ++p;
+                const uint64_t v64 = ((t - t0) << 32) | (l[p] + (t - out_off[p]));
+                int_sweep_element<kTrail, true, kAhead>(v, sZ, t - t0, v64, val, key, 0u, out, member, rec, t0, false, n_lv, n_lf, n_fin);
+            }
+        }
+    }
+    int_counters_add(n_lf, n_lv, n_fin, stats, n_done);
+}
+
+// the stragglers: int_locate_kernel's refilling lanes on the elements val[] = slot << 32 | SA index that have walked `step` steps
+__global__ void __launch_bounds__(256) int_sweep_tail_kernel(IntView v, uint32_t* __restrict__ out, uint64_t total, uint32_t per_wave, unsigned long long* __restrict__ stats,
+                                                             const uint64_t* __restrict__ val, uint32_t step, uint64_t* __restrict__ rec, uint64_t slot0,
+                                                             const Block* __restrict__ member)
+{
+    __shared__ uint64_t sZ[kMaxIntLevels];
+    if (threadIdx.x < v.n_levels) sZ[threadIdx.x] = v.Z[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint64_t next = wave * per_wave;
+    const uint64_t slice_end = next + per_wave < total ? next + per_wave : total;
+    uint64_t t = 0, i = 0;
+    uint32_t off = 0, n_lf = 0, n_lv = 0;
+    bool active = false, need = true;
+    for (;;) {
+        const unsigned long long m = __ballot(need);
+        if (m) {
+            const uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
+            if (need) {
+                const uint64_t cand = next + before;
+                if (cand < slice_end) { const uint64_t e = val[cand]; t = e >> 32; i = e & 0xFFFFFFFFull; off = step; active = true; }
+                else active = false;
+                need = false;
+            }
+            next += __popcll(m);
+        }
+        if (!__any(active)) break;
+        if (active) {
+            uint32_t owner = 0;
+            if (i % v.dens == 0) {
+                uint64_t r = (uint64_t)v.samples[i / v.dens] + off;
+                if (r >= v.n) r -= v.n;
+                if (rec) rec[slot0 + t] = r; else out[t] = (uint32_t)r;
+                need = true;
+                active = false;
+            } else if (rec && member && off != 0 && member_probe(member, i, owner)) {
+                const uint64_t delta = off;
+                const uint64_t ro = rec[owner];
+                uint64_t r;
+                if (ro == ~0ull) r = (delta << 32) | owner;
+                else if ((ro >> 32) == 0) r = ro + delta;
+                else r = ro + (delta << 32);
+                rec[slot0 + t] = r;
+                need = true;
+                active = false;
+            } else {
+                uint32_t c;
+                i = int_lf(v, sZ, i, c, n_lv);
+                ++off;
+                ++n_lf;
+            }
+        }
+    }
+    int_counters_add(n_lf, n_lv, 0, stats, nullptr);
+}
+
 // wt_int::rank(i, c) on raw symbols (for the primitives test): out = #c in BWT[0, i)
 __global__ void __launch_bounds__(256) int_rank_kernel(IntView v, const uint64_t* __restrict__ pos, const uint32_t* __restrict__ sym, uint64_t* __restrict__ out,
                                                        uint64_t count)
@@ -429,6 +598,37 @@ vlg_status launch_int_backward_search(const IntView& v, const uint8_t* d_blob, c
     hipLaunchKernelGGL(int_backward_search_kernel, dim3(grid_for(n_pat, 4096)), dim3(256), 0, st, v, d_blob, d_off, n_pat, d_l, d_r, d_stat_levels);
     VLG_HIP_TRY(hipGetLastError());
     return VLG_OK;
+}
+
+// the integer index in the sorted sweep (sigma <= 65534: the partition key is 16 bits wide)
+vlg_status launch_int_locate_sweep(const IntView& v, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total, uint32_t* d_out,
+                                   uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp, size_t temp_bytes, unsigned long long* d_counter,
+                                   unsigned long long* d_stats, uint64_t tail_threshold, hipStream_t stream, LaunchTimer* timer, Block* member,
+                                   uint32_t n_member_lists, uint64_t* rec, const std::function<vlg_status()>* while_first_step)
+{
+    if (v.sigma >= 0xFFFFu || v.n_levels < 1 || v.n > (1ull << 32)) return fail(VLG_E_INTERNAL, "integer index: not for the sorted sweep");
+    auto grid_of = [](uint64_t n, uint32_t cap) { return dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, cap))); };
+    SweepKernels K;
+    K.n = v.n;
+    K.sigma = (uint32_t)v.sigma;
+    K.first = [&](uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out, unsigned long long* counter, const Block* mem, uint64_t* rc, bool ahead) {
+        const dim3 g = grid_of((t1 - t0 + 7) / 8, 8192);
+        uint32_t* o = static_cast<uint32_t*>(out);
+        if (mem && ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<true, true>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
+        else if (mem) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<true, false>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<false, false>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
+    };
+    K.step = [&](uint64_t* val, uint16_t* key, uint64_t alive, uint32_t step, void* out, unsigned long long* counter, const Block* mem, uint64_t* rc, uint64_t t0, bool probed) {
+        const dim3 g = grid_of(alive, 4096);
+        uint32_t* o = static_cast<uint32_t*>(out);
+        if (mem) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_step_kernel<true>), g, dim3(256), 0, stream, v, val, key, alive, step, o, d_stats, counter, mem, rc, t0, probed);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_step_kernel<false>), g, dim3(256), 0, stream, v, val, key, alive, step, o, d_stats, counter, mem, rc, t0, probed);
+    };
+    K.tail = [&](void* out, uint64_t alive, uint32_t per_wave, const uint64_t* val, uint32_t step, uint64_t* rc, uint64_t t0, const Block* mem, uint32_t blocks) {
+        hipLaunchKernelGGL(int_sweep_tail_kernel, dim3(blocks), dim3(256), 0, stream, v, static_cast<uint32_t*>(out), alive, per_wave, d_stats, val, step, rc, t0, mem);
+    };
+    return run_locate_sweep<uint32_t, false>(K, d_l, d_out_off, n_pat, total, d_out, val_a, val_b, key_a, key_b, temp, temp_bytes, d_counter, tail_threshold, stream, timer,
+                                             member, n_member_lists, rec, while_first_step);
 }
 
 vlg_status launch_int_locate(const IntView& v, uint32_t* d_io, uint64_t total, unsigned long long* d_stats, hipStream_t st)

@@ -460,16 +460,6 @@ __global__ void __launch_bounds__(256) member_build_kernel(const uint64_t* __res
     }
 }
 
-__device__ __forceinline__ bool member_probe(const Block* __restrict__ member, uint64_t i, uint32_t& slot)
-{
-    uint32_t blk, off, bit;
-    split224(i, blk, off);
-    const BlockRegs r = load_block(member, blk);
-    slot = block_rank_bit(r, off, bit);
-    return bit != 0;
-}
-
-
 // =============================================================================================
 // K3: csa[i] = LF iteration to the next sampled SA index (include/sdsl/csa_wt.hpp:335-348,
 //     LF = C[c] + inverse_select(i): suffix_array_helper.hpp:336-349, wt_pc.hpp:385-402).
@@ -1215,38 +1205,29 @@ size_t sweep_temp_bytes(uint64_t total, uint32_t sigma, hipStream_t stream)
 // d_l / d_out_off: SA interval starts and output offsets of the n_pat lists; d_out receives SA values (unsorted, SA order).
 // Scratch (caller-provided): val_a, val_b (u64 each), key_a, key_b (u16 each) for min(total, sweep_batch_max<pos_t>()) elements,
 // temp (sweep_temp_bytes), counter (8 B, zeroed here).
+// The sweep's driver: rounds, partitions, records and the stragglers' slices for ANY index that can launch the three kernels of
+// SweepKernels (kernels.hpp) -- the byte index below, the integer-alphabet index in int_index.hpp.
 template <typename pos_t, bool kWide>
-vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
-                               pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
-                               size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
-                               hipStream_t stream, LaunchTimer* timer, Block* member /* member_blocks(n) super-blocks, or null: no LF step is shared */,
-                               uint32_t n_member_lists /* the first so many lists are pairwise disjoint and ascend: they make up `member` */,
-                               uint64_t* rec /* total words */,
-                               const std::function<vlg_status()>* while_first_step /* host work to do while the first step runs, or null */)
+vlg_status run_locate_sweep(const SweepKernels& K, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
+                            pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
+                            size_t temp_bytes, unsigned long long* d_counter, uint64_t tail_threshold,
+                            hipStream_t stream, LaunchTimer* timer, Block* member /* member_blocks(n) super-blocks, or null: no LF step is shared */,
+                            uint32_t n_member_lists /* the first so many lists are pairwise disjoint and ascend: they make up `member` */,
+                            uint64_t* rec /* total words */,
+                            const std::function<vlg_status()>* while_first_step /* host work to do while the first step runs, or null */)
 {
     bool hook_due = while_first_step != nullptr;
     constexpr uint32_t kShift = kWide ? 33 : 32;
-    if (iv.n > (1ull << kShift)) return fail(VLG_E_UNSUPPORTED, "sorted sweep: text too long for the packed position");
-    if (iv.sample_bytes != (kWide ? 8u : 4u)) return fail(VLG_E_INTERNAL, "sorted sweep: sample width does not match the instantiation");
-    if (sizeof(pos_t) == 4 && iv.n > (1ull << 32) + 1) return fail(VLG_E_INTERNAL, "sorted sweep: positions do not fit 32 bits");
-    const bool rrr = iv.bv_kind == kBvRrr63, text_order = iv.sampling == kSamplingTextOrder;
-    if (iv.dens == 1 && !text_order && total) {                  // every SA index is sampled: no walk, no trails, no records
-        using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
-        if (timer) timer->begin(0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_dense_copy_kernel<pos_t, sample_t>), dim3(grid_for((total + 7) / 8, 32768)), dim3(256), 0, stream,
-                           reinterpret_cast<const sample_t*>(iv.samples), d_l, d_out_off, n_pat, total, d_out);
-        if (timer) timer->end(0);
-        VLG_HIP_TRY(hipGetLastError());
-        if (hook_due) { hook_due = false; if (vlg_status hs = (*while_first_step)()) return hs; }
-        return VLG_OK;
-    }
-    const unsigned bits = bit_width64(iv.sigma);            // keys 0..sigma (sigma = finished, sorts last)
+    if (K.n > (1ull << kShift)) return fail(VLG_E_UNSUPPORTED, "sorted sweep: text too long for the packed position");
+    if (sizeof(pos_t) == 4 && K.n > (1ull << 32) + 1) return fail(VLG_E_INTERNAL, "sorted sweep: positions do not fit 32 bits");
+    if (K.sigma >= 0xFFFFu) return fail(VLG_E_INTERNAL, "sorted sweep: alphabet too large for the 16-bit partition key");
+    const unsigned bits = bit_width64(K.sigma);             // keys 0..sigma (sigma = finished, sorts last)
     const uint64_t batch_max = sweep_batch_max<kWide>();
     if (member) {
         if (total > 0xFFFFFF00ull) return fail(VLG_E_INTERNAL, "member bit-vector: slots need 32 bits");
         if (timer) timer->begin(0);
-        hipLaunchKernelGGL(member_build_kernel, dim3(grid_for(member_blocks(iv.n), 16384)), dim3(256), 0, stream, d_l, d_out_off, n_member_lists,
-                           member_blocks(iv.n), member);
+        hipLaunchKernelGGL(member_build_kernel, dim3(grid_for(member_blocks(K.n), 16384)), dim3(256), 0, stream, d_l, d_out_off, n_member_lists,
+                           member_blocks(K.n), member);
         if (timer) timer->end(0);
         VLG_HIP_TRY(hipGetLastError());
         // more than one sweep: an element may stop at an element of a LATER sweep, whose record must read "still walking" until then
@@ -1258,7 +1239,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
         const bool fused_first = t1 - t0 > tail_threshold && [] { const char* e = getenv("VLG_NO_FUSED_FIRST_ROUND"); return !(e && e[0] == '1'); }();
         static const bool ahead = [] { const char* e = getenv("VLG_SWEEP_LOOKAHEAD"); return !(e && e[0] == '0'); }();
         if (!fused_first) {
-            if (member) VLG_HIP_TRY(hipMemsetAsync(rec + t0, 0xFF, (t1 - t0) * 8, stream));     // "still walking" (sweep_first_kernel writes it itself)
+            if (member) VLG_HIP_TRY(hipMemsetAsync(rec + t0, 0xFF, (t1 - t0) * 8, stream));     // "still walking" (the first-round kernel writes it itself)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_init_kernel<kShift>), dim3(grid_for((t1 - t0 + 7) / 8, 32768)), dim3(256), 0, stream, d_l, d_out_off, n_pat,
                                t0, t1, val_a);
         }
@@ -1269,17 +1250,8 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
         while (alive > tail_threshold && step < 0xFFFFFFu) {
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
             if (timer) timer->begin(0);
-            const dim3 grid(grid_for(alive, 4096));
-            const bool first = fused_first && step == 0;                       // round 0 makes the elements' words itself (sweep_first_kernel)
-            const dim3 grid_first(grid_for((alive + 7) / 8, 8192));
-#define VLG_STEP(BV, TR, TO) do { if (first && ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, TR>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val_a, key_a, out, d_stats, d_counter, member, rec); \
-                                   else if (first) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, false>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val_a, key_a, out, d_stats, d_counter, member, rec); \
-                                   else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<BV, pos_t, TR, kWide, TO>), grid, dim3(256), 0, stream, iv, val_a, key_a, alive, step, out, d_stats, d_counter, member, rec, t0, ahead && fused_first && step == 1); } while (0)
-#define VLG_STEP_BV(TR, TO) do { if (rrr) VLG_STEP(RrrBV, TR, TO); else VLG_STEP(PlainBV, TR, TO); } while (0)
-            if (text_order) { if (member) VLG_STEP_BV(true, true); else VLG_STEP_BV(false, true); }
-            else { if (member) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false); }
-#undef VLG_STEP_BV
-#undef VLG_STEP
+            if (fused_first && step == 0) K.first(t0, t1, val_a, key_a, out, d_counter, member, rec, ahead);      // round 0 makes the elements' words itself
+            else K.step(val_a, key_a, alive, step, out, d_counter, member, rec, t0, ahead && fused_first && step == 1);
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
             size_t tb = temp_bytes;
@@ -1306,12 +1278,8 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
             uint64_t per_wave = (alive + target_waves - 1) / target_waves;
             per_wave = std::min<uint64_t>(std::max<uint64_t>(per_wave, 64 * 16), 1u << 20);
             const uint64_t waves = (alive + per_wave - 1) / per_wave;
-            const dim3 grid((uint32_t)((waves + 3) / 4));
             if (timer) timer->begin(0);
-#define VLG_TAIL(BV, TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, BV, true, kWide, TO>), grid, dim3(256), 0, stream, iv, out, alive, (uint32_t)per_wave, d_stats, val_a, step, member ? rec : nullptr, t0, member)
-            if (text_order) { if (rrr) VLG_TAIL(RrrBV, true); else VLG_TAIL(PlainBV, true); }
-            else { if (rrr) VLG_TAIL(RrrBV, false); else VLG_TAIL(PlainBV, false); }
-#undef VLG_TAIL
+            K.tail(out, alive, (uint32_t)per_wave, val_a, step, member ? rec : nullptr, t0, member, (uint32_t)((waves + 3) / 4));
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
         }
@@ -1341,6 +1309,65 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
         }
     }
     return VLG_OK;
+}
+template vlg_status run_locate_sweep<uint32_t, false>(const SweepKernels&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, uint32_t*, uint64_t*, uint64_t*,
+                                                      uint16_t*, uint16_t*, void*, size_t, unsigned long long*, uint64_t, hipStream_t, LaunchTimer*, Block*,
+                                                      uint32_t, uint64_t*, const std::function<vlg_status()>*);
+
+// the byte index (IndexView: Huffman-shaped tree, plain or rrr bit-vectors, either sampling) in the sweep
+template <typename pos_t, bool kWide>
+vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
+                               pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
+                               size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
+                               hipStream_t stream, LaunchTimer* timer, Block* member, uint32_t n_member_lists, uint64_t* rec,
+                               const std::function<vlg_status()>* while_first_step)
+{
+    if (iv.sample_bytes != (kWide ? 8u : 4u)) return fail(VLG_E_INTERNAL, "sorted sweep: sample width does not match the instantiation");
+    const bool rrr = iv.bv_kind == kBvRrr63, text_order = iv.sampling == kSamplingTextOrder;
+    if (iv.dens == 1 && !text_order && total) {                  // every SA index is sampled: no walk, no trails, no records
+        using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
+        if (timer) timer->begin(0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sa_dense_copy_kernel<pos_t, sample_t>), dim3(grid_for((total + 7) / 8, 32768)), dim3(256), 0, stream,
+                           reinterpret_cast<const sample_t*>(iv.samples), d_l, d_out_off, n_pat, total, d_out);
+        if (timer) timer->end(0);
+        VLG_HIP_TRY(hipGetLastError());
+        if (while_first_step) if (vlg_status hs = (*while_first_step)()) return hs;
+        return VLG_OK;
+    }
+    SweepKernels K;
+    K.n = iv.n;
+    K.sigma = iv.sigma;
+    K.first = [&](uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out_, unsigned long long* counter, const Block* mem, uint64_t* rc, bool ahead) {
+        pos_t* out = static_cast<pos_t*>(out_);
+        const dim3 grid_first(grid_for((t1 - t0 + 7) / 8, 8192));
+#define VLG_FIRST(BV, TR, TO) do { if (ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, TR>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val, key, out, d_stats, counter, mem, rc); \
+                                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, false>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val, key, out, d_stats, counter, mem, rc); } while (0)
+#define VLG_FIRST_BV(TR, TO) do { if (rrr) VLG_FIRST(RrrBV, TR, TO); else VLG_FIRST(PlainBV, TR, TO); } while (0)
+        if (text_order) { if (mem) VLG_FIRST_BV(true, true); else VLG_FIRST_BV(false, true); }
+        else { if (mem) VLG_FIRST_BV(true, false); else VLG_FIRST_BV(false, false); }
+#undef VLG_FIRST_BV
+#undef VLG_FIRST
+    };
+    K.step = [&](uint64_t* val, uint16_t* key, uint64_t alive, uint32_t step, void* out_, unsigned long long* counter, const Block* mem, uint64_t* rc, uint64_t t0, bool probed) {
+        pos_t* out = static_cast<pos_t*>(out_);
+        const dim3 grid(grid_for(alive, 4096));
+#define VLG_STEP(BV, TR, TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_step_kernel<BV, pos_t, TR, kWide, TO>), grid, dim3(256), 0, stream, iv, val, key, alive, step, out, d_stats, counter, mem, rc, t0, probed)
+#define VLG_STEP_BV(TR, TO) do { if (rrr) VLG_STEP(RrrBV, TR, TO); else VLG_STEP(PlainBV, TR, TO); } while (0)
+        if (text_order) { if (mem) VLG_STEP_BV(true, true); else VLG_STEP_BV(false, true); }
+        else { if (mem) VLG_STEP_BV(true, false); else VLG_STEP_BV(false, false); }
+#undef VLG_STEP_BV
+#undef VLG_STEP
+    };
+    K.tail = [&](void* out_, uint64_t alive, uint32_t per_wave, const uint64_t* val, uint32_t step, uint64_t* rc, uint64_t t0, const Block* mem, uint32_t blocks) {
+        pos_t* out = static_cast<pos_t*>(out_);
+        const dim3 grid(blocks);
+#define VLG_TAIL(BV, TO) hipLaunchKernelGGL(HIP_KERNEL_NAME(locate_kernel<pos_t, BV, true, kWide, TO>), grid, dim3(256), 0, stream, iv, out, alive, per_wave, d_stats, val, step, rc, t0, mem)
+        if (text_order) { if (rrr) VLG_TAIL(RrrBV, true); else VLG_TAIL(PlainBV, true); }
+        else { if (rrr) VLG_TAIL(RrrBV, false); else VLG_TAIL(PlainBV, false); }
+#undef VLG_TAIL
+    };
+    return run_locate_sweep<pos_t, kWide>(K, d_l, d_out_off, n_pat, total, d_out, val_a, val_b, key_a, key_b, temp, temp_bytes, d_counter, tail_threshold, stream, timer,
+                                          member, n_member_lists, rec, while_first_step);
 }
 // K3u (above): the whole suffix array into sa_full (n words of 32 bits), then the SA intervals of the lists into d_out.
 // val / key buffers for n_samples walkers; temp as for the sweep.  Rounds are enqueued kUnsampleSync at a time: the count of walkers

@@ -31,6 +31,25 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
                                hipStream_t stream, LaunchTimer* timer, Block* member, uint32_t n_member_lists, uint64_t* rec,
                                const std::function<vlg_status()>* while_first_step = nullptr);
+// The three launches of a sorted sweep over some index; run_locate_sweep owns the rounds, the partitions, the member bit-vector, the
+// records and their resolution.  `out` is the sweep's slice of the position array (pos_t*), `rec` null when no LF step is shared.
+struct SweepKernels {
+    uint64_t n = 0;
+    uint32_t sigma = 0;                  // partition keys are the symbols 0 .. sigma - 1 (16 bits at most); sigma = finished
+    // round 0 of the elements [t0, t1): their words follow from their places (lists l / out_off are the launcher's business)
+    std::function<void(uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out, unsigned long long* n_done, const Block* member, uint64_t* rec, bool ahead)> first;
+    // one round of the elements val / key [0, alive)
+    std::function<void(uint64_t* val, uint16_t* key, uint64_t alive, uint32_t step, void* out, unsigned long long* n_done, const Block* member, uint64_t* rec, uint64_t t0,
+                       bool probed)> step;
+    // the stragglers, unsorted: a wave owns per_wave elements of val
+    std::function<void(void* out, uint64_t alive, uint32_t per_wave, const uint64_t* val, uint32_t step, uint64_t* rec_or_null, uint64_t t0, const Block* member,
+                       uint32_t blocks)> tail;
+};
+template <typename pos_t, bool kWide>
+vlg_status run_locate_sweep(const SweepKernels& K, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
+                            pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
+                            size_t temp_bytes, unsigned long long* d_counter, uint64_t tail_threshold, hipStream_t stream, LaunchTimer* timer,
+                            Block* member, uint32_t n_member_lists, uint64_t* rec, const std::function<vlg_status()>* while_first_step = nullptr);
 // super-blocks of the member bit-vector over the SA indices of a text of n - 1 characters (kernels.hip: sweep_element)
 inline uint64_t member_blocks(uint64_t n) { return n / kBlockBits + 1; }
 // K3u: the whole suffix array reconstructed from the samples (one LF walker per sample, n LF steps in all) into sa_full (n x 4 B),
@@ -48,5 +67,11 @@ template <typename T> vlg_status launch_widen(const T* d_in, uint64_t* d_out, ui
 vlg_status launch_int_backward_search(const IntView& v, const uint8_t* d_blob, const uint64_t* d_off, uint64_t n_pat, uint64_t* d_l, uint64_t* d_r,
                                       unsigned long long* d_stat_levels, hipStream_t st);
 vlg_status launch_int_locate(const IntView& v, uint32_t* d_io, uint64_t total, unsigned long long* d_stats, hipStream_t st);
+vlg_status launch_int_locate_sweep(const IntView& v, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total, uint32_t* d_out,
+                                   uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp, size_t temp_bytes, unsigned long long* d_counter,
+                                   unsigned long long* d_stats, uint64_t tail_threshold, hipStream_t stream, LaunchTimer* timer, Block* member,
+                                   uint32_t n_member_lists, uint64_t* rec, const std::function<vlg_status()>* while_first_step = nullptr);
+// can this index's occurrences be located by the sorted sweep at all (the byte index always; the integer index with a 16-bit key)
+inline bool int_sweep_possible(const IntView& v) { return v.sigma < 0xFFFFu && v.n_levels >= 1 && v.n <= (1ull << 32); }
 
 }  // namespace vlg

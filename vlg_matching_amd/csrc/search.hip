@@ -860,7 +860,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     for (uint32_t i = 0; i <= nd; ++i) { off64[i] = goff64[sl + i] - goff64[sl]; off32[i] = (uint32_t)off64[i]; }
     for (uint32_t i = 0; i < nd; ++i) lh[i] = pl.dl[dlist[sl + i]];
     const uint64_t acc = off64[nd];
-    const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (wide ? 33 : 32)) && !idx->is_int;
+    const bool use_sweep = ws->sweep && acc >= ws->sweep_min && idx->hdr.n <= (1ull << (wide ? 33 : 32)) && (!idx->is_int || (int_sweep_possible(idx->iview) && sizeof(pos_t) == 4 && !wide));
     // K3u: the whole suffix array from the samples, inside the sweep's scratch (n x 4 B + 20 B per sample <= 20 B per occurrence)
     const uint64_t n_walkers = idx->is_int ? 0 : idx->view.n_samples;
     const bool use_unsample = allow_unsample && use_sweep && sizeof(pos_t) == 4 && unsample_applies(idx, ws, acc) &&
@@ -931,7 +931,12 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
         SweepTimer timer(ws);
         bt.mark("  physical: tables + sort plan");
         vlg_status s = VLG_OK;
-        if (wide)
+        if (idx->is_int) {
+            if constexpr (sizeof(pos_t) == 4)
+                s = launch_int_locate_sweep(idx->iview, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b, d_tmp, sort_tmp, d_counter, d_stats, ws->sweep_tail, st,
+                                            &timer, member, n_member_lists, rec, &plan_sort);
+            else s = fail(VLG_E_INTERNAL, "integer-alphabet index with 64-bit positions");
+        } else if (wide)
             s = launch_locate_sweep<pos_t, true>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b, d_tmp, sort_tmp, d_counter, d_stats,
                                                  ws->sweep_tail, st, &timer, member, n_member_lists, rec, &plan_sort);
         else if constexpr (sizeof(pos_t) == 4)                      // (a 64-bit position type always comes with wide indices)
@@ -1699,12 +1704,12 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
                 VLG_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, np, np, (unsigned)phys, (unsigned)dlist.size(), nu, nu, 0,
                                                                pos_bits, ws->stream));
             }
-            if (ws->sweep && phys >= ws->sweep_min && !idx->is_int)
+            if (ws->sweep && phys >= ws->sweep_min && (!idx->is_int || int_sweep_possible(idx->iview)))
                 sort_tmp = std::max(sort_tmp, sweep_temp_bytes(phys, idx->hdr.sigma, ws->stream));
             memcpy(ws->tmp_key, tmp_key, sizeof tmp_key);
             ws->tmp_bytes = sort_tmp;
         }
-        const bool will_sweep = ws->sweep && phys >= ws->sweep_min && !idx->is_int;
+        const bool will_sweep = ws->sweep && phys >= ws->sweep_min && (!idx->is_int || int_sweep_possible(idx->iview));
         // per query: the largest join, and how many pivot elements the window filter will search from (for the ladder, below)
         uint64_t logical_max_query = 0, pivot_elems = 0;
         {
