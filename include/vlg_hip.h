@@ -125,10 +125,13 @@ vlg_status vlg_index_export_parts(const vlg_index* idx, vlg_index_parts* sizes, 
  * offset numbers the blocks of a class by halves (csrc/rrr_code.hpp) instead of bit by bit, so that a rank decodes in a fixed
  * short sequence of table lookups.  The device image is this library's own (blob magic "VGLB2"); a stock
  * csa_wt<wt_huff<rrr_vector<63>>> file is read by vlg_index_load_sdsl_kind, which decodes its blocks and ends here.  `src` must be
- * a plain index. */
+ * a plain index.  An integer-alphabet index (vlg_index_build_int) is compressed the same way, level by level of its wavelet matrix:
+ * csa_wt<wt_int<rrr_vector<63>>, ., ., ., ., int_alphabet<>> (test/csa_int_test.cpp:32); vlg_index_info then says
+ * VLG_BV_INT_MATRIX_RRR63. */
 #define VLG_BV_PLAIN 0
 #define VLG_BV_RRR63 1
 #define VLG_BV_INT_MATRIX 2          /* integer-alphabet index (vlg_index_build_int): bv_kind of vlg_index_info */
+#define VLG_BV_INT_MATRIX_RRR63 3    /* ... with rrr-63 levels (vlg_index_compress of one) */
 vlg_status vlg_index_compress(const vlg_index* src, int bv_kind, vlg_index** out);
 /* The other SA sampling strategy of the reference, and other densities: a second index over the same BWT whose SA samples are
  *   VLG_SAMPLING_SA_ORDER    SA[0], SA[d], SA[2d], ...                   sa_order_sa_sampling, csa_wt's default

@@ -1459,6 +1459,79 @@ def test_integer_alphabet_fm_index(torch_cuda, V, oracle, name):
     assert (r3.counts == res.counts).all() and r3.summary["checksum"] == res.summary["checksum"]
 
 
+@pytest.mark.parametrize("name", ["survey", "sparse", "words", "one", "run", "keeper"])
+def test_integer_alphabet_rrr_index(torch_cuda, V, oracle, name):
+    """csa_wt<wt_int<rrr_vector<63>>, ., ., ., ., int_alphabet<>> (test/csa_int_test.cpp:32): vlg_index_compress of an integer index
+    re-encodes every level of the wavelet matrix as rrr-63 (the byte index's encoder and rank, K6).  Same alphabet, wt_int::rank,
+    csa[i], intervals, tuples and LF steps as the plain index and the restated reference structure; the image travels; on a skewed
+    word-level text it is smaller."""
+    torch = torch_cuda
+    from vlg_matching_amd.index import Workspace
+    text = _int_texts()[name]
+    o = oracle.IntIndex(text.astype(np.uint64), dens=32)
+    plain = V.VlgIndex.build_int(text)
+    idx = plain.compress()
+    info = idx.info()
+    assert info["n"] == len(text) + 1 and info["bv_kind"] == 3 and info["pos_bytes"] == 4
+    Cc, c2c = idx.int_alphabet()
+    assert Cc.tolist() == o.C().tolist() and c2c.tolist() == o.comp2char().tolist()
+    rng = np.random.default_rng(13)
+    L = V.lib()
+    m = 600
+    syms = np.concatenate([rng.choice(text, m - 6), np.array([1, 2, 4, 123456, 2 ** 32 - 1, int(text[0])], dtype=np.uint32)]).astype(np.uint32)
+    pos = np.concatenate([rng.integers(0, o.n + 1, m - 2), [0, o.n]]).astype(np.uint64)
+    d_p, d_s = dev_u64(torch, pos), torch.from_numpy(syms.view(np.int32)).cuda()
+    d_o = torch.zeros(m, dtype=torch.int64, device="cuda")
+    V.capi.check(L.vlg_int_rank_batch(idx._h, d_p.data_ptr(), d_s.data_ptr(), d_o.data_ptr(), m, None))
+    torch.cuda.synchronize()
+    assert host_u64(d_o).tolist() == [o.rank(int(i), int(c)) for i, c in zip(pos, syms)]
+    d_i = dev_u64(torch, np.arange(o.n, dtype=np.uint64))
+    d_v, d_w = torch.zeros_like(d_i), torch.zeros_like(d_i)
+    V.capi.check(L.vlg_sa_batch(idx._h, d_i.data_ptr(), d_v.data_ptr(), o.n, None))
+    V.capi.check(L.vlg_sa_batch(plain._h, d_i.data_ptr(), d_w.data_ptr(), o.n, None))
+    torch.cuda.synchronize()
+    assert (host_u64(d_v) == host_u64(d_w)).all() and sorted(host_u64(d_v).tolist()) == list(range(o.n))
+    qs = _int_queries(text, rng, 100) + ["%d .{0,5}? 999999" % int(text[0]), "999999", "%d" % int(text[-1])]
+    l, r, _ = idx.intervals(qs)
+    lp, rp, _ = plain.intervals(qs)
+    assert l.tolist() == lp.tolist() and r.tolist() == rp.tolist()
+    want = [o.search(qq).tolist() for qq in qs]
+    res = idx.search(qs)
+    for i in range(len(qs)):
+        assert res.tuples(i).tolist() == want[i], qs[i]
+    st0 = np.zeros(4, dtype=np.uint64)
+    for qq in qs:
+        o.search(qq, stats=st0)
+    for opts in ({"sweep_min": 1, "sweep_tail": 16}, {"sweep_min": 1, "sweep_tail": 1 << 30}, {"sweep_min": 1, "sweep_tail": 4, "trail": 0},
+                 {"sweep_min": 1, "sweep_tail": 16, "dedup": 0}, {"sweep": 0, "dedup": 0}):
+        wsx = Workspace()
+        for k_, v_ in opts.items():
+            wsx.set_option(k_, v_)
+        rx = idx.search(qs, workspace=wsx)
+        for i in range(len(qs)):
+            assert rx.tuples(i).tolist() == want[i], (qs[i], opts)
+        if opts.get("dedup", 1) == 0:
+            assert rx.summary["located_occurrences"] == int(st0[0]) and rx.summary["lf_steps"] == int(st0[1]), opts
+    blob = torch.empty(idx.blob_bytes(), dtype=torch.uint8, device="cuda")
+    idx.blob_export(blob.data_ptr(), blob.numel())
+    att = V.VlgIndex.attach_blob(blob.data_ptr(), blob.numel(), keep=blob)
+    assert att.info()["bv_kind"] == 3
+    r3 = att.search(qs)
+    assert (r3.counts == res.counts).all() and r3.summary["checksum"] == res.summary["checksum"]
+
+
+def test_integer_alphabet_rrr_index_is_smaller_on_skewed_text(V):
+    """What the compression is for: a word-level text with Zipf frequencies (most of the upper levels' bits are runs)."""
+    rng = np.random.default_rng(5)
+    text = (1 + rng.zipf(1.6, 400000) % 50000).astype(np.uint32)
+    plain = V.VlgIndex.build_int(text, dens=1 << 20)                  # (samples out of the picture)
+    idx = plain.compress()
+    assert idx.blob_bytes() < 0.8 * plain.blob_bytes(), (idx.blob_bytes(), plain.blob_bytes())
+    qs = _int_queries(text, rng, 50)
+    a, b = plain.search(qs), idx.search(qs)
+    assert (a.counts == b.counts).all() and a.summary["checksum"] == b.summary["checksum"] and a.summary["n_matches"] > 0
+
+
 def test_integer_alphabet_64bit_symbols_through_a_symbol_map(V, oracle):
     """gapped_pattern_query<int_alphabet_tag> reads uint64_t tokens (vlg_index.hpp:57-69).  A text whose symbols need more than 32 bits
     goes through vlg_symbol_map (rank + 1 of every symbol: dense, order-preserving), the mapped text into vlg_index_build_int and
@@ -1521,7 +1594,7 @@ def test_integer_alphabet_fm_index_known_answers_and_refusals(V):
     with pytest.raises(V.VlgError):
         V.VlgIndex.build(b"abcabc").search(Queries.from_int(["5 6"]))             # and the other way round
     with pytest.raises(V.VlgError):
-        idx.compress()
+        idx.compress().compress()                                                 # the source must be a plain index
     with pytest.raises(V.VlgError):
         idx.export_parts()
 

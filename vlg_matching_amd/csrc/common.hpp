@@ -89,14 +89,23 @@ struct IndexView {
 
 // ---- FM-index of an integer text (int_index.hpp): its own blob, recognised by its magic -------------------------------------
 constexpr uint64_t kIntBlobMagic = 0x3149474C56ULL;   // "VLGI1"
+constexpr uint32_t kMaxIntLevels = 32;
 struct IntHeader {
     uint64_t magic, total_bytes;                      // (the first two words as in BlobHeader: what export / attach look at)
     uint64_t n, sigma, n_samples, nb;                 // nb = super-blocks per level
     uint32_t levels, dens;
     uint64_t off_levels, off_Z, off_D, off_C, off_c2c, off_samples;
+    // rrr-63 levels (vlg_index_compress of an integer index; all zero in a plain one -- the header is followed by zeros up to 256 bytes,
+    // so blobs written before these fields existed read as plain): the layout of the byte index's rrr variant, one "node" per level
+    uint64_t bv_kind, n_sb /* super-blocks of 32 x 63 bits per level */, rrr_words, off_rrr_hdr, off_rrr_stream, off_binom;
 };
 struct IntView {
-    const Block* levels;                              // [n_levels][nb] wavelet matrix of the BWT over compact symbols
+    const Block* blocks;                              // plain: [n_levels][nb] wavelet matrix of the BWT over compact symbols
+    const uint4* rrr_hdr;                             // rrr-63: [n_levels][n_sb] headers, the offset stream and the block code's tables
+    const uint64_t* rrr_stream;                       //         (the members the bit-vector policies of device_rank.hpp read)
+    const struct RrrTables* rrr_tables;
+    uint64_t stride;                                  // super-blocks per level: nb (plain) or n_sb (rrr)
+    uint32_t bv_kind, pad_;
     const uint64_t* Z;                                // zeros per level
     const uint64_t* D;                                // C[c] - first position of c in the last arrangement
     const uint64_t* C;                                // [sigma + 1]
@@ -210,4 +219,5 @@ struct vlg_index {
 
 namespace vlg {
 vlg_status attach_int_blob(const void* d_blob, uint64_t bytes, vlg_index* idx);   // int_index.hpp
+void layout_int_blob(IntHeader& h);                                               // int_index.hpp: offsets and total_bytes from the sizes
 }

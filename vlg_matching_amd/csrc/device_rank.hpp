@@ -80,11 +80,12 @@ __device__ __forceinline__ bool member_probe(const Block* __restrict__ member, u
 }
 
 // ---- bit-vector policies: how one node-relative (rank1, bit) pair is obtained -----------------------------------
+// (View: IndexView, or the integer index's IntView -- whatever carries `blocks` / `rrr_hdr`, `rrr_stream`, `rrr_tables`)
 // Plain: one 256-bit super-block read (K1).
 struct PlainBV {
     struct Shared {};
-    static __device__ __forceinline__ void stage(Shared&, const IndexView&) {}
-    static __device__ __forceinline__ void rank_bit(const IndexView& iv, const Shared&, uint32_t base, uint64_t i, uint64_t& r1, uint32_t& bit)
+    template <class View> static __device__ __forceinline__ void stage(Shared&, const View&) {}
+    template <class View> static __device__ __forceinline__ void rank_bit(const View& iv, const Shared&, uint32_t base, uint64_t i, uint64_t& r1, uint32_t& bit)
     {
         uint32_t blk, off;
         split224(i, blk, off);
@@ -92,13 +93,13 @@ struct PlainBV {
         r1 = block_rank_bit(r, off, bit);
     }
     // node-relative positions below 2^32 (n <= 2^32): the same in 32-bit arithmetic
-    static __device__ __forceinline__ void rank_bit(const IndexView& iv, const Shared&, uint32_t base, uint32_t i, uint32_t& r1, uint32_t& bit)
+    template <class View> static __device__ __forceinline__ void rank_bit(const View& iv, const Shared&, uint32_t base, uint32_t i, uint32_t& r1, uint32_t& bit)
     {
         const uint32_t blk = (i >> 5) / 7u, off = i - blk * kBlockBits;
         const BlockRegs r = load_block(iv.blocks, base + blk);
         r1 = block_rank_bit(r, off, bit);
     }
-    static __device__ __forceinline__ uint64_t rank(const IndexView& iv, const Shared&, uint32_t base, uint64_t i)
+    template <class View> static __device__ __forceinline__ uint64_t rank(const View& iv, const Shared&, uint32_t base, uint64_t i)
     {
         return node_rank1(iv.blocks, base, i);
     }
@@ -111,15 +112,15 @@ struct RrrBV {
     struct Shared {
         RrrTables t;
     };
-    static __device__ __forceinline__ void stage(Shared& s, const IndexView& iv)
+    template <class View> static __device__ __forceinline__ void stage(Shared& s, const View& iv)
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(iv.rrr_tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&s.t);
         for (uint32_t i = threadIdx.x; i < sizeof(RrrTables) / 4; i += blockDim.x) dst[i] = src[i];
     }
     // ones in the first `want` bits of the addressed block, plus bit number `want` when asked for
-    template <bool kBit>
-    static __device__ __forceinline__ void decode(const IndexView& iv, const Shared& s, uint32_t base, uint64_t i, uint64_t& r1, uint32_t& bit)
+    template <bool kBit, class View>
+    static __device__ __forceinline__ void decode(const View& iv, const Shared& s, uint32_t base, uint64_t i, uint64_t& r1, uint32_t& bit)
     {
         const uint64_t sb = i / kRrrSuperBits;
         const uint32_t r = (uint32_t)(i - sb * kRrrSuperBits);
@@ -157,17 +158,17 @@ struct RrrBV {
         }
         r1 = rank;
     }
-    static __device__ __forceinline__ void rank_bit(const IndexView& iv, const Shared& s, uint32_t base, uint64_t i, uint64_t& r1, uint32_t& bit)
+    template <class View> static __device__ __forceinline__ void rank_bit(const View& iv, const Shared& s, uint32_t base, uint64_t i, uint64_t& r1, uint32_t& bit)
     {
         decode<true>(iv, s, base, i, r1, bit);
     }
-    static __device__ __forceinline__ void rank_bit(const IndexView& iv, const Shared& s, uint32_t base, uint32_t i, uint32_t& r1, uint32_t& bit)
+    template <class View> static __device__ __forceinline__ void rank_bit(const View& iv, const Shared& s, uint32_t base, uint32_t i, uint32_t& r1, uint32_t& bit)
     {
         uint64_t r;
         decode<true>(iv, s, base, i, r, bit);
         r1 = (uint32_t)r;
     }
-    static __device__ __forceinline__ uint64_t rank(const IndexView& iv, const Shared& s, uint32_t base, uint64_t i)
+    template <class View> static __device__ __forceinline__ uint64_t rank(const View& iv, const Shared& s, uint32_t base, uint64_t i)
     {
         uint64_t r1; uint32_t bit;
         decode<false>(iv, s, base, i, r1, bit);

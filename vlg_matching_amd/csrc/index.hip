@@ -5,6 +5,7 @@
 #include <cstring>
 #include <string.h>
 #include "common.hpp"
+#include <functional>
 #include "device_rank.hpp"
 #include "rrr_code.hpp"
 #include <rocprim/rocprim.hpp>
@@ -595,6 +596,107 @@ __global__ void __launch_bounds__(256) rrr_encode_kernel(const Block* __restrict
 
 }  // namespace
 
+namespace {
+
+// The two passes of the re-encoding around whatever allocates the target: pass 1 counts ones and offset words per super-block and scans
+// them, `place` allocates and returns where headers / offsets / the block code's tables go, pass 2 writes them.
+struct RrrTarget { uint4* hdr; uint64_t* stream; void* tables; };
+vlg_status rrr_encode(const Block* blocks, const RrrTable& tab, uint64_t n_sb, hipStream_t stream,
+                      const std::function<vlg_status(uint64_t total_words, RrrTarget& where)>& place)
+{
+    std::vector<uint8_t> code(64 * 64 * 8, 0);                // the block code's tables (the blob keeps 32 KiB for them)
+    build_rrr_tables(*reinterpret_cast<RrrTables*>(code.data()));
+    uint64_t total_words = 0;
+    DevBuf d_tab, d_code, d_ones, d_words, d_tmp;
+    VLG_HIP_TRY(d_tab.alloc(sizeof tab));
+    VLG_HIP_TRY(d_code.alloc(64 * 64 * 8));
+    VLG_HIP_TRY(hipMemcpy(d_tab.p, &tab, sizeof tab, hipMemcpyHostToDevice));
+    VLG_HIP_TRY(hipMemcpy(d_code.p, code.data(), 64 * 64 * 8, hipMemcpyHostToDevice));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_sb + 255) / 256, 4096);
+    if (n_sb) {
+        VLG_HIP_TRY(d_ones.alloc((n_sb + 1) * 8));
+        VLG_HIP_TRY(d_words.alloc((n_sb + 1) * 8));
+        hipLaunchKernelGGL(rrr_encode_kernel, dim3(grid), dim3(256), 0, stream, blocks, d_tab.as<RrrTable>(), n_sb, d_code.as<RrrTables>(),
+                           d_ones.as<uint64_t>(), d_words.as<uint64_t>(), nullptr, nullptr, nullptr, nullptr);
+        VLG_HIP_TRY(hipGetLastError());
+        uint64_t last_words = 0;
+        VLG_HIP_TRY(hipMemcpyAsync(&last_words, d_words.as<uint64_t>() + (n_sb - 1), 8, hipMemcpyDeviceToHost, stream));
+        size_t tb = 0;
+        VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_ones.as<uint64_t>(), d_ones.as<uint64_t>(), (uint64_t)0, n_sb, rocprim::plus<uint64_t>(), stream));
+        VLG_HIP_TRY(d_tmp.alloc(tb));
+        VLG_HIP_TRY(rocprim::exclusive_scan(d_tmp.p, tb, d_ones.as<uint64_t>(), d_ones.as<uint64_t>(), (uint64_t)0, n_sb, rocprim::plus<uint64_t>(), stream));
+        VLG_HIP_TRY(rocprim::exclusive_scan(d_tmp.p, tb, d_words.as<uint64_t>(), d_words.as<uint64_t>(), (uint64_t)0, n_sb, rocprim::plus<uint64_t>(), stream));
+        uint64_t last_off = 0;
+        VLG_HIP_TRY(hipMemcpyAsync(&last_off, d_words.as<uint64_t>() + (n_sb - 1), 8, hipMemcpyDeviceToHost, stream));
+        VLG_HIP_TRY(hipStreamSynchronize(stream));
+        total_words = last_off + last_words;
+        if (total_words > 0xFFFFFFF0ull) return fail(VLG_E_UNSUPPORTED, "rrr offset stream too long");
+    }
+    RrrTarget w{nullptr, nullptr, nullptr};
+    if (vlg_status st = place(total_words, w)) return st;
+    VLG_HIP_TRY(hipMemcpyAsync(w.tables, d_code.p, 64 * 64 * 8, hipMemcpyDeviceToDevice, stream));
+    VLG_HIP_TRY(hipMemsetAsync(w.stream, 0, (total_words + 2) * 8, stream));
+    VLG_HIP_TRY(hipMemsetAsync(w.hdr, 0, std::max<uint64_t>(n_sb, 1) * 32, stream));
+    if (n_sb) {
+        hipLaunchKernelGGL(rrr_encode_kernel, dim3(grid), dim3(256), 0, stream, blocks, d_tab.as<RrrTable>(), n_sb, d_code.as<RrrTables>(),
+                           nullptr, nullptr, d_ones.as<uint64_t>(), d_words.as<uint64_t>(), w.hdr, w.stream);
+        VLG_HIP_TRY(hipGetLastError());
+    }
+    VLG_HIP_TRY(hipStreamSynchronize(stream));
+    return VLG_OK;
+}
+
+// The integer index (int_index.hpp): every level of the wavelet matrix is one bit-vector of n bits = one "node" of the table; the
+// alphabet, Z, D and the samples are copied.  The reference's counterpart: csa_wt<wt_int<rrr_vector<63>>, ., ., ., ., int_alphabet<>>
+// (test/csa_int_test.cpp:32).
+vlg_status compress_int(const vlg_index* src, vlg_index** out)
+{
+    const IntHeader& sh = src->ihdr;
+    if (sh.bv_kind != kBvPlain) return fail(VLG_E_INVALID, "source index must use plain bit-vectors");
+    IntHeader h = sh;
+    h.bv_kind = kBvRrr63;
+    h.n_sb = sh.n / kRrrSuperBits + 1;
+    const uint64_t n_sb = h.n_sb * sh.levels;
+    if (n_sb > 0xFFFFFFF0ull) return fail(VLG_E_UNSUPPORTED, "too many rrr super-blocks");
+    static_assert(kMaxIntLevels <= 256, "one table entry per level");
+    RrrTable tab;
+    memset(&tab, 0, sizeof tab);
+    tab.count = sh.levels;
+    for (uint32_t l = 0; l < sh.levels; ++l) {
+        tab.pbase[l] = (uint32_t)(l * sh.nb);
+        tab.rbase[l] = (uint32_t)(l * h.n_sb);
+        tab.size[l] = sh.n;
+    }
+    void* d_blob = nullptr;
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(src->d_blob);
+    vlg_status st = rrr_encode(src->iview.blocks, tab, n_sb, nullptr, [&](uint64_t total_words, RrrTarget& w) -> vlg_status {
+        h.rrr_words = total_words;
+        layout_int_blob(h);
+        VLG_HIP_TRY(hipMalloc(&d_blob, h.total_bytes));
+        uint8_t* b = reinterpret_cast<uint8_t*>(d_blob);
+        VLG_HIP_TRY(hipMemset(b, 0, h.off_levels));
+        VLG_HIP_TRY(hipMemcpy(b, &h, sizeof h, hipMemcpyHostToDevice));
+        VLG_HIP_TRY(hipMemcpy(b + h.off_Z, sb + sh.off_Z, kMaxIntLevels * 8, hipMemcpyDeviceToDevice));
+        VLG_HIP_TRY(hipMemcpy(b + h.off_D, sb + sh.off_D, sh.sigma * 8, hipMemcpyDeviceToDevice));
+        VLG_HIP_TRY(hipMemcpy(b + h.off_C, sb + sh.off_C, (sh.sigma + 1) * 8, hipMemcpyDeviceToDevice));
+        VLG_HIP_TRY(hipMemcpy(b + h.off_c2c, sb + sh.off_c2c, sh.sigma * 4, hipMemcpyDeviceToDevice));
+        VLG_HIP_TRY(hipMemcpy(b + h.off_samples, sb + sh.off_samples, sh.n_samples * 4, hipMemcpyDeviceToDevice));
+        w.hdr = reinterpret_cast<uint4*>(b + h.off_rrr_hdr);
+        w.stream = reinterpret_cast<uint64_t*>(b + h.off_rrr_stream);
+        w.tables = b + h.off_binom;
+        return VLG_OK;
+    });
+    if (st) { if (d_blob) (void)hipFree(d_blob); return st; }
+    vlg_index* idx = new vlg_index();
+    st = attach_int_blob(d_blob, h.total_bytes, idx);
+    if (st) { (void)hipFree(d_blob); delete idx; return st; }
+    idx->owns_blob = true;
+    *out = idx;
+    return VLG_OK;
+}
+
+}  // namespace
+
 extern "C" vlg_status vlg_index_compress(const vlg_index* src, int kind, vlg_index** out)
 {
     release_cached_device_memory();          // an index wants its memory now; parked result buffers can be allocated again
@@ -602,7 +704,7 @@ extern "C" vlg_status vlg_index_compress(const vlg_index* src, int kind, vlg_ind
     if (!src || !out) return fail(VLG_E_INVALID, "null argument");
     *out = nullptr;
     if (kind != VLG_BV_RRR63) return fail(VLG_E_INVALID, "unknown bit-vector kind");
-    if (src->is_int) return fail(VLG_E_UNSUPPORTED, "integer-alphabet indexes keep plain bit-vectors");
+    if (src->is_int) return compress_int(src, out);
     if (src->hdr.bv_kind != kBvPlain) return fail(VLG_E_INVALID, "source index must use plain bit-vectors");
     if (src->hdr.sampling != kSamplingSaOrder) return fail(VLG_E_INVALID, "compress the SA-order index first, then resample it (vlg_index_resample)");
     vlg_index* idx = new vlg_index();
@@ -622,54 +724,17 @@ extern "C" vlg_status vlg_index_compress(const vlg_index* src, int kind, vlg_ind
         }
     if (n_sb > 0xFFFFFFF0ull) { delete idx; return fail(VLG_E_UNSUPPORTED, "too many rrr super-blocks"); }
     hipStream_t stream = nullptr;
-    auto run = [&]() -> vlg_status {
-        std::vector<uint8_t> code(64 * 64 * 8, 0);                // the block code's tables (the blob keeps 32 KiB for them)
-        build_rrr_tables(*reinterpret_cast<RrrTables*>(code.data()));
-        uint64_t total_words = 0;
-        DevBuf d_tab, d_code, d_ones, d_words, d_tmp;
-        VLG_HIP_TRY(d_tab.alloc(sizeof tab));
-        VLG_HIP_TRY(d_code.alloc(64 * 64 * 8));
-        VLG_HIP_TRY(hipMemcpy(d_tab.p, &tab, sizeof tab, hipMemcpyHostToDevice));
-        VLG_HIP_TRY(hipMemcpy(d_code.p, code.data(), 64 * 64 * 8, hipMemcpyHostToDevice));
-        if (n_sb) {
-            VLG_HIP_TRY(d_ones.alloc((n_sb + 1) * 8));
-            VLG_HIP_TRY(d_words.alloc((n_sb + 1) * 8));
-            const uint32_t grid = (uint32_t)std::min<uint64_t>((n_sb + 255) / 256, 4096);
-            hipLaunchKernelGGL(rrr_encode_kernel, dim3(grid), dim3(256), 0, stream, src->view.blocks, d_tab.as<RrrTable>(), n_sb, d_code.as<RrrTables>(),
-                               d_ones.as<uint64_t>(), d_words.as<uint64_t>(), nullptr, nullptr, nullptr, nullptr);
-            VLG_HIP_TRY(hipGetLastError());
-            uint64_t last_words = 0;
-            VLG_HIP_TRY(hipMemcpyAsync(&last_words, d_words.as<uint64_t>() + (n_sb - 1), 8, hipMemcpyDeviceToHost, stream));
-            size_t tb = 0;
-            VLG_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_ones.as<uint64_t>(), d_ones.as<uint64_t>(), (uint64_t)0, n_sb, rocprim::plus<uint64_t>(), stream));
-            VLG_HIP_TRY(d_tmp.alloc(tb));
-            VLG_HIP_TRY(rocprim::exclusive_scan(d_tmp.p, tb, d_ones.as<uint64_t>(), d_ones.as<uint64_t>(), (uint64_t)0, n_sb, rocprim::plus<uint64_t>(), stream));
-            VLG_HIP_TRY(rocprim::exclusive_scan(d_tmp.p, tb, d_words.as<uint64_t>(), d_words.as<uint64_t>(), (uint64_t)0, n_sb, rocprim::plus<uint64_t>(), stream));
-            uint64_t last_off = 0;
-            VLG_HIP_TRY(hipMemcpyAsync(&last_off, d_words.as<uint64_t>() + (n_sb - 1), 8, hipMemcpyDeviceToHost, stream));
-            VLG_HIP_TRY(hipStreamSynchronize(stream));
-            total_words = last_off + last_words;
-            if (total_words > 0xFFFFFFF0ull) return fail(VLG_E_UNSUPPORTED, "rrr offset stream too long");
-        }
-        if (vlg_status st = alloc_blob(idx, src->hdr.n, src->hdr.dens, stream, std::max<uint64_t>(n_sb, 1), total_words)) return st;
+    vlg_status st = rrr_encode(src->view.blocks, tab, n_sb, stream, [&](uint64_t total_words, RrrTarget& w) -> vlg_status {
+        if (vlg_status s2 = alloc_blob(idx, src->hdr.n, src->hdr.dens, stream, std::max<uint64_t>(n_sb, 1), total_words)) return s2;
         const BlobHeader& h = idx->hdr;
         uint8_t* b = reinterpret_cast<uint8_t*>(idx->d_blob);
         const uint8_t* sb = reinterpret_cast<const uint8_t*>(src->d_blob);
         VLG_HIP_TRY(hipMemcpyAsync(b + h.off_samples, sb + src->hdr.off_samples, h.n_samples * h.sample_bytes, hipMemcpyDeviceToDevice, stream));
-        VLG_HIP_TRY(hipMemcpyAsync(b + h.off_binom, d_code.p, 64 * 64 * 8, hipMemcpyDeviceToDevice, stream));
-        VLG_HIP_TRY(hipMemsetAsync(b + h.off_rrr_stream, 0, (total_words + 2) * 8, stream));
-        VLG_HIP_TRY(hipMemsetAsync(b + h.off_rrr_hdr, 0, std::max<uint64_t>(n_sb, 1) * 32, stream));
-        if (n_sb) {
-            const uint32_t grid = (uint32_t)std::min<uint64_t>((n_sb + 255) / 256, 4096);
-            hipLaunchKernelGGL(rrr_encode_kernel, dim3(grid), dim3(256), 0, stream, src->view.blocks, d_tab.as<RrrTable>(), n_sb, d_code.as<RrrTables>(),
-                               nullptr, nullptr, d_ones.as<uint64_t>(), d_words.as<uint64_t>(), reinterpret_cast<uint4*>(b + h.off_rrr_hdr),
-                               reinterpret_cast<uint64_t*>(b + h.off_rrr_stream));
-            VLG_HIP_TRY(hipGetLastError());
-        }
-        VLG_HIP_TRY(hipStreamSynchronize(stream));
+        w.hdr = reinterpret_cast<uint4*>(b + h.off_rrr_hdr);
+        w.stream = reinterpret_cast<uint64_t*>(b + h.off_rrr_stream);
+        w.tables = b + h.off_binom;
         return VLG_OK;
-    };
-    vlg_status st = run();
+    });
     if (st) { vlg_index_destroy(idx); return st; }
     *out = idx;
     return VLG_OK;

@@ -22,14 +22,17 @@
 
 namespace {
 
-constexpr uint32_t kMaxIntLevels = 32;
-
 void bind_int_view(vlg_index* idx)
 {
     const uint8_t* b = reinterpret_cast<const uint8_t*>(idx->d_blob);
     const IntHeader& h = idx->ihdr;
     IntView& v = idx->iview;
-    v.levels = reinterpret_cast<const Block*>(b + h.off_levels);
+    v.bv_kind = (uint32_t)h.bv_kind; v.pad_ = 0;
+    v.blocks = h.bv_kind == kBvPlain ? reinterpret_cast<const Block*>(b + h.off_levels) : nullptr;
+    v.rrr_hdr = h.bv_kind == kBvRrr63 ? reinterpret_cast<const uint4*>(b + h.off_rrr_hdr) : nullptr;
+    v.rrr_stream = h.bv_kind == kBvRrr63 ? reinterpret_cast<const uint64_t*>(b + h.off_rrr_stream) : nullptr;
+    v.rrr_tables = h.bv_kind == kBvRrr63 ? reinterpret_cast<const RrrTables*>(b + h.off_binom) : nullptr;
+    v.stride = h.bv_kind == kBvRrr63 ? h.n_sb : h.nb;
     v.Z = reinterpret_cast<const uint64_t*>(b + h.off_Z);
     v.D = reinterpret_cast<const uint64_t*>(b + h.off_D);
     v.C = reinterpret_cast<const uint64_t*>(b + h.off_C);
@@ -40,7 +43,8 @@ void bind_int_view(vlg_index* idx)
     BlobHeader& g = idx->hdr;
     memset(&g, 0, sizeof g);
     g.magic = kIntBlobMagic; g.total_bytes = h.total_bytes; g.n = h.n; g.sigma = (uint32_t)std::min<uint64_t>(h.sigma, 0xFFFFFFFFull);
-    g.dens = h.dens; g.n_samples = h.n_samples; g.sample_bytes = 4; g.bv_kind = VLG_BV_INT_MATRIX; g.n_blocks = h.nb * h.levels;
+    g.dens = h.dens; g.n_samples = h.n_samples; g.sample_bytes = 4; g.bv_kind = h.bv_kind == kBvRrr63 ? VLG_BV_INT_MATRIX_RRR63 : VLG_BV_INT_MATRIX;
+    g.n_blocks = (h.bv_kind == kBvRrr63 ? h.n_sb : h.nb) * h.levels; g.n_rrr_sb = h.n_sb * h.levels; g.rrr_stream_words = h.rrr_words;
     g.max_code_len = h.levels; g.wt_bits = h.n * h.levels;
     idx->is_int = true;
 }
@@ -53,25 +57,41 @@ __device__ __forceinline__ uint32_t int_char2comp(const IntView& v, uint32_t sym
     return lo < v.sigma && v.comp2char[lo] == sym ? (uint32_t)lo : 0u;
 }
 
+// what every workgroup that walks the matrix keeps in LDS: the zeros per level and whatever the bit-vector policy needs (BV: PlainBV or
+// RrrBV of device_rank.hpp, reading the IntView as they read the byte index's IndexView; level l is "node" l * stride)
+template <class BV>
+struct IntLds {
+    uint64_t Z[kMaxIntLevels];
+    typename BV::Shared sh;
+};
+template <class BV>
+__device__ __forceinline__ void stage_int(IntLds<BV>& s, const IntView& v)
+{
+    if (threadIdx.x < v.n_levels) s.Z[threadIdx.x] = v.Z[threadIdx.x];
+    BV::stage(s.sh, v);
+    __syncthreads();
+}
+
 // position of (the first i symbols' share of) symbol c in the last arrangement: D[c] + this = C[c] + rank_c(i)
-__device__ __forceinline__ uint64_t int_walk(const IntView& v, const uint64_t* __restrict__ Z, uint64_t p, uint32_t c, uint32_t& levels)
+template <class BV>
+__device__ __forceinline__ uint64_t int_walk(const IntView& v, const IntLds<BV>& s, uint64_t p, uint32_t c, uint32_t& levels)
 {
     for (uint32_t l = 0; l < v.n_levels; ++l) {
-        const uint64_t r1 = node_rank1(v.levels, (uint32_t)(l * v.nb), p);
+        const uint64_t r1 = BV::rank(v, s.sh, (uint32_t)(l * v.stride), p);
         ++levels;
-        p = ((c >> (v.n_levels - 1 - l)) & 1) ? Z[l] + r1 : p - r1;
+        p = ((c >> (v.n_levels - 1 - l)) & 1) ? s.Z[l] + r1 : p - r1;
     }
     return p;
 }
 
 // backward_search (suffix_array_algorithm.hpp:250-278, 305-326), one lane per sub-pattern; symbols are the raw uint32_t of the query
+template <class BV>
 __global__ void __launch_bounds__(256) int_backward_search_kernel(IntView v, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off, uint64_t n_pat,
                                                                   uint64_t* __restrict__ out_l, uint64_t* __restrict__ out_r,
                                                                   unsigned long long* __restrict__ stat_levels)
 {
-    __shared__ uint64_t sZ[kMaxIntLevels];
-    if (threadIdx.x < v.n_levels) sZ[threadIdx.x] = v.Z[threadIdx.x];
-    __syncthreads();
+    __shared__ IntLds<BV> sZ;
+    stage_int(sZ, v);
     uint32_t levels = 0;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pat; p += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t* pat = reinterpret_cast<const uint32_t*>(blob + off[p]);
@@ -100,12 +120,12 @@ __global__ void __launch_bounds__(256) int_backward_search_kernel(IntView v, con
 }
 
 // csa[i] (csa_wt.hpp:335-348) for the SA indices in io[], in place; the lanes of a wave refill from the wave's slice like K3's
+template <class BV>
 __global__ void __launch_bounds__(256) int_locate_kernel(IntView v, uint32_t* __restrict__ io, uint64_t total, uint32_t per_wave,
                                                          unsigned long long* __restrict__ stats)
 {
-    __shared__ uint64_t sZ[kMaxIntLevels];
-    if (threadIdx.x < v.n_levels) sZ[threadIdx.x] = v.Z[threadIdx.x];
-    __syncthreads();
+    __shared__ IntLds<BV> sZ;
+    stage_int(sZ, v);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint64_t next = wave * per_wave;
@@ -136,13 +156,11 @@ __global__ void __launch_bounds__(256) int_locate_kernel(IntView v, uint32_t* __
             } else if (v.n_levels == 0) {                            // only the sentinel exists
                 i = 0; ++off;
             } else {
-                uint32_t blk, o;
-                split224(i, blk, o);
-                const BlockRegs r = load_block(v.levels, (uint32_t)(lvl * v.nb) + blk);
                 uint32_t bit;
-                const uint64_t r1 = block_rank_bit(r, o, bit);
+                uint64_t r1;
+                BV::rank_bit(v, sZ.sh, (uint32_t)(lvl * v.stride), i, r1, bit);
                 ++n_lv;
-                i = bit ? sZ[lvl] + r1 : i - r1;
+                i = bit ? sZ.Z[lvl] + r1 : i - r1;
                 c = (c << 1) | bit;
                 if (++lvl == v.n_levels) { i = v.D[c] + i; lvl = 0; c = 0; ++off; ++n_lf; }      // LF: suffix_array_helper.hpp:341-348
             }
@@ -158,17 +176,17 @@ __global__ void __launch_bounds__(256) int_locate_kernel(IntView v, uint32_t* __
 // ---- the sorted sweep on the wavelet matrix (round 4; kernels.hip: K3s explains the sweep, sweep_element the records) ---------------
 // An LF step reads one super-block per matrix level and the symbol's D entry; the symbol read (its compact number, < sigma <= 65534) is
 // the partition key.  Everything else -- rounds, partition, member bit-vector, records, resolution -- is run_locate_sweep's.
-__device__ __forceinline__ uint64_t int_lf(const IntView& v, const uint64_t* __restrict__ sZ, uint64_t i, uint32_t& c, uint32_t& n_lv)
+template <class BV>
+__device__ __forceinline__ uint64_t int_lf(const IntView& v, const IntLds<BV>& sZ, uint64_t i, uint32_t& c, uint32_t& n_lv)
 {
     uint64_t p = i;
     c = 0;
     for (uint32_t l = 0; l < v.n_levels; ++l) {
-        uint32_t blk, o, bit;
-        split224(p, blk, o);
-        const BlockRegs r = load_block(v.levels, (uint32_t)(l * v.nb) + blk);
-        const uint64_t r1 = block_rank_bit(r, o, bit);
+        uint32_t bit;
+        uint64_t r1;
+        BV::rank_bit(v, sZ.sh, (uint32_t)(l * v.stride), p, r1, bit);
         ++n_lv;
-        p = bit ? sZ[l] + r1 : p - r1;
+        p = bit ? sZ.Z[l] + r1 : p - r1;
         c = (c << 1) | bit;
     }
     return v.D[c] + p;                                               // LF: suffix_array_helper.hpp:341-348
@@ -181,8 +199,8 @@ __device__ __forceinline__ void int_counters_add(unsigned long long a, unsigned 
     if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&stats[0], a); if (b) atomicAdd(&stats[1], b); if (c && n_done) atomicAdd(n_done, c); }
 }
 
-template <bool kTrail, bool kFirst, bool kAhead>
-__device__ __forceinline__ void int_sweep_element(const IntView& v, const uint64_t* __restrict__ sZ, uint64_t e, uint64_t v64, uint64_t* __restrict__ val,
+template <class BV, bool kTrail, bool kFirst, bool kAhead>
+__device__ __forceinline__ void int_sweep_element(const IntView& v, const IntLds<BV>& sZ, uint64_t e, uint64_t v64, uint64_t* __restrict__ val,
                                                   uint16_t* __restrict__ key, uint32_t step, uint32_t* __restrict__ out, const Block* __restrict__ member,
                                                   uint64_t* __restrict__ rec, uint64_t slot0, bool probed, uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin)
 {
@@ -220,30 +238,29 @@ __device__ __forceinline__ void int_sweep_element(const IntView& v, const uint64
     }
 }
 
-template <bool kTrail>
+template <class BV, bool kTrail>
 __global__ void __launch_bounds__(256) int_sweep_step_kernel(IntView v, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count, uint32_t step,
                                                              uint32_t* __restrict__ out, unsigned long long* __restrict__ stats, unsigned long long* __restrict__ n_done,
                                                              const Block* __restrict__ member, uint64_t* __restrict__ rec, uint64_t slot0, bool probed)
 {
-    __shared__ uint64_t sZ[kMaxIntLevels];
-    if (threadIdx.x < v.n_levels) sZ[threadIdx.x] = v.Z[threadIdx.x];
-    __syncthreads();
+    __shared__ IntLds<BV> sZ;
+    stage_int(sZ, v);
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x)
-        int_sweep_element<kTrail, false, false>(v, sZ, e, val[e], val, key, step, out, member, rec, slot0, probed, n_lv, n_lf, n_fin);
+        int_sweep_element<BV, kTrail, false, false>(v, sZ, e, val[e], val, key, step, out, member, rec, slot0, probed, n_lv, n_lf, n_fin);
     int_counters_add(n_lf, n_lv, n_fin, stats, n_done);
 }
 
-template <bool kTrail, bool kAhead>
+template <class BV, bool kTrail, bool kAhead>
 __global__ void __launch_bounds__(256) int_sweep_first_kernel(IntView v, const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t t0,
                                                               uint64_t total, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint32_t* __restrict__ out,
                                                               unsigned long long* __restrict__ stats, unsigned long long* __restrict__ n_done,
                                                               const Block* __restrict__ member, uint64_t* __restrict__ rec)
 {
     constexpr uint32_t kPer = 8;
-    __shared__ uint64_t sZ[kMaxIntLevels];
+    __shared__ IntLds<BV> sZ;
     __shared__ uint64_t s_first;
-    if (threadIdx.x < v.n_levels) sZ[threadIdx.x] = v.Z[threadIdx.x];
+    stage_int(sZ, v);
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
     for (uint64_t base = t0 + (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
         __syncthreads();
@@ -260,7 +277,7 @@ __global__ void __launch_bounds__(256) int_sweep_first_kernel(IntView v, const u
             if (t < total) {
                 while (out_off[p + 1] <= t) ++p;
                 const uint64_t v64 = ((t - t0) << 32) | (l[p] + (t - out_off[p]));
-                int_sweep_element<kTrail, true, kAhead>(v, sZ, t - t0, v64, val, key, 0u, out, member, rec, t0, false, n_lv, n_lf, n_fin);
+                int_sweep_element<BV, kTrail, true, kAhead>(v, sZ, t - t0, v64, val, key, 0u, out, member, rec, t0, false, n_lv, n_lf, n_fin);
             }
         }
     }
@@ -268,13 +285,13 @@ __global__ void __launch_bounds__(256) int_sweep_first_kernel(IntView v, const u
 }
 
 // the stragglers: int_locate_kernel's refilling lanes on the elements val[] = slot << 32 | SA index that have walked `step` steps
+template <class BV>
 __global__ void __launch_bounds__(256) int_sweep_tail_kernel(IntView v, uint32_t* __restrict__ out, uint64_t total, uint32_t per_wave, unsigned long long* __restrict__ stats,
                                                              const uint64_t* __restrict__ val, uint32_t step, uint64_t* __restrict__ rec, uint64_t slot0,
                                                              const Block* __restrict__ member)
 {
-    __shared__ uint64_t sZ[kMaxIntLevels];
-    if (threadIdx.x < v.n_levels) sZ[threadIdx.x] = v.Z[threadIdx.x];
-    __syncthreads();
+    __shared__ IntLds<BV> sZ;
+    stage_int(sZ, v);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint64_t next = wave * per_wave;
@@ -325,12 +342,12 @@ __global__ void __launch_bounds__(256) int_sweep_tail_kernel(IntView v, uint32_t
 }
 
 // wt_int::rank(i, c) on raw symbols (for the primitives test): out = #c in BWT[0, i)
+template <class BV>
 __global__ void __launch_bounds__(256) int_rank_kernel(IntView v, const uint64_t* __restrict__ pos, const uint32_t* __restrict__ sym, uint64_t* __restrict__ out,
                                                        uint64_t count)
 {
-    __shared__ uint64_t sZ[kMaxIntLevels];
-    if (threadIdx.x < v.n_levels) sZ[threadIdx.x] = v.Z[threadIdx.x];
-    __syncthreads();
+    __shared__ IntLds<BV> sZ;
+    stage_int(sZ, v);
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t c = sym[j];
         const uint32_t cc = int_char2comp(v, c);
@@ -375,8 +392,12 @@ __global__ void int_bit_keys_kernel(const uint32_t* __restrict__ vals, uint64_t 
 __global__ void int_D_kernel(IntView v, uint64_t* __restrict__ D)
 {
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < v.sigma; c += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t lv = 0;
-        D[c] = v.C[c] - int_walk(v, v.Z, 0, (uint32_t)c, lv);
+        uint64_t p = 0;                                                // (the index under construction is a plain one)
+        for (uint32_t l = 0; l < v.n_levels; ++l) {
+            const uint64_t r1 = node_rank1(v.blocks, (uint32_t)(l * v.nb), p);
+            p = ((c >> (v.n_levels - 1 - l)) & 1) ? v.Z[l] + r1 : p - r1;
+        }
+        D[c] = v.C[c] - p;
     }
 }
 __global__ void int_samples_kernel(const uint32_t* __restrict__ sa, uint64_t n_samples, uint32_t dens, uint32_t* __restrict__ samples)
@@ -391,7 +412,14 @@ __global__ void int_zero_check_kernel(const uint32_t* __restrict__ text, uint64_
 inline void layout_int(IntHeader& h)
 {
     uint64_t off = align_up(sizeof(IntHeader), 256);
-    h.off_levels = off;  off = align_up(off + (uint64_t)h.levels * h.nb * sizeof(Block), 256);
+    h.off_levels = off;
+    if (h.bv_kind == kBvRrr63) {
+        h.off_rrr_hdr = off;    off = align_up(off + std::max<uint64_t>((uint64_t)h.levels * h.n_sb, 1) * 32, 256);
+        h.off_rrr_stream = off; off = align_up(off + (h.rrr_words + 2) * 8, 256);
+        h.off_binom = off;      off = align_up(off + 64 * 64 * 8, 256);
+    } else {
+        off = align_up(off + (uint64_t)h.levels * h.nb * sizeof(Block), 256);
+    }
     h.off_Z = off;       off = align_up(off + (uint64_t)kMaxIntLevels * 8, 256);
     h.off_D = off;       off = align_up(off + h.sigma * 8, 256);
     h.off_C = off;       off = align_up(off + (h.sigma + 1) * 8, 256);
@@ -403,12 +431,15 @@ inline void layout_int(IntHeader& h)
 }  // namespace
 
 namespace vlg {
+void layout_int_blob(IntHeader& h) { layout_int(h); }          // for vlg_index_compress (index.hip)
+
 // a blob whose magic says "integer index": called by vlg_index_attach_blob (index.hip)
 vlg_status attach_int_blob(const void* d_blob, uint64_t bytes, vlg_index* idx)
 {
     VLG_HIP_TRY(hipMemcpy(&idx->ihdr, d_blob, sizeof(IntHeader), hipMemcpyDeviceToHost));
     const IntHeader& h = idx->ihdr;
-    if (h.magic != kIntBlobMagic || h.total_bytes > bytes || h.levels > kMaxIntLevels) return fail(VLG_E_INVALID, "not a VLG integer-index blob");
+    if (h.magic != kIntBlobMagic || h.total_bytes > bytes || h.levels > kMaxIntLevels || h.bv_kind > kBvRrr63)
+        return fail(VLG_E_INVALID, "not a VLG integer-index blob");
     idx->d_blob = const_cast<void*>(d_blob);
     idx->owns_blob = false;
     bind_int_view(idx);
@@ -584,7 +615,10 @@ extern "C" vlg_status vlg_int_rank_batch(const vlg_index* idx, const uint64_t* d
     if (!idx || (count && (!d_i || !d_sym || !d_out))) return fail(VLG_E_INVALID, "null argument");
     if (!idx->is_int) return fail(VLG_E_INVALID, "not an integer-alphabet index");
     if (!count) return VLG_OK;
-    hipLaunchKernelGGL(int_rank_kernel, dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream, idx->iview, d_i, d_sym, d_out, count);
+    if (idx->iview.bv_kind == kBvRrr63)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(int_rank_kernel<RrrBV>), dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream, idx->iview, d_i, d_sym, d_out, count);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(int_rank_kernel<PlainBV>), dim3(grid_for(count, 8192)), dim3(256), 0, (hipStream_t)stream, idx->iview, d_i, d_sym, d_out, count);
     VLG_HIP_TRY(hipGetLastError());
     return VLG_OK;
 }
@@ -595,13 +629,17 @@ vlg_status launch_int_backward_search(const IntView& v, const uint8_t* d_blob, c
                                       unsigned long long* d_stat_levels, hipStream_t st)
 {
     if (!n_pat) return VLG_OK;
-    hipLaunchKernelGGL(int_backward_search_kernel, dim3(grid_for(n_pat, 4096)), dim3(256), 0, st, v, d_blob, d_off, n_pat, d_l, d_r, d_stat_levels);
+    if (v.bv_kind == kBvRrr63)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(int_backward_search_kernel<RrrBV>), dim3(grid_for(n_pat, 4096)), dim3(256), 0, st, v, d_blob, d_off, n_pat, d_l, d_r, d_stat_levels);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(int_backward_search_kernel<PlainBV>), dim3(grid_for(n_pat, 4096)), dim3(256), 0, st, v, d_blob, d_off, n_pat, d_l, d_r, d_stat_levels);
     VLG_HIP_TRY(hipGetLastError());
     return VLG_OK;
 }
 
 // the integer index in the sorted sweep (sigma <= 65534: the partition key is 16 bits wide)
-vlg_status launch_int_locate_sweep(const IntView& v, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total, uint32_t* d_out,
+template <class BV>
+static vlg_status launch_int_locate_sweep_bv(const IntView& v, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total, uint32_t* d_out,
                                    uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp, size_t temp_bytes, unsigned long long* d_counter,
                                    unsigned long long* d_stats, uint64_t tail_threshold, hipStream_t stream, LaunchTimer* timer, Block* member,
                                    uint32_t n_member_lists, uint64_t* rec, const std::function<vlg_status()>* while_first_step)
@@ -614,21 +652,33 @@ vlg_status launch_int_locate_sweep(const IntView& v, const uint64_t* d_l, const 
     K.first = [&](uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out, unsigned long long* counter, const Block* mem, uint64_t* rc, bool ahead) {
         const dim3 g = grid_of((t1 - t0 + 7) / 8, 8192);
         uint32_t* o = static_cast<uint32_t*>(out);
-        if (mem && ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<true, true>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
-        else if (mem) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<true, false>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<false, false>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
+        if (mem && ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<BV, true, true>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
+        else if (mem) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<BV, true, false>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<BV, false, false>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
     };
     K.step = [&](uint64_t* val, uint16_t* key, uint64_t alive, uint32_t step, void* out, unsigned long long* counter, const Block* mem, uint64_t* rc, uint64_t t0, bool probed) {
         const dim3 g = grid_of(alive, 4096);
         uint32_t* o = static_cast<uint32_t*>(out);
-        if (mem) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_step_kernel<true>), g, dim3(256), 0, stream, v, val, key, alive, step, o, d_stats, counter, mem, rc, t0, probed);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_step_kernel<false>), g, dim3(256), 0, stream, v, val, key, alive, step, o, d_stats, counter, mem, rc, t0, probed);
+        if (mem) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_step_kernel<BV, true>), g, dim3(256), 0, stream, v, val, key, alive, step, o, d_stats, counter, mem, rc, t0, probed);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_step_kernel<BV, false>), g, dim3(256), 0, stream, v, val, key, alive, step, o, d_stats, counter, mem, rc, t0, probed);
     };
     K.tail = [&](void* out, uint64_t alive, uint32_t per_wave, const uint64_t* val, uint32_t step, uint64_t* rc, uint64_t t0, const Block* mem, uint32_t blocks) {
-        hipLaunchKernelGGL(int_sweep_tail_kernel, dim3(blocks), dim3(256), 0, stream, v, static_cast<uint32_t*>(out), alive, per_wave, d_stats, val, step, rc, t0, mem);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_tail_kernel<BV>), dim3(blocks), dim3(256), 0, stream, v, static_cast<uint32_t*>(out), alive, per_wave, d_stats, val, step, rc, t0, mem);
     };
     return run_locate_sweep<uint32_t, false>(K, d_l, d_out_off, n_pat, total, d_out, val_a, val_b, key_a, key_b, temp, temp_bytes, d_counter, tail_threshold, stream, timer,
                                              member, n_member_lists, rec, while_first_step);
+}
+
+vlg_status launch_int_locate_sweep(const IntView& v, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total, uint32_t* d_out,
+                                   uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp, size_t temp_bytes, unsigned long long* d_counter,
+                                   unsigned long long* d_stats, uint64_t tail_threshold, hipStream_t stream, LaunchTimer* timer, Block* member,
+                                   uint32_t n_member_lists, uint64_t* rec, const std::function<vlg_status()>* while_first_step)
+{
+    return v.bv_kind == kBvRrr63
+               ? launch_int_locate_sweep_bv<RrrBV>(v, d_l, d_out_off, n_pat, total, d_out, val_a, val_b, key_a, key_b, temp, temp_bytes, d_counter, d_stats, tail_threshold,
+                                                   stream, timer, member, n_member_lists, rec, while_first_step)
+               : launch_int_locate_sweep_bv<PlainBV>(v, d_l, d_out_off, n_pat, total, d_out, val_a, val_b, key_a, key_b, temp, temp_bytes, d_counter, d_stats, tail_threshold,
+                                                     stream, timer, member, n_member_lists, rec, while_first_step);
 }
 
 vlg_status launch_int_locate(const IntView& v, uint32_t* d_io, uint64_t total, unsigned long long* d_stats, hipStream_t st)
@@ -638,7 +688,10 @@ vlg_status launch_int_locate(const IntView& v, uint32_t* d_io, uint64_t total, u
     uint64_t per_wave = (total + target_waves - 1) / target_waves;
     per_wave = std::min<uint64_t>(std::max<uint64_t>(per_wave, 64 * 16), 1u << 20);
     const uint64_t waves = (total + per_wave - 1) / per_wave;
-    hipLaunchKernelGGL(int_locate_kernel, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, v, d_io, total, (uint32_t)per_wave, d_stats);
+    if (v.bv_kind == kBvRrr63)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(int_locate_kernel<RrrBV>), dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, v, d_io, total, (uint32_t)per_wave, d_stats);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(int_locate_kernel<PlainBV>), dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, v, d_io, total, (uint32_t)per_wave, d_stats);
     VLG_HIP_TRY(hipGetLastError());
     return VLG_OK;
 }

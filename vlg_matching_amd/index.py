@@ -407,7 +407,7 @@ class VlgIndex:
         return {k: int(getattr(i, k)) for k, _ in capi.IndexInfo._fields_}
 
     def compress(self, bv_kind=1):
-        """A csa_wt<wt_huff<rrr_vector<63>>>-equivalent of this (plain) index; same answers, compressed bit-vectors."""
+        """A csa_wt<wt_huff<rrr_vector<63>>>-equivalent of this (plain) index (wt_int<rrr_vector<63>> for an integer index); same answers, compressed bit-vectors."""
         h = C.c_void_p()
         check(lib().vlg_index_compress(self._h, bv_kind, C.byref(h)))
         return VlgIndex(h)
@@ -451,7 +451,7 @@ class VlgIndex:
     def _queries(self, queries, dialect=capi.DIALECT_LIBRARY, strict=True):
         if isinstance(queries, Queries):
             return queries
-        if self.info()["bv_kind"] == 2:                       # integer-alphabet index: the integer query dialect
+        if self.info()["bv_kind"] in (2, 3):                       # integer-alphabet index: the integer query dialect
             return Queries.from_int(queries, strict)
         return Queries(queries, dialect, strict)
 
