@@ -352,6 +352,12 @@ void vlg_workspace_destroy(vlg_workspace* ws);
  * Matches are the left-most, lazy, non-overlapping tuples of SURVEY.md Appendix C, bit-exact. */
 vlg_status vlg_search_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* ws, vlg_result** out);
 
+/* K4 stand-alone (std::sort of one occurrence list, benchmark/gapped-matching/include/index_sasearch.hpp:80): every list
+ * d_pos[h_off[l], h_off[l + 1]) of 32-bit positions < 2^position_bits is sorted ascending in place by the per-list sort of the batch
+ * path.  mode 1: as "list_sort" = 1 above, mode 2: as 2.  n_clustered (may be null) receives the number of long lists whose
+ * positions were too clustered for the window pass (they took the four full passes).  Synchronises `stream` before it returns. */
+vlg_status vlg_sort_lists_u32(uint32_t* d_pos, const uint64_t* h_off, uint64_t n_lists, uint32_t position_bits, int mode,
+                              uint64_t* n_clustered, void* stream);
 /* K5 on its own: the gap-bounded merge join of benchmark/gapped-matching/include/index_sasearch.hpp:85-116 (semantics of
  * vlg_iterator, include/sdsl/vlg_index.hpp:227-291) over caller-provided occurrence lists in HBM.
  *   d_lists      all lists concatenated, u64 positions, every list ascending (what std::sort leaves, index_sasearch.hpp:80);
@@ -476,8 +482,9 @@ vlg_status vlg_workspace_profile(vlg_workspace* ws, int enable);
  * "trail" (default 1, needs "dedup"): inside a sorted sweep an occurrence that steps onto an SA index another occurrence
  * has visited stops there and takes that occurrence's position plus the distance (csa[i] = csa[LF(i)] + 1 shared between
  * lanes), so a batch walks every LF trail once; 0 = every occurrence walks to its own sample like csa_wt::operator[].
- * "list_sort" (default 1): with 32-bit positions every occurrence list is sorted inside itself by LSD radix passes on the
- * position bits alone (short lists in LDS); 0, or 64-bit positions: "global_sort_min" (default 2^20): from this many
+ * "list_sort" (default 1): with 32-bit positions every occurrence list is sorted inside itself (short lists in LDS by value ranges;
+ * long ones by two LSD radix passes over the top 16 position bits + one LDS pass over windows of whole groups; 2: four LSD passes
+ * over all position bits, what lists with clustered positions take anyway); 0, or 64-bit positions: "global_sort_min" (default 2^20): from this many
  * occurrences on all lists are sorted by one radix sort of (list, position) keys instead of one segmented sort.
  * "filter" (default 1): before the join drop the list elements whose gap windows hold no element of the neighbouring
  * lists (they are in no match); "filter_min" (default 2^12) = join slots below which a query is joined as it is

@@ -128,6 +128,7 @@ SYMBOLS = [
     ("vlg_workspace_destroy", None, [_P]),
     ("vlg_search_batch", _I, [_P, _P, _P, C.POINTER(_P)]),
     ("vlg_join_batch", _I, [_P, _P, _U64, _P, _P, _P, _P, _U64, _P, C.POINTER(_P)]),
+    ("vlg_sort_lists_u32", _I, [_P, _P, _U64, C.c_uint32, _I, C.POINTER(_U64), _P]),
     ("vlg_result_summary_get", _I, [_P, C.POINTER(ResultSummary)]),
     ("vlg_result_fetch", _I, [_P, _P, _P, _P, _P]),
     ("vlg_result_fetch32", _I, [_P, _P, _P]),

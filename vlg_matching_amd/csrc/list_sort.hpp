@@ -6,7 +6,8 @@
 // (list, position) keys with one device-wide radix sort moves 16 bytes per element and pass and spends its upper passes on list
 // bits that are in order already (C3: 30 + 18 bits = 6 passes of 8 bits).  Here only the position bits are sorted, as 32-bit keys,
 // INSIDE every list:
-//   lists of up to kSortTile elements  one workgroup sorts the list in LDS (rocPRIM block_radix_sort), one read + one write;
+//   lists of up to kSortTile elements  one workgroup sorts the list in LDS (a bucket sort by value ranges; rocPRIM block_radix_sort when the
+//                                      positions are clustered), one read + one write;
 //   longer lists                       LSD radix passes of <= 8 bits over tiles of kSortTile elements that never straddle two
 //                                      lists: per tile a digit histogram, per list an exclusive scan of the histograms (by chunks
 //                                      of kSortChunk tiles, so that a list of 2000 tiles is not one serial loop), then every tile
@@ -21,75 +22,217 @@ constexpr uint32_t kSortTile = 4096;          // elements per tile: 256 threads 
 constexpr uint32_t kSortChunk = 32;           // tiles per chunk of the histogram scan
 
 // ---- short lists: whole list in one workgroup ------------------------------------------------------------------------------------
+// The positions of a pattern's occurrences are spread over the text, so a list of `len` keys dealt into as many equal value ranges
+// ("bins", between the list's own minimum and maximum) leaves about one key per bin: an LDS counter per bin gives every key its bin's
+// arrival number, a scan of the counters where the bins start, and a key's place is its bin's start + the keys of the same bin that
+// are smaller (a loop over one or two keys).  One read and one write of the list and a few dozen instructions per key, where the
+// block-wide radix sort ranks every key four times by 8-bit digits (the class VALU-bound at 95 %).  A list whose
+// positions are clustered (some bin holds more than kBucketMaxOcc keys) takes the radix sort as before -- the branch is block-uniform.
+#ifndef VLG_BUCKET_SORT
+#define VLG_BUCKET_SORT 1
+#endif
+constexpr uint32_t kBucketMaxOcc = 24;
+__device__ __forceinline__ uint32_t bin_at(uint32_t j) { return j + (j >> 5); }      // counters padded: thread t scans bins [t*k, t*k + k)
+
+template <uint32_t kThreads, uint32_t kItems, bool kInlineFallback>
+struct BucketSort {
+    using Load = rocprim::block_load<uint32_t, kThreads, kItems, rocprim::block_load_method::block_load_transpose>;
+    using Store = rocprim::block_store<uint32_t, kThreads, kItems, rocprim::block_store_method::block_store_transpose>;
+    using Sort = rocprim::block_radix_sort<uint32_t, kThreads, kItems>;
+    static constexpr uint32_t kCap = kThreads * kItems, kPad = kCap + kCap / 32 + 1, kWaves = (kThreads + 63) / 64;
+    static_assert(kCap < 0x10000u, "two 16-bit counts share one scan");
+    struct Buckets { uint32_t cnt[kPad]; uint32_t tmp[kCap]; uint32_t work[kCap / 2 + 2]; };
+    union Radix { typename Load::storage_type load; typename Store::storage_type store; typename Sort::storage_type sort; };
+    union Both { Buckets b; Radix r; };
+    using Storage = typename std::conditional<kInlineFallback, Both, Buckets>::type;
+    struct Misc { uint32_t lo, hi, max, wave[kWaves]; };
+    static __device__ __forceinline__ Buckets& buckets(Buckets& s) { return s; }
+    static __device__ __forceinline__ Buckets& buckets(Both& s) { return s.b; }
+
+    // the block-wide radix sort (clustered positions)
+    static __device__ __forceinline__ void radix(const uint32_t* src, uint32_t* dst, uint32_t len, uint32_t bits, Radix& r)
+    {
+        uint32_t keys[kItems];
+        Load().load(src, keys, len, 0xFFFFFFFFu, r.load);               // positions are < 2^32 - 1: the padding sorts last
+        __syncthreads();
+        Sort().sort(keys, r.sort, 0, bits);
+        __syncthreads();
+        Store().store(dst, keys, len, r.store);
+    }
+
+    // src[0, len) sorted ascending into dst[0, len) (the same array or another one), len <= kCap, by the whole workgroup.
+    // false (block-uniform; only without the inline fallback): the keys are clustered, nothing was written
+    static __device__ __forceinline__ bool run(const uint32_t* src, uint32_t* dst, uint32_t len, uint32_t bits, Storage& st, Misc& m_)
+    {
+        const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        Buckets& s = buckets(st);
+        if (len == 0) return true;
+        if (VLG_BUCKET_SORT) {
+            uint32_t key[kItems], ba[kItems];                                 // bin << 8 | arrival number inside the bin (capped)
+            if (tid == 0) { m_.lo = 0xFFFFFFFFu; m_.hi = 0; m_.max = 0; }
+            for (uint32_t j = tid; j < kPad; j += kThreads) s.cnt[j] = 0;
+            uint32_t lo = 0xFFFFFFFFu, hi = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kItems; ++i) {
+                const uint32_t e = i * kThreads + tid;
+                key[i] = e < len ? src[e] : 0u;
+                if (e < len) { lo = key[i] < lo ? key[i] : lo; hi = key[i] > hi ? key[i] : hi; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t a = __shfl_xor(lo, o), c = __shfl_xor(hi, o);
+                lo = a < lo ? a : lo; hi = c > hi ? c : hi;
+            }
+            __syncthreads();
+            if (lane == 0) { atomicMin(&m_.lo, lo); atomicMax(&m_.hi, hi); }
+            __syncthreads();
+            lo = m_.lo; hi = m_.hi;
+            // bin = (key - lo) * kCap / range, as a multiplication: m = floor(kCap * 2^32 / range), (key - lo) * m <= kCap * 2^32
+            const uint64_t m = ((uint64_t)kCap << 32) / ((uint64_t)hi - lo + 1);
+#pragma unroll
+            for (uint32_t i = 0; i < kItems; ++i) {
+                const uint32_t e = i * kThreads + tid;
+                uint32_t bn = (uint32_t)(((uint64_t)(key[i] - lo) * m) >> 32);
+                bn = bn < kCap ? bn : kCap - 1;
+                const uint32_t arr = e < len ? atomicAdd(&s.cnt[bin_at(bn)], 1u) : 0u;
+                ba[i] = (bn << 8) | (arr < 255u ? arr : 255u);
+            }
+            __syncthreads();
+            // exclusive scan of the counters (thread t: bins [t * kItems, (t + 1) * kItems)), the fullest bin, and -- in the upper half of
+            // the same scan -- the number of bins that hold more than one key: those go on a work list (start << 8 | keys)
+            uint32_t sum = 0, mx = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kItems; ++i) {
+                const uint32_t c = s.cnt[bin_at(tid * kItems + i)];
+                sum += c + (c >= 2 ? 0x10000u : 0u);
+                mx = c > mx ? c : mx;
+            }
+            uint32_t incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += v; }
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }
+            if (lane == 63) m_.wave[wv] = incl;
+            if (lane == 0) atomicMax(&m_.max, mx);
+            __syncthreads();
+            uint32_t run_ = incl - sum, all_ = 0;
+            for (uint32_t w = 0; w < kWaves; ++w) { const uint32_t v = m_.wave[w]; if (w < wv) run_ += v; all_ += v; }
+            const bool spread = m_.max <= kBucketMaxOcc;
+            uint32_t at_work = run_ >> 16;
+            run_ &= 0xFFFFu;
+#pragma unroll
+            for (uint32_t i = 0; i < kItems; ++i) {
+                const uint32_t at = bin_at(tid * kItems + i), c = s.cnt[at];
+                s.cnt[at] = run_;
+                if (c >= 2 && spread) s.work[at_work++] = (run_ << 8) | c;
+                run_ += c;
+            }
+            const uint32_t n_work = all_ >> 16;
+            __syncthreads();
+            if (spread) {
+#pragma unroll
+                for (uint32_t i = 0; i < kItems; ++i)
+                    if (i * kThreads + tid < len) s.tmp[s.cnt[bin_at(ba[i] >> 8)] + (ba[i] & 255u)] = key[i];
+                __syncthreads();
+#pragma unroll 1
+                for (uint32_t w = tid; w < n_work; w += kThreads) {
+                    const uint32_t e = s.work[w], s0 = e >> 8, n = e & 255u;
+                    if (n == 2) {                                             // three quarters of them
+                        const uint32_t a0 = s.tmp[s0], a1 = s.tmp[s0 + 1];
+                        if (a0 > a1) { s.tmp[s0] = a1; s.tmp[s0 + 1] = a0; }
+                    } else {
+                        for (uint32_t j = s0 + 1; j < s0 + n; ++j) {          // insertion sort of a handful of keys
+                            const uint32_t v = s.tmp[j];
+                            uint32_t k = j;
+                            while (k > s0) { const uint32_t u = s.tmp[k - 1]; if (u <= v) break; s.tmp[k] = u; --k; }
+                            s.tmp[k] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (uint32_t i = 0; i < kItems; ++i) {
+                    const uint32_t e = i * kThreads + tid;
+                    if (e < len) dst[e] = s.tmp[e];
+                }
+                return true;
+            }
+            if (!kInlineFallback) return false;
+        }
+        if constexpr (kInlineFallback) radix(src, dst, len, bits, st.r);
+        return true;
+    }
+};
+
 template <uint32_t kThreads, uint32_t kItems>
 __global__ void __launch_bounds__(kThreads) list_sort_small_kernel(uint32_t* __restrict__ P, const uint64_t* __restrict__ off,
                                                                    const uint32_t* __restrict__ lists, uint32_t n_lists, uint32_t bits)
 {
-    using Load = rocprim::block_load<uint32_t, kThreads, kItems, rocprim::block_load_method::block_load_transpose>;
-    using Store = rocprim::block_store<uint32_t, kThreads, kItems, rocprim::block_store_method::block_store_transpose>;
-    using Sort = rocprim::block_radix_sort<uint32_t, kThreads, kItems>;
-    __shared__ union { typename Load::storage_type load; typename Store::storage_type store; typename Sort::storage_type sort; } s;
+    using BS = BucketSort<kThreads, kItems, true>;
+    __shared__ typename BS::Storage s;
+    __shared__ typename BS::Misc misc;
     if (blockIdx.x >= n_lists) return;
     const uint32_t l = lists[blockIdx.x];
     const uint64_t begin = off[l];
-    const uint32_t len = (uint32_t)(off[l + 1] - begin);
-    uint32_t keys[kItems];
-    Load().load(P + begin, keys, len, 0xFFFFFFFFu, s.load);       // positions are < 2^32 - 1: the padding sorts last
-    __syncthreads();
-    Sort().sort(keys, s.sort, 0, bits);
-    __syncthreads();
-    Store().store(P + begin, keys, len, s.store);
+    BS::run(P + begin, P + begin, (uint32_t)(off[l + 1] - begin), bits, s, misc);
 }
 
 // ---- long lists ----------------------------------------------------------------------------------------------------------------------
 struct SortList { uint64_t begin; uint32_t len, tile0, chunk0, pad; };      // a long list: elements, first tile, first chunk
 
 // digit histogram of every tile: hist[tile][256]
+// (flagged_only, here and in the other pass kernels: a pass over the lists whose SortList::pad is set -- launched with a small grid that
+//  strides over the tiles and leaves at once when *any_flagged is zero, which is the common case: no clustered list in the batch)
 __global__ void __launch_bounds__(256) list_sort_hist_kernel(const uint32_t* __restrict__ in, const SortList* __restrict__ lists,
                                                              const uint32_t* __restrict__ tile_list, uint32_t n_tiles, uint32_t shift,
-                                                             uint32_t mask, uint16_t* __restrict__ hist)
+                                                             uint32_t mask, uint16_t* __restrict__ hist, bool flagged_only, const uint32_t* __restrict__ any_flagged)
 {
     __shared__ uint32_t h[256];
-    const uint32_t t = blockIdx.x;
-    if (t >= n_tiles) return;
-    const SortList L = lists[tile_list[t]];
-    const uint32_t first = (t - L.tile0) * kSortTile;
-    const uint32_t cnt = L.len - first < kSortTile ? L.len - first : kSortTile;
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t* src = in + L.begin + first;
+    if (flagged_only && *any_flagged == 0) return;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const SortList L = lists[tile_list[t]];
+        if (flagged_only && !L.pad) continue;
+        const uint32_t first = (t - L.tile0) * kSortTile;
+        const uint32_t cnt = L.len - first < kSortTile ? L.len - first : kSortTile;
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t* src = in + L.begin + first;
 #pragma unroll
-    for (uint32_t i = 0; i < kSortTile / 256; ++i) {
-        const uint32_t e = i * 256 + threadIdx.x;
-        if (e < cnt) atomicAdd(&h[(src[e] >> shift) & mask], 1u);
+        for (uint32_t i = 0; i < kSortTile / 256; ++i) {
+            const uint32_t e = i * 256 + threadIdx.x;
+            if (e < cnt) atomicAdd(&h[(src[e] >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        hist[(uint64_t)t * 256 + threadIdx.x] = (uint16_t)h[threadIdx.x];      // <= kSortTile = 2^12
+        __syncthreads();
     }
-    __syncthreads();
-    hist[(uint64_t)t * 256 + threadIdx.x] = (uint16_t)h[threadIdx.x];      // <= kSortTile = 2^12
 }
 
 // totals of every chunk of kSortChunk tiles: tot[chunk][256]
 __global__ void __launch_bounds__(256) list_sort_chunk_kernel(const uint16_t* __restrict__ hist, const SortList* __restrict__ lists,
                                                               const uint32_t* __restrict__ chunk_list, uint32_t n_chunks,
-                                                              uint32_t* __restrict__ tot)
+                                                              uint32_t* __restrict__ tot, bool flagged_only, const uint32_t* __restrict__ any_flagged)
 {
-    const uint32_t c = blockIdx.x;
-    if (c >= n_chunks) return;
-    const SortList L = lists[chunk_list[c]];
-    const uint32_t tiles = (L.len + kSortTile - 1) / kSortTile;
-    const uint32_t t0 = (c - L.chunk0) * kSortChunk, t1 = t0 + kSortChunk < tiles ? t0 + kSortChunk : tiles;
-    uint32_t sum = 0;
-    for (uint32_t t = t0; t < t1; ++t) sum += hist[(uint64_t)(L.tile0 + t) * 256 + threadIdx.x];
-    tot[(uint64_t)c * 256 + threadIdx.x] = sum;
+    if (flagged_only && *any_flagged == 0) return;
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const SortList L = lists[chunk_list[c]];
+        if (flagged_only && !L.pad) continue;
+        const uint32_t tiles = (L.len + kSortTile - 1) / kSortTile;
+        const uint32_t t0 = (c - L.chunk0) * kSortChunk, t1 = t0 + kSortChunk < tiles ? t0 + kSortChunk : tiles;
+        uint32_t sum = 0;
+        for (uint32_t t = t0; t < t1; ++t) sum += hist[(uint64_t)(L.tile0 + t) * 256 + threadIdx.x];
+        tot[(uint64_t)c * 256 + threadIdx.x] = sum;
+    }
 }
 
 // per list: tot[chunk][d] becomes the number of keys of the list that go before the chunk's keys with digit d (smaller digits of the
 // whole list + digit d of the chunks before it)
-__global__ void __launch_bounds__(256) list_sort_scan_kernel(const SortList* __restrict__ lists, uint32_t n_long, uint32_t* __restrict__ tot)
+__global__ void __launch_bounds__(256) list_sort_scan_kernel(const SortList* __restrict__ lists, uint32_t n_long, uint32_t* __restrict__ tot, bool flagged_only,
+                                                             const uint32_t* __restrict__ any_flagged)
 {
     __shared__ uint32_t s[256];
     const uint32_t m = blockIdx.x;
     if (m >= n_long) return;
+    if (flagged_only && *any_flagged == 0) return;
     const SortList L = lists[m];
+    if (flagged_only && !L.pad) return;
     const uint32_t tiles = (L.len + kSortTile - 1) / kSortTile, chunks = (tiles + kSortChunk - 1) / kSortChunk;
     uint32_t run = 0;
     for (uint32_t c = 0; c < chunks; ++c) {
@@ -114,18 +257,21 @@ __global__ void __launch_bounds__(256) list_sort_scan_kernel(const SortList* __r
 // per chunk: pref[tile][d] = where the tile's keys with digit d start inside the list
 __global__ void __launch_bounds__(256) list_sort_prefix_kernel(const uint16_t* __restrict__ hist, const SortList* __restrict__ lists,
                                                                const uint32_t* __restrict__ chunk_list, uint32_t n_chunks,
-                                                               const uint32_t* __restrict__ tot, uint32_t* __restrict__ pref)
+                                                               const uint32_t* __restrict__ tot, uint32_t* __restrict__ pref, bool flagged_only,
+                                                               const uint32_t* __restrict__ any_flagged)
 {
-    const uint32_t c = blockIdx.x;
-    if (c >= n_chunks) return;
-    const SortList L = lists[chunk_list[c]];
-    const uint32_t tiles = (L.len + kSortTile - 1) / kSortTile;
-    const uint32_t t0 = (c - L.chunk0) * kSortChunk, t1 = t0 + kSortChunk < tiles ? t0 + kSortChunk : tiles;
-    uint32_t run = tot[(uint64_t)c * 256 + threadIdx.x];
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint64_t at = (uint64_t)(L.tile0 + t) * 256 + threadIdx.x;
-        pref[at] = run;
-        run += hist[at];
+    if (flagged_only && *any_flagged == 0) return;
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const SortList L = lists[chunk_list[c]];
+        if (flagged_only && !L.pad) continue;
+        const uint32_t tiles = (L.len + kSortTile - 1) / kSortTile;
+        const uint32_t t0 = (c - L.chunk0) * kSortChunk, t1 = t0 + kSortChunk < tiles ? t0 + kSortChunk : tiles;
+        uint32_t run = tot[(uint64_t)c * 256 + threadIdx.x];
+        for (uint32_t t = t0; t < t1; ++t) {
+            const uint64_t at = (uint64_t)(L.tile0 + t) * 256 + threadIdx.x;
+            pref[at] = run;
+            run += hist[at];
+        }
     }
 }
 
@@ -134,7 +280,7 @@ __global__ void __launch_bounds__(256) list_sort_prefix_kernel(const uint16_t* _
 __global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                                 const SortList* __restrict__ lists, const uint32_t* __restrict__ tile_list,
                                                                 uint32_t n_tiles, uint32_t shift, uint32_t dbits,
-                                                                const uint32_t* __restrict__ pref)
+                                                                const uint32_t* __restrict__ pref, bool flagged_only, const uint32_t* __restrict__ any_flagged)
 {
     constexpr uint32_t kItems = kSortTile / 256;
     using Rank = rocprim::block_radix_rank<256, 8, rocprim::block_radix_rank_algorithm::match>;
@@ -146,42 +292,130 @@ __global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* 
     __shared__ typename Rank::storage_type s_rank;
     __shared__ uint32_t s_keys[kSortTile];
     __shared__ uint32_t first[256];
-    const uint32_t t = blockIdx.x;
-    if (t >= n_tiles) return;
-    const SortList L = lists[tile_list[t]];
-    const uint32_t begin = (t - L.tile0) * kSortTile;
-    const uint32_t cnt = L.len - begin < kSortTile ? L.len - begin : kSortTile;
-    const uint32_t mask = (1u << dbits) - 1u;
-    const uint32_t* src = in + L.begin + begin;
-    const uint32_t wbase = (threadIdx.x >> 6) * (64 * kItems) + (threadIdx.x & 63);
-    uint32_t keys[kItems];
-    unsigned int ranks[kItems];
+    if (flagged_only && *any_flagged == 0) return;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const SortList L = lists[tile_list[t]];
+        if (flagged_only && !L.pad) continue;
+        const uint32_t begin = (t - L.tile0) * kSortTile;
+        const uint32_t cnt = L.len - begin < kSortTile ? L.len - begin : kSortTile;
+        const uint32_t mask = (1u << dbits) - 1u;
+        const uint32_t* src = in + L.begin + begin;
+        const uint32_t wbase = (threadIdx.x >> 6) * (64 * kItems) + (threadIdx.x & 63);
+        uint32_t keys[kItems];
+        unsigned int ranks[kItems];
 #pragma unroll
-    for (uint32_t i = 0; i < kItems; ++i) {
-        const uint32_t e = wbase + 64 * i;                                   // warp-striped: the order of the elements themselves
-        keys[i] = e < cnt ? src[e] : 0xFFFFFFFFu;                            // the padding has the largest digit and stands last: it stays last
-    }
-    unsigned int prefix[1], counts[1];
-    Rank().rank_keys(keys, ranks, s_rank, [shift, mask](const uint32_t& k) { return (k >> shift) & mask; }, prefix, counts);
-    first[threadIdx.x] = prefix[0];                                          // where the tile's keys with digit threadIdx.x start
-#pragma unroll
-    for (uint32_t i = 0; i < kItems; ++i) s_keys[ranks[i]] = keys[i];
-    __syncthreads();
-    const uint32_t* pf = pref + (uint64_t)t * 256;
-    uint32_t* dst = out + L.begin;
-#pragma unroll
-    for (uint32_t i = 0; i < kItems; ++i) {
-        const uint32_t p = i * 256 + threadIdx.x;                            // neighbouring lanes write neighbouring keys of a run
-        if (p < cnt) {
-            const uint32_t k = s_keys[p], d = (k >> shift) & mask;
-            dst[pf[d] + (p - first[d])] = k;
+        for (uint32_t i = 0; i < kItems; ++i) {
+            const uint32_t e = wbase + 64 * i;                                   // warp-striped: the order of the elements themselves
+            keys[i] = e < cnt ? src[e] : 0xFFFFFFFFu;                            // the padding has the largest digit and stands last: it stays last
         }
+        unsigned int prefix[1], counts[1];
+        Rank().rank_keys(keys, ranks, s_rank, [shift, mask](const uint32_t& k) { return (k >> shift) & mask; }, prefix, counts);
+        first[threadIdx.x] = prefix[0];                                          // where the tile's keys with digit threadIdx.x start
+#pragma unroll
+        for (uint32_t i = 0; i < kItems; ++i) s_keys[ranks[i]] = keys[i];
+        __syncthreads();
+        const uint32_t* pf = pref + (uint64_t)t * 256;
+        uint32_t* dst = out + L.begin;
+#pragma unroll
+        for (uint32_t i = 0; i < kItems; ++i) {
+            const uint32_t p = i * 256 + threadIdx.x;                            // neighbouring lanes write neighbouring keys of a run
+            if (p < cnt) {
+                const uint32_t k = s_keys[p], d = (k >> shift) & mask;
+                dst[pf[d] + (p - first[d])] = k;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- long lists, the short way: two passes + windows ------------------------------------------------------------------------------
+// After LSD passes over the TOP 16 bits only, a list is ordered by those bits and the keys that share them (a "group": len / 65536 keys
+// of a list whose positions are spread over the text) stand together in any order.  The tiles of the list, their borders moved back to
+// the start of the group they fall into, are windows of whole groups: a workgroup sorts its window in LDS (BucketSort: the window's
+// keys span a narrow value range, dealt into bins again) and the list is sorted -- 2 ranking passes + 1 cheap pass, 32 instead of 48
+// bytes per key.  A border is looked for at most kWinReach keys back; a list with a longer group (clustered positions) is flagged
+// (SortList::pad) by the plan kernel, skipped by the window kernels, and sorted by the four full passes, which run for flagged lists only.
+// A window whose keys are clustered inside it (BucketSort gives up) is sorted by the block-wide radix sort in a second kernel.
+#ifndef VLG_WINDOW_SORT
+#define VLG_WINDOW_SORT 1
+#endif
+#ifndef VLG_WINDOWS_PER_TILE
+#define VLG_WINDOWS_PER_TILE 2
+#endif
+#ifndef VLG_WINDOW_THREADS
+#define VLG_WINDOW_THREADS 256
+#endif
+#ifndef VLG_WINDOW_ITEMS
+#define VLG_WINDOW_ITEMS 12
+#endif
+constexpr uint32_t kWinPerTile = VLG_WINDOWS_PER_TILE, kWinSpan = kSortTile / kWinPerTile;       // a window: kWinSpan keys before its borders move
+constexpr uint32_t kWinThreads = VLG_WINDOW_THREADS, kWinItems = VLG_WINDOW_ITEMS, kWinCap = kWinThreads * kWinItems, kWinReach = kWinCap - kWinSpan;
+static_assert(kWinCap > kWinSpan && kSortTile % kWinPerTile == 0, "a window holds its span and the group it reaches back for");
+constexpr uint32_t kWinMaxLen = 1u << 25;       // longer lists: groups of the top 16 bits would fill a window by themselves
+
+// win[u]: where window u of the batch starts inside its list (u = kWinPerTile * tile + j; the list's length for a window behind its end)
+__global__ void __launch_bounds__(256) list_sort_window_plan_kernel(const uint32_t* __restrict__ in, SortList* __restrict__ lists,
+                                                                    const uint32_t* __restrict__ tile_list, uint32_t n_tiles, uint32_t shift,
+                                                                    uint32_t* __restrict__ win, uint32_t* __restrict__ any /* [0]: lists flagged */)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_tiles * kWinPerTile) return;
+    const uint32_t m = tile_list[u / kWinPerTile];
+    const SortList L = lists[m];
+    const uint32_t x = (u - L.tile0 * kWinPerTile) * kWinSpan;
+    if (x == 0) { win[u] = 0; if (L.len > kWinMaxLen) { lists[m].pad = 1; any[0] = 1; } return; }
+    if (x >= L.len) { win[u] = L.len; return; }
+    const uint32_t* src = in + L.begin;
+    const uint32_t h = src[x] >> shift;
+    const uint32_t lo = x > kWinReach ? x - kWinReach : 0;
+    uint32_t a = lo, b = x;                                                  // first key of the group of src[x], inside [lo, x]
+    while (a < b) { const uint32_t mid = (a + b) >> 1; if ((src[mid] >> shift) < h) a = mid + 1; else b = mid; }
+    if (a == lo && lo > 0 && (src[lo - 1] >> shift) == h) { lists[m].pad = 1; any[0] = 1; }   // the group starts further back than a window reaches
+    win[u] = a;
+}
+
+// desc[u] = {where window u starts in the batch's array, its keys}: everything the window kernel needs in ONE load (it used to walk
+// tile -> list -> borders -> keys, four dependent round trips in front of a few microseconds of work); no keys for a flagged list
+__global__ void __launch_bounds__(256) list_sort_window_desc_kernel(const SortList* __restrict__ lists, const uint32_t* __restrict__ tile_list,
+                                                                    uint32_t n_tiles, const uint32_t* __restrict__ win, uint2* __restrict__ desc)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_tiles * kWinPerTile) return;
+    const SortList L = lists[tile_list[u / kWinPerTile]];
+    const uint32_t k = u - L.tile0 * kWinPerTile;
+    const uint32_t a = win[u], b = (uint64_t)(k + 1) * kWinSpan >= L.len ? L.len : win[u + 1];     // <= kWinCap keys (plan kernel)
+    desc[u] = make_uint2((uint32_t)(L.begin + a), L.pad ? 0u : b - a);
+}
+
+// kRadix: the windows the bucket pass gave up on (win_flag), by the block-wide radix sort -- a kernel of its own so that the common
+// pass does not carry its registers
+// (measured on 2.7e8 keys: 4 workgroups per CU 1.87 ms, 5 -- what the register cap below buys -- 1.62 ms, 512 threads x 6 keys 1.83 ms:
+//  the pass waits on its dependent loads and barriers, not on its instructions)
+template <bool kRadix>
+__global__ void __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(5, 8))) list_sort_window_kernel(const uint32_t* in, uint32_t* out /* may be the same array */,
+                                                               const uint2* __restrict__ desc, uint32_t n_windows, uint32_t bits,
+                                                               uint8_t* __restrict__ win_flag, uint32_t* __restrict__ any /* [1]: windows flagged */)
+{
+    using BS = BucketSort<kWinThreads, kWinItems, false>;
+    __shared__ typename std::conditional<kRadix, typename BS::Radix, typename BS::Storage>::type s;
+    __shared__ typename BS::Misc misc;
+    if (kRadix && any[1] == 0) return;
+    for (uint32_t u = blockIdx.x; u < n_windows; u += gridDim.x) {
+        if (kRadix && !win_flag[u]) continue;
+        const uint2 d = desc[u];
+        if constexpr (kRadix) {
+            BS::radix(in + d.x, out + d.x, d.y, bits, s);
+        } else {
+            const bool done = BS::run(in + d.x, out + d.x, d.y, bits, s, misc);
+            if (threadIdx.x == 0) { win_flag[u] = done ? 0 : 1; if (!done) any[1] = 1; }
+        }
+        __syncthreads();
     }
 }
 
 inline uint64_t list_sort_scratch_bytes(uint64_t n_long, uint64_t n_tiles, uint64_t n_chunks)
 {
-    return n_long * sizeof(SortList) + (n_tiles + n_chunks) * 4 + n_tiles * 256 * 6 + n_chunks * 256 * 4 + 8 * 256;
+    return n_long * sizeof(SortList) + (n_tiles + n_chunks) * 4 + n_tiles * 256 * 6 + n_chunks * 256 * 4 + (n_tiles * kWinPerTile + 1) * 13 + 12 * 256;
 }
 
 // The host side comes in two halves so that the tables are built and uploaded BEFORE the lists exist (while locate still runs):
@@ -201,7 +435,10 @@ struct ListSortPlan {
     uint32_t* d_small[kSortClasses] = {};
     uint32_t n_long = 0, n_tiles = 0, n_chunks = 0;
     SortList* d_longs = nullptr;
-    uint32_t *d_tile_list = nullptr, *d_chunk_list = nullptr, *d_tot = nullptr, *d_pref = nullptr;
+    uint32_t *d_tile_list = nullptr, *d_chunk_list = nullptr, *d_tot = nullptr, *d_pref = nullptr, *d_win = nullptr;
+    uint8_t* d_win_flag = nullptr;
+    uint2* d_win_desc = nullptr;
+    uint32_t* d_any = nullptr;       // [0]: some list is flagged, [1]: some window is
     uint16_t* d_hist = nullptr;
 };
 
@@ -246,6 +483,10 @@ inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Ar
         lp.d_hist = A.take<uint16_t>((uint64_t)lp.n_tiles * 256);
         lp.d_tot = A.take<uint32_t>((uint64_t)lp.n_chunks * 256);
         lp.d_pref = A.take<uint32_t>((uint64_t)lp.n_tiles * 256);
+        lp.d_win = A.take<uint32_t>((uint64_t)lp.n_tiles * kWinPerTile + 1);
+        lp.d_win_flag = A.take<uint8_t>((uint64_t)lp.n_tiles * kWinPerTile + 1);
+        lp.d_win_desc = A.take<uint2>((uint64_t)lp.n_tiles * kWinPerTile + 1);
+        lp.d_any = A.take<uint32_t>(2);
         if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (list sort)");
         VLG_HIP_TRY(hipMemcpyAsync(lp.d_longs, longs.data(), lp.n_long * sizeof(SortList), hipMemcpyHostToDevice, st));
         VLG_HIP_TRY(hipMemcpyAsync(lp.d_tile_list, tile_list.data(), lp.n_tiles * 4, hipMemcpyHostToDevice, st));
@@ -257,7 +498,8 @@ inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Ar
 }
 
 // P: the lists (in suffix-array order inside), `other`: a second buffer of the same size; the sorted lists end up in P.
-inline vlg_status list_sort_enqueue(const ListSortPlan& lp, uint32_t* P, uint32_t* other, const uint64_t* d_off64, unsigned bits, hipStream_t st)
+inline vlg_status list_sort_enqueue(const ListSortPlan& lp, uint32_t* P, uint32_t* other, const uint64_t* d_off64, unsigned bits, hipStream_t st,
+                                    bool allow_windows = true)
 {
 #define VLG_SMALL(C, T, I) do { static_assert(T * I == kSortClassMax[C], "class size"); \
         if (lp.n_small[C]) hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_small_kernel<T, I>), dim3(lp.n_small[C]), dim3(T), 0, st, P, d_off64, lp.d_small[C], lp.n_small[C], bits); } while (0)
@@ -269,19 +511,37 @@ inline vlg_status list_sort_enqueue(const ListSortPlan& lp, uint32_t* P, uint32_
 #undef VLG_SMALL
     VLG_HIP_TRY(hipGetLastError());
     if (!lp.n_long) return VLG_OK;
-    const unsigned passes = bits <= 16 ? 2 : 4;                    // even: the lists come back to P
-    const unsigned dbits = (bits + passes - 1) / passes;          // <= 8
     uint32_t* src = P;
     uint32_t* dst = other;
-    for (unsigned p = 0; p < passes; ++p) {
-        const uint32_t shift = p * dbits, mask = (1u << dbits) - 1u;
-        hipLaunchKernelGGL(list_sort_hist_kernel, dim3(lp.n_tiles), dim3(256), 0, st, src, lp.d_longs, lp.d_tile_list, lp.n_tiles, shift, mask, lp.d_hist);
-        hipLaunchKernelGGL(list_sort_chunk_kernel, dim3(lp.n_chunks), dim3(256), 0, st, lp.d_hist, lp.d_longs, lp.d_chunk_list, lp.n_chunks, lp.d_tot);
-        hipLaunchKernelGGL(list_sort_scan_kernel, dim3(lp.n_long), dim3(256), 0, st, lp.d_longs, lp.n_long, lp.d_tot);
-        hipLaunchKernelGGL(list_sort_prefix_kernel, dim3(lp.n_chunks), dim3(256), 0, st, lp.d_hist, lp.d_longs, lp.d_chunk_list, lp.n_chunks, lp.d_tot, lp.d_pref);
-        hipLaunchKernelGGL(list_sort_scatter_kernel, dim3(lp.n_tiles), dim3(256), 0, st, src, dst, lp.d_longs, lp.d_tile_list, lp.n_tiles, shift, dbits, lp.d_pref);
-        VLG_HIP_TRY(hipGetLastError());
+    const uint32_t few = 1024;                                   // blocks of a pass that almost always has nothing to do
+    auto pass = [&](uint32_t shift, uint32_t dbits, bool flagged_only) {
+        const uint32_t mask = (1u << dbits) - 1u;
+        const dim3 gt(flagged_only ? std::min(lp.n_tiles, few) : lp.n_tiles), gc(flagged_only ? std::min(lp.n_chunks, few) : lp.n_chunks);
+        hipLaunchKernelGGL(list_sort_hist_kernel, gt, dim3(256), 0, st, src, lp.d_longs, lp.d_tile_list, lp.n_tiles, shift, mask, lp.d_hist, flagged_only, lp.d_any);
+        hipLaunchKernelGGL(list_sort_chunk_kernel, gc, dim3(256), 0, st, lp.d_hist, lp.d_longs, lp.d_chunk_list, lp.n_chunks, lp.d_tot, flagged_only, lp.d_any);
+        hipLaunchKernelGGL(list_sort_scan_kernel, dim3(lp.n_long), dim3(256), 0, st, lp.d_longs, lp.n_long, lp.d_tot, flagged_only, lp.d_any);
+        hipLaunchKernelGGL(list_sort_prefix_kernel, gc, dim3(256), 0, st, lp.d_hist, lp.d_longs, lp.d_chunk_list, lp.n_chunks, lp.d_tot, lp.d_pref, flagged_only, lp.d_any);
+        hipLaunchKernelGGL(list_sort_scatter_kernel, gt, dim3(256), 0, st, src, dst, lp.d_longs, lp.d_tile_list, lp.n_tiles, shift, dbits, lp.d_pref, flagged_only, lp.d_any);
         std::swap(src, dst);
+    };
+    static const bool windows = [] { const char* e = getenv("VLG_WINDOW_SORT"); return e ? e[0] != '0' : VLG_WINDOW_SORT != 0; }();
+    const bool by_windows = windows && allow_windows && bits >= 17;
+    VLG_HIP_TRY(hipMemsetAsync(lp.d_any, 0, 8, st));
+    if (by_windows) {
+        pass(bits - 16, 8, false);                                   // the top 16 bits, low digit first; the lists are back in P
+        pass(bits - 8, 8, false);
+        hipLaunchKernelGGL(list_sort_window_plan_kernel, dim3((lp.n_tiles * kWinPerTile + 255) / 256), dim3(256), 0, st, P, lp.d_longs, lp.d_tile_list, lp.n_tiles, bits - 16, lp.d_win, lp.d_any);
+        const uint32_t n_windows = lp.n_tiles * kWinPerTile;
+        hipLaunchKernelGGL(list_sort_window_desc_kernel, dim3((n_windows + 255) / 256), dim3(256), 0, st, lp.d_longs, lp.d_tile_list, lp.n_tiles, lp.d_win, lp.d_win_desc);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_window_kernel<false>), dim3(n_windows), dim3(kWinThreads), 0, st, P, P, lp.d_win_desc, n_windows, bits, lp.d_win_flag, lp.d_any);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(list_sort_window_kernel<true>), dim3(std::min(n_windows, few)), dim3(kWinThreads), 0, st, P, P, lp.d_win_desc, n_windows, bits, lp.d_win_flag, lp.d_any);
+        VLG_HIP_TRY(hipGetLastError());
+    }
+    const unsigned passes = bits <= 16 ? 2 : 4;                    // even: the lists come back to P
+    const unsigned dbits = (bits + passes - 1) / passes;          // <= 8
+    for (unsigned p = 0; p < passes; ++p) {                        // (by windows: only for the lists the plan kernel flagged)
+        pass(p * dbits, dbits, by_windows);
+        VLG_HIP_TRY(hipGetLastError());
     }
     return VLG_OK;
 }

@@ -71,7 +71,7 @@ struct vlg_workspace {
                                              // (C3, ms for the class: 0 18.2, 64 18.3, 256 16.6, 512 16.8, 1024 19.2, always half words 31.5)
     uint32_t pivot_rungs = 1;   // the pivot filter searches through the ladder: 0 never (fences + bisection), 1 when it pays, 2 always
     bool want_rungs = false;    // ... and the super-chunk in work has enough pivot searches to pay for building it
-    bool list_sort = true;      // 32-bit positions: every list sorted inside itself (list_sort.hpp); off: the two rocPRIM paths below
+    int list_sort = 1;          // 32-bit positions: every list sorted inside itself (list_sort.hpp; 2: without the window passes); 0: the two rocPRIM paths below
     uint64_t global_sort_min = 1ull << 20;  // at least this many occurrences: all lists are sorted by one radix sort of (list, position) keys
     uint64_t sweep_min = 1ull << 22;    // below this many occurrences the persistent random-access kernel is used
     uint64_t sweep_tail = 1ull << 22;   // stragglers of a sweep are finished one lane each (C3, ms per batch: 2^20 214.0, 2^22 213.4, 2^24 213.7, 2^26 213.8)
@@ -255,7 +255,7 @@ extern "C" vlg_status vlg_workspace_set_option(vlg_workspace* ws, const char* na
     if (!strcmp(name, "sweep")) { ws->sweep = value != 0; return VLG_OK; }
     if (!strcmp(name, "sweep_min")) { ws->sweep_min = (uint64_t)value; return VLG_OK; }
     if (!strcmp(name, "global_sort_min")) { ws->global_sort_min = (uint64_t)value; return VLG_OK; }
-    if (!strcmp(name, "list_sort")) { ws->list_sort = value != 0; return VLG_OK; }
+    if (!strcmp(name, "list_sort")) { ws->list_sort = value > 2 ? 1 : (int)value; return VLG_OK; }
     if (!strcmp(name, "trail")) { ws->trail = value != 0; return VLG_OK; }
     if (!strcmp(name, "tuples")) { ws->tuples = value != 0; return VLG_OK; }
     if (!strcmp(name, "filter")) { ws->filter = value != 0; return VLG_OK; }
@@ -999,7 +999,7 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     } else if (lsp.ready) {
         // 32-bit positions: sorted inside every list (list_sort.hpp) -- 4 passes of 8 B per element instead of 6 of 16 B
         Timed t(ws, KS_SORT, 2ull * acc * sizeof(pos_t));
-        if (vlg_status ls = list_sort_enqueue(lsp, reinterpret_cast<uint32_t*>(Pa), reinterpret_cast<uint32_t*>(scratch), d_off64, bits, st)) return ls;
+        if (vlg_status ls = list_sort_enqueue(lsp, reinterpret_cast<uint32_t*>(Pa), reinterpret_cast<uint32_t*>(scratch), d_off64, bits, st, ws->list_sort == 1)) return ls;
         A.used = sort_mark;                               // its tables are dead once its kernels have run (stream order)
         sorted = true;
         P_out = Pa;
@@ -2110,6 +2110,58 @@ extern "C" vlg_status vlg_queries_occurrences(const vlg_index* idx, const vlg_qu
 // =============================================================================================
 // K5 on caller-provided lists
 // =============================================================================================
+// K4 stand-alone: every list d_pos[off[l], off[l + 1]) sorted ascending in place (std::sort, index_sasearch.hpp:80) by the per-list sort
+// of the batch path (list_sort.hpp), for tests and callers that bring their own lists of 32-bit positions.
+extern "C" vlg_status vlg_sort_lists_u32(uint32_t* d_pos, const uint64_t* h_off, uint64_t n_lists, uint32_t position_bits, int mode,
+                                         uint64_t* n_clustered, void* stream)
+{
+    if (!h_off || (n_lists && h_off[n_lists] && !d_pos)) return fail(VLG_E_INVALID, "null argument");
+    if (position_bits < 1 || position_bits > 32 || (mode != 1 && mode != 2)) return fail(VLG_E_INVALID, "position_bits in [1,32], mode 1 or 2");
+    if (n_lists >= 0xFFFFFFF0ull || h_off[0] != 0) return fail(VLG_E_INVALID, "bad list offsets");
+    for (uint64_t l = 0; l < n_lists; ++l) if (h_off[l + 1] < h_off[l]) return fail(VLG_E_INVALID, "list offsets must ascend");
+    if (n_clustered) *n_clustered = 0;
+    const uint64_t total = h_off[n_lists];
+    if (!total) return VLG_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VLG_E_NO_DEVICE, "no HIP device available (the VLG library has no CPU fallback)");
+    hipStream_t st = (hipStream_t)stream;
+    HostPool pool;
+    void* d_mem = nullptr;
+    auto run = [&]() -> vlg_status {
+        HostPoolScope scope(&pool);
+        svec<uint64_t> off64(h_off, h_off + n_lists + 1);
+        uint64_t n_long = 0, n_tiles = 0, n_chunks = 0;
+        for (uint64_t l = 0; l < n_lists; ++l) {
+            const uint64_t len = off64[l + 1] - off64[l];
+            if (len > kSortTile) { const uint64_t t = (len + kSortTile - 1) / kSortTile; ++n_long; n_tiles += t; n_chunks += (t + kSortChunk - 1) / kSortChunk; }
+        }
+        const uint64_t bytes = align_up(total * 4, 256) + align_up((n_lists + 1) * 8, 256) + align_up(n_lists * 4, 256) + kSortClasses * 256 +
+                               list_sort_scratch_bytes(n_long, n_tiles, n_chunks) + 16 * 256 + 8192;
+        VLG_HIP_TRY(hipMalloc(&d_mem, bytes));
+        Arena A{reinterpret_cast<uint8_t*>(d_mem), bytes};
+        uint32_t* other = A.take<uint32_t>(total);
+        uint64_t* d_off = A.take<uint64_t>(n_lists + 1);
+        if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (vlg_sort_lists_u32)");
+        VLG_HIP_TRY(hipMemcpyAsync(d_off, off64.data(), (n_lists + 1) * 8, hipMemcpyHostToDevice, st));
+        ListSortPlan lp;
+        if (vlg_status s = list_sort_prepare(off64, (uint32_t)n_lists, A, st, lp)) return s;
+        if (vlg_status s = list_sort_enqueue(lp, d_pos, other, d_off, position_bits, st, mode == 1)) return s;
+        if (n_clustered && lp.n_long) {
+            std::vector<SortList> back(lp.n_long);
+            VLG_HIP_TRY(hipMemcpyAsync(back.data(), lp.d_longs, lp.n_long * sizeof(SortList), hipMemcpyDeviceToHost, st));
+            VLG_HIP_TRY(hipStreamSynchronize(st));
+            for (const SortList& L : back) *n_clustered += L.pad ? 1 : 0;
+        }
+        VLG_HIP_TRY(hipStreamSynchronize(st));
+        return VLG_OK;
+    };
+    vlg_status s;
+    try { s = run(); } catch (const std::bad_alloc&) { s = fail(VLG_E_OOM, "host memory (vlg_sort_lists_u32)"); }
+    if (d_mem) { (void)hipStreamSynchronize(st); (void)hipFree(d_mem); }
+    pool.release();
+    return s;
+}
+
 extern "C" vlg_status vlg_join_batch(const uint64_t* d_lists, const uint64_t* h_list_off, uint64_t n_lists, const uint64_t* h_join_list,
                                      const uint64_t* h_lo, const uint64_t* h_hi, const uint64_t* h_end_len, uint64_t n_joins,
                                      vlg_workspace* ws, vlg_result** out)
