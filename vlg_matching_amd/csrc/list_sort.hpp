@@ -182,18 +182,18 @@ struct SortList { uint64_t begin; uint32_t len, tile0, chunk0, pad; };      // a
 //  strides over the tiles and leaves at once when *any_flagged is zero, which is the common case: no clustered list in the batch)
 __global__ void __launch_bounds__(256) list_sort_hist_kernel(const uint32_t* __restrict__ in, const SortList* __restrict__ lists,
                                                              const uint32_t* __restrict__ tile_list, uint32_t n_tiles, uint32_t shift,
-                                                             uint32_t mask, uint16_t* __restrict__ hist, bool flagged_only, const uint32_t* __restrict__ any_flagged)
+                                                             uint32_t mask, uint16_t* __restrict__ hist, bool flagged_only, const uint32_t* __restrict__ any_flagged,
+                                                             const uint2* __restrict__ tile_desc /* {first key in the batch's array, keys} */)
 {
     __shared__ uint32_t h[256];
     if (flagged_only && *any_flagged == 0) return;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const SortList L = lists[tile_list[t]];
-        if (flagged_only && !L.pad) continue;
-        const uint32_t first = (t - L.tile0) * kSortTile;
-        const uint32_t cnt = L.len - first < kSortTile ? L.len - first : kSortTile;
+        if (flagged_only && !lists[tile_list[t]].pad) continue;
+        const uint2 d = tile_desc[t];                                 // one load in front of the keys, not tile -> list -> keys
+        const uint32_t cnt = d.y;
         h[threadIdx.x] = 0;
         __syncthreads();
-        const uint32_t* src = in + L.begin + first;
+        const uint32_t* src = in + d.x;
 #pragma unroll
         for (uint32_t i = 0; i < kSortTile / 256; ++i) {
             const uint32_t e = i * 256 + threadIdx.x;
@@ -280,7 +280,8 @@ __global__ void __launch_bounds__(256) list_sort_prefix_kernel(const uint16_t* _
 __global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                                 const SortList* __restrict__ lists, const uint32_t* __restrict__ tile_list,
                                                                 uint32_t n_tiles, uint32_t shift, uint32_t dbits,
-                                                                const uint32_t* __restrict__ pref, bool flagged_only, const uint32_t* __restrict__ any_flagged)
+                                                                const uint32_t* __restrict__ pref, bool flagged_only, const uint32_t* __restrict__ any_flagged,
+                                                                const uint2* __restrict__ tile_desc, const uint32_t* __restrict__ tile_base /* where the tile's list starts */)
 {
     constexpr uint32_t kItems = kSortTile / 256;
     using Rank = rocprim::block_radix_rank<256, 8, rocprim::block_radix_rank_algorithm::match>;
@@ -294,12 +295,11 @@ __global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* 
     __shared__ uint32_t first[256];
     if (flagged_only && *any_flagged == 0) return;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const SortList L = lists[tile_list[t]];
-        if (flagged_only && !L.pad) continue;
-        const uint32_t begin = (t - L.tile0) * kSortTile;
-        const uint32_t cnt = L.len - begin < kSortTile ? L.len - begin : kSortTile;
+        if (flagged_only && !lists[tile_list[t]].pad) continue;
+        const uint2 d = tile_desc[t];
+        const uint32_t cnt = d.y;
         const uint32_t mask = (1u << dbits) - 1u;
-        const uint32_t* src = in + L.begin + begin;
+        const uint32_t* src = in + d.x;
         const uint32_t wbase = (threadIdx.x >> 6) * (64 * kItems) + (threadIdx.x & 63);
         uint32_t keys[kItems];
         unsigned int ranks[kItems];
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* 
         for (uint32_t i = 0; i < kItems; ++i) s_keys[ranks[i]] = keys[i];
         __syncthreads();
         const uint32_t* pf = pref + (uint64_t)t * 256;
-        uint32_t* dst = out + L.begin;
+        uint32_t* dst = out + tile_base[t];
 #pragma unroll
         for (uint32_t i = 0; i < kItems; ++i) {
             const uint32_t p = i * 256 + threadIdx.x;                            // neighbouring lanes write neighbouring keys of a run
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_e
 
 inline uint64_t list_sort_scratch_bytes(uint64_t n_long, uint64_t n_tiles, uint64_t n_chunks)
 {
-    return n_long * sizeof(SortList) + (n_tiles + n_chunks) * 4 + n_tiles * 256 * 6 + n_chunks * 256 * 4 + (n_tiles * kWinPerTile + 1) * 13 + 12 * 256;
+    return n_long * sizeof(SortList) + (n_tiles + n_chunks) * 4 + n_tiles * 256 * 6 + n_chunks * 256 * 4 + (n_tiles * kWinPerTile + 1) * 13 + n_tiles * 12 + 14 * 256;
 }
 
 // The host side comes in two halves so that the tables are built and uploaded BEFORE the lists exist (while locate still runs):
@@ -438,6 +438,8 @@ struct ListSortPlan {
     uint32_t *d_tile_list = nullptr, *d_chunk_list = nullptr, *d_tot = nullptr, *d_pref = nullptr, *d_win = nullptr;
     uint8_t* d_win_flag = nullptr;
     uint2* d_win_desc = nullptr;
+    uint2* d_tile_desc = nullptr;
+    uint32_t* d_tile_base = nullptr;
     uint32_t* d_any = nullptr;       // [0]: some list is flagged, [1]: some window is
     uint16_t* d_hist = nullptr;
 };
@@ -446,7 +448,8 @@ inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Ar
 {
     svec<uint32_t> small[kSortClasses];                            // <= kSortClassMax[c] elements
     svec<SortList> longs;
-    svec<uint32_t> tile_list, chunk_list;
+    svec<uint32_t> tile_list, chunk_list, tile_base;
+    svec<uint2> tile_desc;
     for (uint32_t l = 0; l < nd; ++l) {
         const uint64_t len = off64[l + 1] - off64[l];
         if (len <= 1) continue;
@@ -460,6 +463,12 @@ inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Ar
             const uint32_t m = (uint32_t)longs.size();
             longs.push_back(SortList{off64[l], (uint32_t)len, (uint32_t)tile_list.size(), (uint32_t)chunk_list.size(), 0});
             tile_list.insert(tile_list.end(), tiles, m);
+            if (off64[l] + len > 0xFFFFFFFFull) return fail(VLG_E_INTERNAL, "list sort: more than 2^32 keys");
+            for (uint32_t t = 0; t < tiles; ++t) {
+                const uint32_t first = t * kSortTile;
+                tile_desc.push_back(make_uint2((uint32_t)(off64[l] + first), std::min<uint32_t>((uint32_t)len - first, kSortTile)));
+            }
+            tile_base.insert(tile_base.end(), tiles, (uint32_t)off64[l]);
             chunk_list.insert(chunk_list.end(), chunks, m);
         }
     }
@@ -480,6 +489,8 @@ inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Ar
         lp.d_longs = A.take<SortList>(lp.n_long);
         lp.d_tile_list = A.take<uint32_t>(lp.n_tiles);
         lp.d_chunk_list = A.take<uint32_t>(lp.n_chunks);
+        lp.d_tile_desc = A.take<uint2>(lp.n_tiles);
+        lp.d_tile_base = A.take<uint32_t>(lp.n_tiles);
         lp.d_hist = A.take<uint16_t>((uint64_t)lp.n_tiles * 256);
         lp.d_tot = A.take<uint32_t>((uint64_t)lp.n_chunks * 256);
         lp.d_pref = A.take<uint32_t>((uint64_t)lp.n_tiles * 256);
@@ -491,6 +502,8 @@ inline vlg_status list_sort_prepare(const svec<uint64_t>& off64, uint32_t nd, Ar
         VLG_HIP_TRY(hipMemcpyAsync(lp.d_longs, longs.data(), lp.n_long * sizeof(SortList), hipMemcpyHostToDevice, st));
         VLG_HIP_TRY(hipMemcpyAsync(lp.d_tile_list, tile_list.data(), lp.n_tiles * 4, hipMemcpyHostToDevice, st));
         VLG_HIP_TRY(hipMemcpyAsync(lp.d_chunk_list, chunk_list.data(), lp.n_chunks * 4, hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemcpyAsync(lp.d_tile_desc, tile_desc.data(), lp.n_tiles * sizeof(uint2), hipMemcpyHostToDevice, st));
+        VLG_HIP_TRY(hipMemcpyAsync(lp.d_tile_base, tile_base.data(), lp.n_tiles * 4, hipMemcpyHostToDevice, st));
     }
     if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (list sort)");
     lp.ready = true;
@@ -517,11 +530,11 @@ inline vlg_status list_sort_enqueue(const ListSortPlan& lp, uint32_t* P, uint32_
     auto pass = [&](uint32_t shift, uint32_t dbits, bool flagged_only) {
         const uint32_t mask = (1u << dbits) - 1u;
         const dim3 gt(flagged_only ? std::min(lp.n_tiles, few) : lp.n_tiles), gc(flagged_only ? std::min(lp.n_chunks, few) : lp.n_chunks);
-        hipLaunchKernelGGL(list_sort_hist_kernel, gt, dim3(256), 0, st, src, lp.d_longs, lp.d_tile_list, lp.n_tiles, shift, mask, lp.d_hist, flagged_only, lp.d_any);
+        hipLaunchKernelGGL(list_sort_hist_kernel, gt, dim3(256), 0, st, src, lp.d_longs, lp.d_tile_list, lp.n_tiles, shift, mask, lp.d_hist, flagged_only, lp.d_any, lp.d_tile_desc);
         hipLaunchKernelGGL(list_sort_chunk_kernel, gc, dim3(256), 0, st, lp.d_hist, lp.d_longs, lp.d_chunk_list, lp.n_chunks, lp.d_tot, flagged_only, lp.d_any);
         hipLaunchKernelGGL(list_sort_scan_kernel, dim3(lp.n_long), dim3(256), 0, st, lp.d_longs, lp.n_long, lp.d_tot, flagged_only, lp.d_any);
         hipLaunchKernelGGL(list_sort_prefix_kernel, gc, dim3(256), 0, st, lp.d_hist, lp.d_longs, lp.d_chunk_list, lp.n_chunks, lp.d_tot, lp.d_pref, flagged_only, lp.d_any);
-        hipLaunchKernelGGL(list_sort_scatter_kernel, gt, dim3(256), 0, st, src, dst, lp.d_longs, lp.d_tile_list, lp.n_tiles, shift, dbits, lp.d_pref, flagged_only, lp.d_any);
+        hipLaunchKernelGGL(list_sort_scatter_kernel, gt, dim3(256), 0, st, src, dst, lp.d_longs, lp.d_tile_list, lp.n_tiles, shift, dbits, lp.d_pref, flagged_only, lp.d_any, lp.d_tile_desc, lp.d_tile_base);
         std::swap(src, dst);
     };
     static const bool windows = [] { const char* e = getenv("VLG_WINDOW_SORT"); return e ? e[0] != '0' : VLG_WINDOW_SORT != 0; }();

@@ -2122,6 +2122,7 @@ extern "C" vlg_status vlg_sort_lists_u32(uint32_t* d_pos, const uint64_t* h_off,
     if (n_clustered) *n_clustered = 0;
     const uint64_t total = h_off[n_lists];
     if (!total) return VLG_OK;
+    if (total > 0xFFFFFF00ull) return fail(VLG_E_UNSUPPORTED, "more than 2^32 keys in one vlg_sort_lists_u32 call: split the batch");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VLG_E_NO_DEVICE, "no HIP device available (the VLG library has no CPU fallback)");
     hipStream_t st = (hipStream_t)stream;
