@@ -42,4 +42,6 @@ step "resolve hop statistics"
 bash tools/prof_sq.sh C3 sq sq2 tcp
 for P in sq sq2 tcp; do cp gpurun_out/prof_sq_C3/$P.txt $O/pmc_${P}_bench_C3.txt; done
 step "SQ / TCP counter passes"
+bash tools/prof_c4.sh C4 r04 && cp gpurun_out/r04_kernel_stats_bench_C4.csv $O/kernel_stats_bench_C4.csv && cp gpurun_out/r04_bench_C4_under_rocprof.json $O/bench_C4_under_rocprof.json
+step "C4 kernel statistics"
 ls -la $O >> $O/log

@@ -492,7 +492,12 @@ __device__ __forceinline__ void pivot_ranges_rungs(const pos_t* __restrict__ P, 
 // window form an index range, which is marked in that list's activity bits; the hull of the range's positions is the
 // "element" followed to the next level (a superset of what the exact windows would mark, which is all the filter needs).
 struct PTask { uint32_t seg0, k, p, pad; };          // first segment of the query, sub-patterns, pivot level
-constexpr uint32_t kPivotRun = 64 * kPivotGroups;     // pivot elements per wave
+constexpr uint32_t kPivotRun = 64 * kPivotGroups;     // pivot elements per wave and turn
+#ifndef VLG_PIVOT_TURNS
+#define VLG_PIVOT_TURNS 1
+#endif
+constexpr uint32_t kPivotTurns = VLG_PIVOT_TURNS;     // runs a wave takes one after the other (round 4, C3: 1 -> 21.9 ms, 4 -> 24.1 ms: the task
+                                                      // look-up in front of a run is not what the kernel waits for; more, shorter waves win)
 
 template <typename pos_t, bool kRungs>
 __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restrict__ P, const pos_t* __restrict__ F /* fences of P, or null */,
@@ -503,13 +508,24 @@ __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restri
 {
     constexpr uint32_t G = kPivotGroups;
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t run = uniform(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (run >= task_run0[ntasks]) return;
-    const uint32_t t = wave_task_find(task_run0, ntasks, run);
-    const PTask tk = tasks[t];
-    const RSeg pv = segs[tk.seg0 + tk.p];
+    // a wave takes kPivotTurns consecutive runs (1: measured, see kPivotTurns)
+    const uint64_t run_first = uniform(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kPivotTurns;
+    const uint64_t total_runs = task_run0[ntasks];
+    if (run_first >= total_runs) return;
+    const uint64_t run_last = run_first + kPivotTurns < total_runs ? run_first + kPivotTurns : total_runs;
+    uint32_t t = wave_task_find(task_run0, ntasks, run_first);
+    uint64_t t_begin = task_run0[t], t_end = task_run0[t + 1];
+    PTask tk = tasks[t];
+    RSeg pv = segs[tk.seg0 + tk.p];
+#pragma unroll 1
+    for (uint64_t run = run_first; run < run_last; ++run) {
+    if (run >= t_end) {
+        do { ++t; t_begin = t_end; t_end = task_run0[t + 1]; } while (run >= t_end);
+        tk = tasks[t];
+        pv = segs[tk.seg0 + tk.p];
+    }
     const uint64_t len = pv.pend - pv.pbegin;
-    const uint64_t off0 = (run - task_run0[t]) * kPivotRun;
+    const uint64_t off0 = (run - t_begin) * kPivotRun;
     const uint64_t off1 = off0 + kPivotRun < len ? off0 + kPivotRun : len;
     uint64_t x[G];
     bool on0[G];
@@ -576,6 +592,7 @@ __global__ void __launch_bounds__(256) filter_pivot_kernel(const pos_t* __restri
             }
             follow(sg, a, b, on, lo_pos, hi_pos, l + 2 < tk.k);
         }
+    }
     }
 }
 
@@ -884,11 +901,11 @@ vlg_status filter_group(uint64_t n_positions /* every list element is smaller */
         for (const PTask& pt : ptasks) probes += (uint64_t)(segs[pt.seg0 + pt.p].pend - segs[pt.seg0 + pt.p].pbegin) * (pt.k >= 2 ? pt.k - 2 + (pt.p + 1 == pt.k ? 1 : 0) : 0);
         Timed t(ws, KS_FILTER_PIVOT, 16 * probes);
         if (ws->rungs && ws->pivot_rungs)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t, true>), dim3((uint32_t)((prun0.back() + 3) / 4)), dim3(256), 0, st, P,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t, true>), dim3((uint32_t)((prun0.back() + 4 * kPivotTurns - 1) / (4 * kPivotTurns))), dim3(256), 0, st, P,
                                static_cast<const pos_t*>(ws->fences), static_cast<const pos_t*>(ws->rungs), ws->rung_off, fg.d_segs, d_ptasks, d_prun0,
                                (uint32_t)ptasks.size(), fg.d_abits);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t, false>), dim3((uint32_t)((prun0.back() + 3) / 4)), dim3(256), 0, st, P,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(filter_pivot_kernel<pos_t, false>), dim3((uint32_t)((prun0.back() + 4 * kPivotTurns - 1) / (4 * kPivotTurns))), dim3(256), 0, st, P,
                                static_cast<const pos_t*>(ws->fences), (const pos_t*)nullptr, (const uint64_t*)nullptr, fg.d_segs, d_ptasks, d_prun0,
                                (uint32_t)ptasks.size(), fg.d_abits);
         VLG_HIP_TRY(hipGetLastError());

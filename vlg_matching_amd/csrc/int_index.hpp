@@ -255,22 +255,15 @@ template <class BV, bool kTrail, bool kAhead>
 __global__ void __launch_bounds__(256) int_sweep_first_kernel(IntView v, const uint64_t* __restrict__ l, const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t t0,
                                                               uint64_t total, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint32_t* __restrict__ out,
                                                               unsigned long long* __restrict__ stats, unsigned long long* __restrict__ n_done,
-                                                              const Block* __restrict__ member, uint64_t* __restrict__ rec)
+                                                              const Block* __restrict__ member, uint64_t* __restrict__ rec,
+                                                              const uint32_t* __restrict__ chunk_list)
 {
-    constexpr uint32_t kPer = 8;
+    constexpr uint32_t kPer = kSweepChunk / 256;
     __shared__ IntLds<BV> sZ;
-    __shared__ uint64_t s_first;
     stage_int(sZ, v);
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
-    for (uint64_t base = t0 + (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t lo = 0, hi = n_pat;                             // last list with out_off[p] <= base
-            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (out_off[mid] <= base) lo = mid; else hi = mid; }
-            s_first = lo;
-        }
-        __syncthreads();
-        uint64_t p = s_first;
+    for (uint64_t base = t0 + (uint64_t)blockIdx.x * kSweepChunk; base < total; base += (uint64_t)gridDim.x * kSweepChunk) {
+        uint64_t p = chunk_list[(base - t0) / kSweepChunk];         // the list of the chunk's first element (sweep_chunk_lists_kernel)
 #pragma unroll 1
         for (uint32_t i = 0; i < kPer; ++i) {
             const uint64_t t = base + i * 256 + threadIdx.x;
@@ -649,12 +642,14 @@ static vlg_status launch_int_locate_sweep_bv(const IntView& v, const uint64_t* d
     SweepKernels K;
     K.n = v.n;
     K.sigma = (uint32_t)v.sigma;
-    K.first = [&](uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out, unsigned long long* counter, const Block* mem, uint64_t* rc, bool ahead) {
+    K.first = [&](uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out, unsigned long long* counter, const Block* mem, uint64_t* rc, bool ahead,
+                  uint32_t* chunk_list) {
+        launch_sweep_chunk_lists(d_out_off, n_pat, t0, t1, chunk_list, stream);
         const dim3 g = grid_of((t1 - t0 + 7) / 8, 8192);
         uint32_t* o = static_cast<uint32_t*>(out);
-        if (mem && ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<BV, true, true>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
-        else if (mem) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<BV, true, false>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<BV, false, false>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc);
+        if (mem && ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<BV, true, true>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc, chunk_list);
+        else if (mem) hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<BV, true, false>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc, chunk_list);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(int_sweep_first_kernel<BV, false, false>), g, dim3(256), 0, stream, v, d_l, d_out_off, n_pat, t0, t1, val, key, o, d_stats, counter, mem, rc, chunk_list);
     };
     K.step = [&](uint64_t* val, uint16_t* key, uint64_t alive, uint32_t step, void* out, unsigned long long* counter, const Block* mem, uint64_t* rc, uint64_t t0, bool probed) {
         const dim3 g = grid_of(alive, 4096);

@@ -407,6 +407,13 @@ __device__ __forceinline__ uint32_t seg_find(const uint32_t* __restrict__ seg_be
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (seg_begin[mid] <= slot) lo = mid; else hi = mid; }
     return lo;
 }
+// the same for a whole wave asking about one slot (all 64 lanes call it): three rounds of 64 probes instead of a chain of seventeen
+// dependent loads in front of the wave's run
+__device__ __forceinline__ uint32_t wave_seg_find(const uint32_t* __restrict__ seg_begin, uint32_t nseg, uint64_t slot)
+{
+    const uint32_t lb = wave_kary_lower_bound<uint32_t>(seg_begin, 0, nseg, slot + 1);       // first segment that begins behind the slot
+    return uniform(lb ? lb - 1 : 0u);
+}
 
 // Feasibility of every slot is ONE BIT; "nearest feasible slot at or after j" is a successor query on a hierarchical
 // bitset: level 0 = the feasibility bits, bit i of level l+1 = (word i of level l != 0).  A query reads one word per
@@ -528,7 +535,7 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
     if (wave * kRun >= (uint64_t)(r1 - r0)) return;
     const uint32_t run_begin = r0 + (uint32_t)wave * kRun;
     const uint32_t run_end = r1 - run_begin > kRun ? run_begin + kRun : r1;
-    uint32_t s_w = seg_find(seg_begin, nseg, run_begin);          // wave-uniform: segment of `base`
+    uint32_t s_w = wave_seg_find(seg_begin, nseg, run_begin);     // wave-uniform: segment of `base`
     uint32_t seg_end = seg_begin[s_w + 1];
     SegMeta m = sm[s_w], nx = sm[m.next];
     uint32_t hint_seg = kNone, hint = 0;                           // answer of the last lane of the previous step and its segment
@@ -637,7 +644,7 @@ __global__ void __launch_bounds__(256) join_jump_kernel(const pos_t* __restrict_
     if (run_begin >= r1) return;
     const uint64_t run_end = run_begin + kRun < r1 ? run_begin + kRun : r1;
     pos_t* tile = s_tile[wv];
-    uint32_t s = uniform(seg_find(seg_begin, nseg, run_begin));
+    uint32_t s = wave_seg_find(seg_begin, nseg, run_begin);
     uint64_t cur = run_begin;
     while (cur < run_end) {
         while (seg_begin[s + 1] <= cur) ++s;
@@ -874,7 +881,7 @@ __global__ void __launch_bounds__(256) join_gather_kernel(const pos_t* __restric
     const uint64_t run_begin = r0 + wave * kRun;
     const bool live = run_begin < r1;                      // (no early return: every wave of the workgroup reaches the barriers below)
     const uint64_t run_end = !live ? run_begin : (run_begin + kRun < r1 ? run_begin + kRun : r1);
-    uint32_t s_w = live ? seg_find(seg_begin, nseg, run_begin) : 0;
+    uint32_t s_w = live ? wave_seg_find(seg_begin, nseg, run_begin) : 0;       // (`live` is wave-uniform)
     unsigned long long local = 0;
     for (uint64_t base = run_begin; base < run_end; base += 64) {
         const uint64_t e = base + lane;

@@ -798,6 +798,17 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
     block_add<3>(v, dst);
 }
 
+__global__ void __launch_bounds__(256) sweep_chunk_lists_kernel(const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t t0, uint64_t t1,
+                                                                uint32_t* __restrict__ chunk_list)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t base = t0 + c * kSweepChunk;
+    if (base >= t1) return;
+    uint64_t lo = 0, hi = n_pat;                                                 // last list with out_off[p] <= base
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (out_off[mid] <= base) lo = mid; else hi = mid; }
+    chunk_list[c] = (uint32_t)lo;
+}
+
 // Round 0 without the pass that would write the elements' words first and the read that would fetch them again: an element's word
 // follows from its place -- slot t - t0, SA index l[list] + (t - first slot of the list) -- so a workgroup looks its list up once per
 // 2048 consecutive elements (as sweep_init_kernel does) and walks them at once.
@@ -806,27 +817,20 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
                                                           uint64_t t0, uint64_t total, uint64_t* __restrict__ val, uint16_t* __restrict__ key,
                                                           pos_t* __restrict__ out, unsigned long long* __restrict__ stats,
                                                           unsigned long long* __restrict__ n_done, const Block* __restrict__ member,
-                                                          uint64_t* __restrict__ rec)
+                                                          uint64_t* __restrict__ rec, const uint32_t* __restrict__ chunk_list)
 {
     __shared__ WalkLds<BV> s;
-    __shared__ uint64_t s_first;
     __shared__ ListStage s_lists;
     stage_walk(s, iv);
     using sample_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
     using Sampling = typename std::conditional<kTextOrder, TextOrderSampling<sample_t>, SaOrderSampling<sample_t>>::type;
     const Sampling sampling(iv);
     constexpr uint32_t kShift = kWide ? 33 : 32;
-    constexpr uint32_t kPer = 8;
+    constexpr uint32_t kPer = kSweepChunk / 256;
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
-    for (uint64_t base = t0 + (uint64_t)blockIdx.x * 256 * kPer; base < total; base += (uint64_t)gridDim.x * 256 * kPer) {
-        __syncthreads();                                                         // (s_first of the previous turn has been read)
-        if (threadIdx.x == 0) {
-            uint64_t lo = 0, hi = n_pat;
-            while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (out_off[mid] <= base) lo = mid; else hi = mid; }
-            s_first = lo;
-        }
-        __syncthreads();
-        uint64_t p = s_first;
+    for (uint64_t base = t0 + (uint64_t)blockIdx.x * kSweepChunk; base < total; base += (uint64_t)gridDim.x * kSweepChunk) {
+        __syncthreads();                                                         // (the lists staged for the previous turn have been read)
+        uint64_t p = chunk_list[(base - t0) / kSweepChunk];                      // the list of the chunk's first element (sweep_chunk_lists_kernel)
         const uint64_t end = base + 256 * kPer < total ? base + 256 * kPer : total;
         const bool staged = kStageLists && stage_lists(s_lists, out_off, l, n_pat, p, end);
         uint32_t q = 0;
@@ -1207,6 +1211,13 @@ size_t sweep_temp_bytes(uint64_t total, uint32_t sigma, hipStream_t stream)
 // temp (sweep_temp_bytes), counter (8 B, zeroed here).
 // The sweep's driver: rounds, partitions, records and the stragglers' slices for ANY index that can launch the three kernels of
 // SweepKernels (kernels.hpp) -- the byte index below, the integer-alphabet index in int_index.hpp.
+void launch_sweep_chunk_lists(const uint64_t* d_out_off, uint64_t n_pat, uint64_t t0, uint64_t t1, uint32_t* chunk_list, hipStream_t stream)
+{
+    const uint64_t chunks = (t1 - t0 + kSweepChunk - 1) / kSweepChunk;
+    if (!chunks) return;
+    hipLaunchKernelGGL(sweep_chunk_lists_kernel, dim3((uint32_t)((chunks + 255) / 256)), dim3(256), 0, stream, d_out_off, n_pat, t0, t1, chunk_list);
+}
+
 template <typename pos_t, bool kWide>
 vlg_status run_locate_sweep(const SweepKernels& K, const uint64_t* d_l, const uint64_t* d_out_off, uint64_t n_pat, uint64_t total,
                             pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
@@ -1250,7 +1261,7 @@ vlg_status run_locate_sweep(const SweepKernels& K, const uint64_t* d_l, const ui
         while (alive > tail_threshold && step < 0xFFFFFFu) {
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, 8, stream));
             if (timer) timer->begin(0);
-            if (fused_first && step == 0) K.first(t0, t1, val_a, key_a, out, d_counter, member, rec, ahead);      // round 0 makes the elements' words itself
+            if (fused_first && step == 0) K.first(t0, t1, val_a, key_a, out, d_counter, member, rec, ahead, reinterpret_cast<uint32_t*>(val_b));      // round 0 makes the elements' words itself
             else K.step(val_a, key_a, alive, step, out, d_counter, member, rec, t0, ahead && fused_first && step == 1);
             if (timer) timer->end(0);
             VLG_HIP_TRY(hipGetLastError());
@@ -1337,11 +1348,13 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     SweepKernels K;
     K.n = iv.n;
     K.sigma = iv.sigma;
-    K.first = [&](uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out_, unsigned long long* counter, const Block* mem, uint64_t* rc, bool ahead) {
+    K.first = [&](uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out_, unsigned long long* counter, const Block* mem, uint64_t* rc, bool ahead,
+                  uint32_t* chunk_list) {
         pos_t* out = static_cast<pos_t*>(out_);
+        launch_sweep_chunk_lists(d_out_off, n_pat, t0, t1, chunk_list, stream);
         const dim3 grid_first(grid_for((t1 - t0 + 7) / 8, 8192));
-#define VLG_FIRST(BV, TR, TO) do { if (ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, TR>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val, key, out, d_stats, counter, mem, rc); \
-                                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, false>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val, key, out, d_stats, counter, mem, rc); } while (0)
+#define VLG_FIRST(BV, TR, TO) do { if (ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, TR>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val, key, out, d_stats, counter, mem, rc, chunk_list); \
+                                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, false>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val, key, out, d_stats, counter, mem, rc, chunk_list); } while (0)
 #define VLG_FIRST_BV(TR, TO) do { if (rrr) VLG_FIRST(RrrBV, TR, TO); else VLG_FIRST(PlainBV, TR, TO); } while (0)
         if (text_order) { if (mem) VLG_FIRST_BV(true, true); else VLG_FIRST_BV(false, true); }
         else { if (mem) VLG_FIRST_BV(true, false); else VLG_FIRST_BV(false, false); }

@@ -33,11 +33,16 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
                                const std::function<vlg_status()>* while_first_step = nullptr);
 // The three launches of a sorted sweep over some index; run_locate_sweep owns the rounds, the partitions, the member bit-vector, the
 // records and their resolution.  `out` is the sweep's slice of the position array (pos_t*), `rec` null when no LF step is shared.
+constexpr uint32_t kSweepChunk = 2048;          // elements a workgroup of the first round takes per turn
+// the list that holds the first element of every chunk of a sweep [t0, t1): looked up for all chunks at once, in parallel, instead of by
+// one lane of every workgroup in front of its work (a binary search is seventeen dependent loads)
+void launch_sweep_chunk_lists(const uint64_t* d_out_off, uint64_t n_pat, uint64_t t0, uint64_t t1, uint32_t* chunk_list, hipStream_t stream);
 struct SweepKernels {
     uint64_t n = 0;
     uint32_t sigma = 0;                  // partition keys are the symbols 0 .. sigma - 1 (16 bits at most); sigma = finished
     // round 0 of the elements [t0, t1): their words follow from their places (lists l / out_off are the launcher's business)
-    std::function<void(uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out, unsigned long long* n_done, const Block* member, uint64_t* rec, bool ahead)> first;
+    std::function<void(uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out, unsigned long long* n_done, const Block* member, uint64_t* rec, bool ahead,
+                       uint32_t* chunk_list /* scratch, one word per kSweepChunk elements: sweep_chunk_lists_kernel */)> first;
     // one round of the elements val / key [0, alive)
     std::function<void(uint64_t* val, uint16_t* key, uint64_t alive, uint32_t step, void* out, unsigned long long* n_done, const Block* member, uint64_t* rec, uint64_t t0,
                        bool probed)> step;
