@@ -400,6 +400,11 @@ __device__ __forceinline__ bool gap_window<uint32_t>(uint64_t x, uint64_t lo, ui
 // Slots are dealt to waves in contiguous runs so a wave can carry the segment it is in and the last answer
 // of its searches from one 64-slot step to the next.
 constexpr uint32_t kRun = 2048;
+#ifndef VLG_LINK_RUN
+#define VLG_LINK_RUN 2048
+#endif
+constexpr uint32_t kLinkRun = VLG_LINK_RUN;      // slots a wave of the link pass takes (round 4, C3: 2048 -> 21.3 ms, 4096 -> 21.9 ms: what stands in front of
+                                                 // a run -- segment, metadata, the first fence -- is not what the pass waits for; it is issue-bound)
 
 __device__ __forceinline__ uint32_t seg_find(const uint32_t* __restrict__ seg_begin, uint32_t nseg, uint64_t slot)
 {
@@ -532,9 +537,9 @@ __global__ void __launch_bounds__(256) join_link_kernel(const pos_t* __restrict_
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wave * kRun >= (uint64_t)(r1 - r0)) return;
-    const uint32_t run_begin = r0 + (uint32_t)wave * kRun;
-    const uint32_t run_end = r1 - run_begin > kRun ? run_begin + kRun : r1;
+    if (wave * kLinkRun >= (uint64_t)(r1 - r0)) return;
+    const uint32_t run_begin = r0 + (uint32_t)wave * kLinkRun;
+    const uint32_t run_end = r1 - run_begin > kLinkRun ? run_begin + kLinkRun : r1;
     uint32_t s_w = wave_seg_find(seg_begin, nseg, run_begin);     // wave-uniform: segment of `base`
     uint32_t seg_end = seg_begin[s_w + 1];
     SegMeta m = sm[s_w], nx = sm[m.next];

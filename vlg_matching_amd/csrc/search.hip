@@ -582,7 +582,7 @@ constexpr uint32_t kStatsChecksum = 8, kStatsWords = kStatsChecksum + kChecksumS
 
 namespace {
 
-inline uint32_t runs_grid(uint64_t slots) { return (uint32_t)((((slots + kRun - 1) / kRun) + 3) / 4); }   // 4 waves per workgroup
+inline uint32_t runs_grid(uint64_t slots, uint32_t run = kRun) { return (uint32_t)((((slots + run - 1) / run) + 3) / 4); }   // 4 waves per workgroup
 
 inline uint32_t grid_for(uint64_t n, uint32_t cap = 16384) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, cap)); }
 
@@ -1408,10 +1408,10 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
         if (b1 > b0) {
             Timed t(ws, KS_JOIN_LINK, 8ull * (b1 - b0));
             if (dist == 1)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t, true>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, F, d_segb, nlive, d_sm,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t, true>), dim3(runs_grid(b1 - b0, kLinkRun)), dim3(256), 0, st, P, F, d_segb, nlive, d_sm,
                                    (uint32_t)b0, (uint32_t)b1, fref, lvl_ptr[0], endp, link);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t, false>), dim3(runs_grid(b1 - b0)), dim3(256), 0, st, P, F, d_segb, nlive, d_sm,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(join_link_kernel<pos_t, false>), dim3(runs_grid(b1 - b0, kLinkRun)), dim3(256), 0, st, P, F, d_segb, nlive, d_sm,
                                    (uint32_t)b0, (uint32_t)b1, fref, lvl_ptr[0], endp, link);
         }
         if (vlg_status s = summarize_class(dist)) return s;
