@@ -876,7 +876,10 @@ constexpr uint32_t kResolveHops = 64;
 // A workgroup takes kResolveChunk CONSECUTIVE records per turn (not every gridDim-th group of 256): consecutive elements of a list
 // that read the same symbol in front of them follow consecutive elements of another list, so the lines a wave fetches for its hops
 // are the lines the next waves of the same chunk need -- through the CU's own L1 when they belong to one workgroup.
-constexpr uint32_t kResolveChunk = 4096;
+#ifndef VLG_RESOLVE_CHUNK
+#define VLG_RESOLVE_CHUNK 4096
+#endif
+constexpr uint32_t kResolveChunk = VLG_RESOLVE_CHUNK;
 template <typename pos_t, bool kWide>
 __global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict__ rec, uint64_t count, pos_t* __restrict__ out,
                                                             unsigned long long* __restrict__ n_open, uint32_t round, bool diag)
