@@ -778,6 +778,10 @@ __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds
     }
 }
 
+#ifndef VLG_SWEEP_PAIRS
+#define VLG_SWEEP_PAIRS 1
+#endif
+constexpr bool kSweepPairs = VLG_SWEEP_PAIRS != 0;
 template <class BV, typename pos_t, bool kTrail, bool kWide, bool kTextOrder>
 __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint64_t count,
                                                          uint32_t step, pos_t* __restrict__ out,
@@ -791,11 +795,91 @@ __global__ void __launch_bounds__(256) sweep_step_kernel(IndexView iv, uint64_t*
     using Sampling = typename std::conditional<kTextOrder, TextOrderSampling<sample_t>, SaOrderSampling<sample_t>>::type;
     const Sampling sampling(iv);
     uint32_t n_lv = 0, n_lf = 0, n_fin = 0;
+    // (pairs of elements as in round 0 -- sweep_first_pair -- were measured here too, on C4: nothing; the later rounds' elements are sparse)
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (uint64_t)gridDim.x * blockDim.x)
         sweep_element<BV, pos_t, kTrail, kWide>(iv, s, sampling, e, val[e], val, key, step, out, member, rec, slot0, n_lv, n_lf, n_fin, probed);
     unsigned long long v[3] = {n_lf, n_lv, n_fin};
     unsigned long long* const dst[3] = {&stats[0], &stats[1], n_done};
     block_add<3>(v, dst);
+}
+
+// Two elements of round 0 side by side (plain bit-vectors): every tree level and the look-ahead probe of both are loaded before either
+// is used, so a lane has two dependent chains in flight instead of one (the kernel runs at full occupancy on 46 registers and waits
+// ~1 us per wave-wide dependent load: more waves cannot come, more loads per wave can).  Same outcome as two sweep_element calls.
+template <typename pos_t, bool kTrail, bool kWide, bool kAhead, class Sampling>
+__device__ __forceinline__ void sweep_first_pair(const IndexView& iv, const WalkLds<PlainBV>& s, const Sampling& sampling, bool onA, uint64_t eA, uint64_t wA,
+                                                 bool onB, uint64_t eB, uint64_t wB, uint64_t* __restrict__ val, uint16_t* __restrict__ key,
+                                                 pos_t* __restrict__ out, const Block* __restrict__ member, uint64_t* __restrict__ rec, uint64_t slot0,
+                                                 uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin)
+{
+    constexpr uint32_t kShift = kWide ? 33 : 32;
+    constexpr uint64_t kPosMask = (1ull << kShift) - 1;
+    using walk_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
+    const uint64_t iA = wA & kPosMask, iB = wB & kPosMask;
+    uint64_t sv = 0;
+    if (onA && sampling.probe(iA, sv)) {                                     // csa_wt.hpp:343-347 (round 0: no steps yet)
+        if (kTrail) rec[slot0 + (wA >> kShift)] = sv; else out[wA >> kShift] = (pos_t)sv;
+        key[eA] = (uint16_t)iv.sigma; ++n_fin; onA = false;
+    }
+    if (onB && sampling.probe(iB, sv)) {
+        if (kTrail) rec[slot0 + (wB >> kShift)] = sv; else out[wB >> kShift] = (pos_t)sv;
+        key[eB] = (uint16_t)iv.sigma; ++n_fin; onB = false;
+    }
+    if (kTrail) {                                                            // still walking (no pass clears the records beforehand)
+        if (onA) rec[slot0 + (wA >> kShift)] = ~0ull;
+        if (onB) rec[slot0 + (wB >> kShift)] = ~0ull;
+    }
+    // inverse_select of both (wt_pc.hpp:385-402), level by level
+    uint32_t vA = 0, vB = 0, cA = 0, cB = 0;
+    walk_t pA = (walk_t)iA, pB = (walk_t)iB;
+    bool a = onA, b = onB;
+    while (a || b) {
+        const DNode ndA = s.nodes[vA], ndB = s.nodes[vB];
+        uint32_t blkA, offA, blkB, offB;
+        split224((uint64_t)pA, blkA, offA);
+        split224((uint64_t)pB, blkB, offB);
+        BlockRegs rA, rB;
+        if (a) rA = load_block(iv.blocks, ndA.base + blkA);
+        if (b) rB = load_block(iv.blocks, ndB.base + blkB);
+        if (a) {
+            uint32_t bit;
+            const walk_t r1 = (walk_t)block_rank_bit(rA, offA, bit);
+            ++n_lv;
+            pA = bit ? r1 : pA - r1;
+            const uint32_t ch = bit ? ndA.child[1] : ndA.child[0];
+            if (ch & kLeafFlag) { cA = ch & ~kLeafFlag; a = false; } else vA = ch;
+        }
+        if (b) {
+            uint32_t bit;
+            const walk_t r1 = (walk_t)block_rank_bit(rB, offB, bit);
+            ++n_lv;
+            pB = bit ? r1 : pB - r1;
+            const uint32_t ch = bit ? ndB.child[1] : ndB.child[0];
+            if (ch & kLeafFlag) { cB = ch & ~kLeafFlag; b = false; } else vB = ch;
+        }
+    }
+    const uint64_t jA = s.C[cA] + (uint64_t)pA, jB = s.C[cB] + (uint64_t)pB;  // LF: suffix_array_helper.hpp:341-348
+    n_lf += (onA ? 1u : 0u) + (onB ? 1u : 0u);
+    bool stopA = false, stopB = false;
+    uint32_t ownA = 0, ownB = 0;
+    if (kTrail && kAhead) {                                                  // the look-ahead probes of both, their blocks in flight together
+        uint32_t blkA, offA, blkB, offB, bit;
+        split224(jA, blkA, offA);
+        split224(jB, blkB, offB);
+        BlockRegs rA, rB;
+        if (onA) rA = load_block(member, blkA);
+        if (onB) rB = load_block(member, blkB);
+        if (onA) { ownA = block_rank_bit(rA, offA, bit); stopA = bit != 0; }
+        if (onB) { ownB = block_rank_bit(rB, offB, bit); stopB = bit != 0; }
+    }
+    if (onA) {
+        if (stopA) { rec[slot0 + (wA >> kShift)] = (1ull << kShift) | ownA; key[eA] = (uint16_t)iv.sigma; ++n_fin; }
+        else { val[eA] = (wA & ~kPosMask) | jA; key[eA] = (uint16_t)cA; }
+    }
+    if (onB) {
+        if (stopB) { rec[slot0 + (wB >> kShift)] = (1ull << kShift) | ownB; key[eB] = (uint16_t)iv.sigma; ++n_fin; }
+        else { val[eB] = (wB & ~kPosMask) | jB; key[eB] = (uint16_t)cB; }
+    }
 }
 
 __global__ void __launch_bounds__(256) sweep_chunk_lists_kernel(const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t t0, uint64_t t1,
@@ -834,20 +918,34 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
         const uint64_t end = base + 256 * kPer < total ? base + 256 * kPer : total;
         const bool staged = kStageLists && stage_lists(s_lists, out_off, l, n_pat, p, end);
         uint32_t q = 0;
+        auto word_of = [&](uint64_t t) -> uint64_t {                            // slot << kShift | SA index of element t (t ascends from call to call)
+            uint64_t sai;
+            if (staged) {
+                while (s_lists.off[q + 1] <= t) ++q;
+                sai = s_lists.l[q] + (t - s_lists.off[q]);
+            } else {
+                while (out_off[p + 1] <= t) ++p;
+                sai = l[p] + (t - out_off[p]);
+            }
+            return ((t - t0) << kShift) | sai;
+        };
+        // (measured, round 4: C4 -- 33-bit indices, a deeper tree -- locate 98 -> 93 ms; C3 16.9 -> 17.4 ms: there the kernel has no issue slots
+        //  to spare and loses a wave per SIMD to the registers: pairs for wide indices only)
+        if constexpr (std::is_same<BV, PlainBV>::value && kSweepPairs && kWide) {
+            static_assert(kPer % 2 == 0, "elements are taken in pairs");
 #pragma unroll 1
-        for (uint32_t i = 0; i < kPer; ++i) {
-            const uint64_t t = base + i * 256 + threadIdx.x;
-            if (t < total) {
-                uint64_t sai;
-                if (staged) {
-                    while (s_lists.off[q + 1] <= t) ++q;
-                    sai = s_lists.l[q] + (t - s_lists.off[q]);
-                } else {
-                    while (out_off[p + 1] <= t) ++p;
-                    sai = l[p] + (t - out_off[p]);
-                }
-                const uint64_t v64 = ((t - t0) << kShift) | sai;
-                sweep_element<BV, pos_t, kTrail, kWide, true, kAhead>(iv, s, sampling, t - t0, v64, val, key, 0u, out, member, rec, t0, n_lv, n_lf, n_fin);
+            for (uint32_t i = 0; i < kPer; i += 2) {
+                const uint64_t tA = base + i * 256 + threadIdx.x, tB = tA + 256;
+                const bool onA = tA < total, onB = tB < total;
+                const uint64_t wA = onA ? word_of(tA) : 0, wB = onB ? word_of(tB) : 0;
+                sweep_first_pair<pos_t, kTrail, kWide, kAhead>(iv, s, sampling, onA, tA - t0, wA, onB, tB - t0, wB, val, key, out, member, rec, t0, n_lv, n_lf, n_fin);
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t i = 0; i < kPer; ++i) {
+                const uint64_t t = base + i * 256 + threadIdx.x;
+                if (t < total)
+                    sweep_element<BV, pos_t, kTrail, kWide, true, kAhead>(iv, s, sampling, t - t0, word_of(t), val, key, 0u, out, member, rec, t0, n_lv, n_lf, n_fin);
             }
         }
     }
