@@ -34,14 +34,17 @@ constexpr uint32_t kSortChunk = 32;           // tiles per chunk of the histogra
 constexpr uint32_t kBucketMaxOcc = 24;
 __device__ __forceinline__ uint32_t bin_at(uint32_t j) { return j + (j >> 5); }      // counters padded: thread t scans bins [t*k, t*k + k)
 
-template <uint32_t kThreads, uint32_t kItems, bool kInlineFallback>
+// kRankLoop: how the keys of a bin are put in order -- every key counts the smaller keys of its bin (a loop over one or two keys; what the
+// short lists' kernel takes: C4 7.0 -> 5.8 ms for the lists of 2049..4096 keys) or one lane per multi-key bin sorts it in place (fewer
+// registers: what the windows' kernel takes)
+template <uint32_t kThreads, uint32_t kItems, bool kInlineFallback, bool kRankLoop = false>
 struct BucketSort {
     using Load = rocprim::block_load<uint32_t, kThreads, kItems, rocprim::block_load_method::block_load_transpose>;
     using Store = rocprim::block_store<uint32_t, kThreads, kItems, rocprim::block_store_method::block_store_transpose>;
     using Sort = rocprim::block_radix_sort<uint32_t, kThreads, kItems>;
     static constexpr uint32_t kCap = kThreads * kItems, kPad = kCap + kCap / 32 + 1, kWaves = (kThreads + 63) / 64;
     static_assert(kCap < 0x10000u, "two 16-bit counts share one scan");
-    struct Buckets { uint32_t cnt[kPad]; uint32_t tmp[kCap]; uint32_t work[kCap / 2 + 2]; };
+    struct Buckets { uint32_t cnt[kPad]; uint32_t tmp[kCap]; uint32_t work[kRankLoop ? 1 : kCap / 2 + 2]; };
     union Radix { typename Load::storage_type load; typename Store::storage_type store; typename Sort::storage_type sort; };
     union Both { Buckets b; Radix r; };
     using Storage = typename std::conditional<kInlineFallback, Both, Buckets>::type;
@@ -121,7 +124,7 @@ struct BucketSort {
             for (uint32_t i = 0; i < kItems; ++i) {
                 const uint32_t at = bin_at(tid * kItems + i), c = s.cnt[at];
                 s.cnt[at] = run_;
-                if (c >= 2 && spread) s.work[at_work++] = (run_ << 8) | c;
+                if (!kRankLoop && c >= 2 && spread) s.work[at_work++] = (run_ << 8) | c;
                 run_ += c;
             }
             const uint32_t n_work = all_ >> 16;
@@ -131,6 +134,31 @@ struct BucketSort {
                 for (uint32_t i = 0; i < kItems; ++i)
                     if (i * kThreads + tid < len) s.tmp[s.cnt[bin_at(ba[i] >> 8)] + (ba[i] & 255u)] = key[i];
                 __syncthreads();
+                if constexpr (kRankLoop) {
+                    uint32_t fin[kItems];
+#pragma unroll
+                    for (uint32_t i = 0; i < kItems; ++i) {
+                        const uint32_t bn = ba[i] >> 8;
+                        const uint32_t s0 = s.cnt[bin_at(bn)], e0 = bn + 1 < kCap ? s.cnt[bin_at(bn + 1)] : len;
+                        const uint32_t mine = s0 + (ba[i] & 255u);
+                        uint32_t c = 0;
+                        if (i * kThreads + tid < len)
+                            for (uint32_t j = s0; j < e0; ++j) { const uint32_t v = s.tmp[j]; c += (v < key[i] || (v == key[i] && j < mine)) ? 1u : 0u; }
+                        fin[i] = s0 + c;
+                    }
+                    __syncthreads();
+                    uint32_t* outk = s.cnt;                                   // the counters are done with: the sorted keys line up here
+#pragma unroll
+                    for (uint32_t i = 0; i < kItems; ++i)
+                        if (i * kThreads + tid < len) outk[fin[i]] = key[i];
+                    __syncthreads();
+#pragma unroll
+                    for (uint32_t i = 0; i < kItems; ++i) {
+                        const uint32_t e = i * kThreads + tid;
+                        if (e < len) dst[e] = outk[e];
+                    }
+                    return true;
+                }
 #pragma unroll 1
                 for (uint32_t w = tid; w < n_work; w += kThreads) {
                     const uint32_t e = s.work[w], s0 = e >> 8, n = e & 255u;
@@ -165,7 +193,7 @@ template <uint32_t kThreads, uint32_t kItems>
 __global__ void __launch_bounds__(kThreads) list_sort_small_kernel(uint32_t* __restrict__ P, const uint64_t* __restrict__ off,
                                                                    const uint32_t* __restrict__ lists, uint32_t n_lists, uint32_t bits)
 {
-    using BS = BucketSort<kThreads, kItems, true>;
+    using BS = BucketSort<kThreads, kItems, true, true>;
     __shared__ typename BS::Storage s;
     __shared__ typename BS::Misc misc;
     if (blockIdx.x >= n_lists) return;
@@ -342,6 +370,9 @@ __global__ void __launch_bounds__(256) list_sort_scatter_kernel(const uint32_t* 
 #ifndef VLG_WINDOWS_PER_TILE
 #define VLG_WINDOWS_PER_TILE 2
 #endif
+#ifndef VLG_WINDOW_RANK_LOOP
+#define VLG_WINDOW_RANK_LOOP 0     /* measured on C3: work list 2.9 ms, rank loop 3.2 ms (96 registers, 4 spilled) */
+#endif
 #ifndef VLG_WINDOW_THREADS
 #define VLG_WINDOW_THREADS 256
 #endif
@@ -396,7 +427,7 @@ __global__ void __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_e
                                                                const uint2* __restrict__ desc, uint32_t n_windows, uint32_t bits,
                                                                uint8_t* __restrict__ win_flag, uint32_t* __restrict__ any /* [1]: windows flagged */)
 {
-    using BS = BucketSort<kWinThreads, kWinItems, false>;
+    using BS = BucketSort<kWinThreads, kWinItems, false, VLG_WINDOW_RANK_LOOP != 0>;
     __shared__ typename std::conditional<kRadix, typename BS::Radix, typename BS::Storage>::type s;
     __shared__ typename BS::Misc misc;
     if (kRadix && any[1] == 0) return;
