@@ -648,6 +648,11 @@ __global__ void filter_gather_counts_kernel(const uint32_t* __restrict__ task_ci
 // survivors of the chunk's segments -> Pc, in task order; run_cnt = the gathered counts, run_off = their exclusive scan.
 // A wave looks at kCompactRuns runs and works on the ones that have survivors.
 constexpr uint32_t kCompactRuns = 16;
+#ifndef VLG_SPARSE_TURN
+#define VLG_SPARSE_TURN 8
+#endif
+constexpr uint32_t kSparseTurn = VLG_SPARSE_TURN;      // survivors of a lane's half word moved per turn of the sparse path: their loads are in flight
+                                                       // together (round 4, C3, the class: 2 -> 15.7 ms, 4 -> 13.6, 8 -> 13.3)
 template <typename pos_t>
 __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __restrict__ P, const RSeg* __restrict__ segs,
                                                              const uint32_t* __restrict__ task_seg, const uint64_t* __restrict__ task_run0,
@@ -662,23 +667,34 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __rest
     if (r0 >= total) return;
     unsigned long long todo = __ballot(lane < kCompactRuns && r0 + lane < total && run_cnt[r0 + lane] != 0);
     uint32_t t = 0;
-    uint64_t t_end = 0;                                                          // runs before it belong to task t (or to none yet)
+    uint64_t t_begin = 0, t_end = 0;                                             // runs before t_end belong to task t (or to none yet)
     RSeg sg;
+    uint64_t ahead_run = ~0ull, ahead_words = 0;                                 // the activity words of the next run, asked for a run early
     while (todo) {
         const uint64_t run = r0 + (uint32_t)(__ffsll((long long)todo) - 1);
         todo &= todo - 1;
         if (run >= t_end) {                                                      // neighbouring runs mostly share their task
             t = wave_task_find(task_run0, ntasks, run);
+            t_begin = task_run0[t];
             t_end = task_run0[t + 1];
             sg = segs[task_seg[t]];
         }
         const uint64_t len = sg.pend - sg.pbegin;
-        const uint64_t off0 = (run - task_run0[t]) * kRun;
+        const uint64_t off0 = (run - t_begin) * kRun;
         const uint64_t off1 = off0 + kRun < len ? off0 + kRun : len;
         // the 32 activity words of the run in one load; every lane then knows where each word's survivors go
         const uint64_t w0 = (sg.abit + off0) >> 6;
         const uint32_t nw = (uint32_t)((off1 - off0 + 63) >> 6);
-        const uint64_t mine = lane < nw ? abits[w0 + lane] : 0;
+        const uint64_t mine = ahead_run == run ? ahead_words : (lane < nw ? abits[w0 + lane] : 0);
+        ahead_run = ~0ull;
+        if (todo) {                                                              // the next run with survivors, if it is of the same list:
+            const uint64_t nr = r0 + (uint32_t)(__ffsll((long long)todo) - 1);   // its words are in flight while this run's survivors move
+            if (nr < t_end) {
+                const uint64_t n0 = (nr - t_begin) * kRun, n1 = n0 + kRun < len ? n0 + kRun : len;
+                ahead_words = lane < (uint32_t)((n1 - n0 + 63) >> 6) ? abits[((sg.abit + n0) >> 6) + lane] : 0;
+                ahead_run = nr;
+            }
+        }
         uint32_t before = (uint32_t)__popcll(mine);                              // inclusive scan over the words
         for (int o = 1; o < 32; o <<= 1) { const uint32_t v = __shfl_up(before, o); if ((int)lane >= o) before += v; }
         before -= (uint32_t)__popcll(mine);
@@ -695,17 +711,21 @@ __global__ void __launch_bounds__(256) filter_compact_kernel(const pos_t* __rest
             for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
             uint32_t out = out0 + inc - cnt;
             const pos_t* __restrict__ src = P + sg.pbegin + off0 + 32ull * lane;
-            while (hb) {                                                         // two survivors per turn: both loads in flight
-                const uint32_t b0 = (uint32_t)__ffs((int)hb) - 1;
-                hb &= hb - 1;
-                const pos_t v0 = src[b0];
-                if (hb) {
-                    const uint32_t b1 = (uint32_t)__ffs((int)hb) - 1;
-                    hb &= hb - 1;
-                    const pos_t v1 = src[b1];
-                    Pc[out] = v0; Pc[out + 1] = v1;
-                    out += 2;
-                } else Pc[out++] = v0;
+            while (hb) {                                                         // kSparseTurn survivors per turn: their loads in flight together
+                pos_t v[kSparseTurn];
+                uint32_t got = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < kSparseTurn; ++u) {
+                    if (hb) {
+                        const uint32_t b = (uint32_t)__ffs((int)hb) - 1;
+                        hb &= hb - 1;
+                        v[u] = src[b];
+                        got = u + 1;
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kSparseTurn; ++u) if (u < got) Pc[out + u] = v[u];
+                out += got;
             }
             continue;
         }
