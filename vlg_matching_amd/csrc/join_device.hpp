@@ -872,49 +872,54 @@ __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restr
     }
 }
 
-// tuples of every match: walk the links from the level-0 element.  One thread per (query, match) slot of list 0.
+// tuples of every match: walk the links from the level-0 element.  One thread per MATCH of the chunk (match g belongs to the query q with
+// out_first[q] <= g < out_first[q + 1]; it is that query's match number g - out_first[q]) -- the kernel used to run over every slot of
+// every first list and let three quarters of its lanes find out that their slot held no match.
 // Results are written as wide as the positions are (ResultPiece::width); vlg_result_fetch widens them on the way to the host.
 template <typename pos_t>
-__global__ void __launch_bounds__(256) join_gather_kernel(const pos_t* __restrict__ P, const uint32_t* __restrict__ seg_begin, uint32_t nseg,
-                                                          const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm, uint64_t r0,
-                                                          uint64_t r1, const uint32_t* __restrict__ link, const uint32_t* __restrict__ mlist,
-                                                          const unsigned long long* __restrict__ counts, pos_t* __restrict__ out_first,
-                                                          pos_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
+__global__ void __launch_bounds__(256) join_gather_kernel(const pos_t* __restrict__ P, const SegMeta* __restrict__ sm, const QueryMeta* __restrict__ qm,
+                                                          const unsigned long long* __restrict__ first_of /* [nq] = qm[.].out_first, dense */, uint32_t nq,
+                                                          uint64_t n_matches, const uint32_t* __restrict__ link, const uint32_t* __restrict__ mlist,
+                                                          pos_t* __restrict__ out_first, pos_t* __restrict__ out_tuples, unsigned long long* __restrict__ checksum)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t run_begin = r0 + wave * kRun;
-    const bool live = run_begin < r1;                      // (no early return: every wave of the workgroup reaches the barriers below)
-    const uint64_t run_end = !live ? run_begin : (run_begin + kRun < r1 ? run_begin + kRun : r1);
-    uint32_t s_w = live ? wave_seg_find(seg_begin, nseg, run_begin) : 0;       // (`live` is wave-uniform)
+    const uint64_t run_begin = wave * kRun;
+    const bool live = run_begin < n_matches;               // (no early return: every wave of the workgroup reaches the barriers below)
+    const uint64_t run_end = !live ? run_begin : (run_begin + kRun < n_matches ? run_begin + kRun : n_matches);
+    // the query of the run's first match: the last one that starts at or before it (queries without matches start where their successor starts)
+    uint32_t q_w = 0;
+    if (live) {                                            // (`live` is wave-uniform)
+        const uint32_t ub = wave_kary_lower_bound<unsigned long long>(first_of, 0, nq, run_begin + 1);
+        q_w = uniform(ub ? ub - 1 : 0u);
+    }
     unsigned long long local = 0;
     for (uint64_t base = run_begin; base < run_end; base += 64) {
-        const uint64_t e = base + lane;
-        uint32_t s = s_w;
-        if (e < run_end) {
-            while (seg_begin[s + 1] <= e) ++s;
-            const SegMeta m = sm[s];
-            const uint64_t t = e - m.begin;
-            if (m.level == 0 && t < counts[m.query]) {
-                const QueryMeta Q = qm[m.query];
-                uint32_t el = mlist[e];                                // logical element of level 0
-                const pos_t first = P[phys_of(m, el)];
-                out_first[Q.out_first + t] = first;
-                local += first;
-                if (out_tuples) {                                      // null: first positions only (workspace option "tuples" = 0)
-                    pos_t* tp = out_tuples + Q.out_tuple + t * Q.k;
-                    tp[0] = first;
-                    uint32_t cur = Q.k > 1 ? link[el] : 0;
-                    uint32_t sg = m.next;
-                    for (uint32_t i = 1; i < Q.k; ++i) {
-                        const SegMeta mi = sm[sg];
-                        if (mi.dist == 0) { tp[i] = P[cur]; }          // link of a dist-1 element is a physical index
-                        else { tp[i] = P[phys_of(mi, cur)]; cur = link[cur]; sg = mi.next; }
-                    }
+        const uint64_t g = base + lane;
+        uint32_t q = q_w;
+        if (g < run_end) {
+            while (q + 1 < nq && first_of[q + 1] <= g) ++q;
+            const QueryMeta Q = qm[q];
+            const SegMeta m = sm[Q.seg0];
+            const uint64_t t = g - Q.out_first;
+            const uint32_t el = mlist[m.begin + t];                    // logical element of level 0
+            const pos_t first = P[phys_of(m, el)];
+            out_first[g] = first;
+            local += first;
+            if (out_tuples) {                                          // null: first positions only (workspace option "tuples" = 0)
+                pos_t* tp = out_tuples + Q.out_tuple + t * Q.k;
+                tp[0] = first;
+                uint32_t cur = Q.k > 1 ? link[el] : 0;
+                uint32_t sg = m.next;
+                for (uint32_t i = 1; i < Q.k; ++i) {
+                    const SegMeta mi = sm[sg];
+                    if (mi.dist == 0) { tp[i] = P[cur]; }              // link of a dist-1 element is a physical index
+                    else { tp[i] = P[phys_of(mi, cur)]; cur = link[cur]; sg = mi.next; }
                 }
             }
         }
-        s_w = __shfl(s, 0);
+        const uint32_t last = (uint32_t)((run_end - base < 64 ? run_end - base : 64) - 1);
+        q_w = __shfl(q, (int)last);                                    // the next step's matches come behind this step's last one
     }
     // one atomic per workgroup, spread over kChecksumSlots words (a single word takes ~90 atomics per microsecond; there are
     // 10^5..10^6 waves here); the host adds the slots up

@@ -1447,10 +1447,12 @@ vlg_status run_join_chunk(const vlg_queries* q, vlg_workspace* ws, vlg_result* r
         res->pieces.push_back(piece);
         jt.mark("  chunk: result malloc");
         VLG_HIP_TRY(hipMemcpyAsync(d_qm, qm.data(), nq * sizeof(QueryMeta), hipMemcpyHostToDevice, st));
+        svec<unsigned long long> first_of(nq);                      // where every query's matches start, dense (the counts have been read: their place is free)
+        for (uint32_t i = 0; i < nq; ++i) first_of[i] = qm[i].out_first;
+        VLG_HIP_TRY(hipMemcpyAsync(d_counts, first_of.data(), nq * 8, hipMemcpyHostToDevice, st));
         Timed t(ws, KS_GATHER, sizeof(pos_t) * (M + TV));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(runs_grid(lvl0_end - lvl0_begin)), dim3(256), 0, st, P, d_segb, nlive,
-                           d_sm, d_qm, lvl0_begin, lvl0_end, link, mlist, d_counts, static_cast<pos_t*>(piece.d_first),
-                           static_cast<pos_t*>(piece.d_tuples), d_stats + kStatsChecksum);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(join_gather_kernel<pos_t>), dim3(runs_grid(M)), dim3(256), 0, st, P, d_sm, d_qm, d_counts, nq, M, link, mlist,
+                           static_cast<pos_t*>(piece.d_first), static_cast<pos_t*>(piece.d_tuples), d_stats + kStatsChecksum);
         VLG_HIP_TRY(hipGetLastError());
     } else {
         res->pieces.push_back(piece);
