@@ -970,7 +970,7 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
 // stopped elements in (the per-round tails of its buffers, last round first, then first to last): 35.5 instead of 17.7 ms --
 // neighbours in SA order are not neighbours in slot order; (3) following the chains on a second stream beside the sweep's late rounds:
 // this kernel 18.0 -> 13.3 ms, but the rounds and their partitions slow down by 7 ms: the requests are conserved, not hidden.
-constexpr uint32_t kResolveHops = 64;
+constexpr uint32_t kResolveHops = 4096;       // (64 left 2·10⁵ of C3's 6·10⁸ pointers open -- runs of more than 64 occurrences side by side in the text -- and cost a second pass over all records: 1 ms)
 // A workgroup takes kResolveChunk CONSECUTIVE records per turn (not every gridDim-th group of 256): consecutive elements of a list
 // that read the same symbol in front of them follow consecutive elements of another list, so the lines a wave fetches for its hops
 // are the lines the next waves of the same chunk need -- through the CU's own L1 when they belong to one workgroup.
