@@ -888,17 +888,23 @@ __global__ void __launch_bounds__(256) join_gather_kernel(const pos_t* __restric
     const bool live = run_begin < n_matches;               // (no early return: every wave of the workgroup reaches the barriers below)
     const uint64_t run_end = !live ? run_begin : (run_begin + kRun < n_matches ? run_begin + kRun : n_matches);
     // the query of the run's first match: the last one that starts at or before it (queries without matches start where their successor starts)
-    uint32_t q_w = 0;
+    uint32_t q_w = 0, q_end = 0;                           // ... and the query of its last match: a lane looks its own query up between the two
     if (live) {                                            // (`live` is wave-uniform)
         const uint32_t ub = wave_kary_lower_bound<unsigned long long>(first_of, 0, nq, run_begin + 1);
         q_w = uniform(ub ? ub - 1 : 0u);
+        const uint32_t ue = wave_kary_lower_bound<unsigned long long>(first_of, 0, nq, run_end);
+        q_end = uniform(ue ? ue - 1 : 0u);
     }
     unsigned long long local = 0;
     for (uint64_t base = run_begin; base < run_end; base += 64) {
         const uint64_t g = base + lane;
         uint32_t q = q_w;
         if (g < run_end) {
-            while (q + 1 < nq && first_of[q + 1] <= g) ++q;
+            uint32_t hi = q_end;                                       // last query that starts at or before match g (a batch with few matches has
+            while (q < hi) {                                           // thousands of queries between two of them: no walk from query to query)
+                const uint32_t mid = q + ((hi - q + 1) >> 1);
+                if (first_of[mid] <= g) q = mid; else hi = mid - 1;
+            }
             const QueryMeta Q = qm[q];
             const SegMeta m = sm[Q.seg0];
             const uint64_t t = g - Q.out_first;
