@@ -721,11 +721,12 @@ template <class BV, typename pos_t, bool kTrail, bool kWide, bool kFirst = false
 __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds<BV>& s, const Sampling& sampling, uint64_t e, uint64_t v64,
                                               uint64_t* __restrict__ val, uint16_t* __restrict__ key, uint32_t step, pos_t* __restrict__ out,
                                               const Block* __restrict__ member, uint64_t* __restrict__ rec, uint64_t slot0,
-                                              uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin, bool probed = false)
+                                              uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin, bool probed = false, uint8_t* __restrict__ front = nullptr)
 {
     constexpr uint32_t kShift = kWide ? 33 : 32;
     constexpr uint64_t kPosMask = (1ull << kShift) - 1;
     uint64_t i = v64 & kPosMask;
+    uint8_t in_front = 0xFF;                             // (kFirst: the symbol in front of an element that stops on its first step)
     uint64_t sv = 0;
     uint32_t owner = 0;
     if (sampling.probe(i, sv)) {
@@ -771,11 +772,13 @@ __device__ __forceinline__ void sweep_element(const IndexView& iv, const WalkLds
             rec[slot0 + (v64 >> kShift)] = ((uint64_t)(step + 1) << kShift) | owner;
             key[e] = (uint16_t)iv.sigma;
             ++n_fin;
+            in_front = (uint8_t)c;
         } else {
             val[e] = (v64 & ~kPosMask) | j;
             key[e] = (uint16_t)c;
         }
     }
+    if (kTrail && kFirst && front) front[slot0 + (v64 >> kShift)] = in_front;
 }
 
 #ifndef VLG_SWEEP_PAIRS
@@ -810,12 +813,13 @@ template <typename pos_t, bool kTrail, bool kWide, bool kAhead, class Sampling>
 __device__ __forceinline__ void sweep_first_pair(const IndexView& iv, const WalkLds<PlainBV>& s, const Sampling& sampling, bool onA, uint64_t eA, uint64_t wA,
                                                  bool onB, uint64_t eB, uint64_t wB, uint64_t* __restrict__ val, uint16_t* __restrict__ key,
                                                  pos_t* __restrict__ out, const Block* __restrict__ member, uint64_t* __restrict__ rec, uint64_t slot0,
-                                                 uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin)
+                                                 uint32_t& n_lv, uint32_t& n_lf, uint32_t& n_fin, uint8_t* __restrict__ front)
 {
     constexpr uint32_t kShift = kWide ? 33 : 32;
     constexpr uint64_t kPosMask = (1ull << kShift) - 1;
     using walk_t = typename std::conditional<kWide, uint64_t, uint32_t>::type;
     const uint64_t iA = wA & kPosMask, iB = wB & kPosMask;
+    const bool hadA = onA, hadB = onB;
     uint64_t sv = 0;
     if (onA && sampling.probe(iA, sv)) {                                     // csa_wt.hpp:343-347 (round 0: no steps yet)
         if (kTrail) rec[slot0 + (wA >> kShift)] = sv; else out[wA >> kShift] = (pos_t)sv;
@@ -880,6 +884,10 @@ __device__ __forceinline__ void sweep_first_pair(const IndexView& iv, const Walk
         if (stopB) { rec[slot0 + (wB >> kShift)] = (1ull << kShift) | ownB; key[eB] = (uint16_t)iv.sigma; ++n_fin; }
         else { val[eB] = (wB & ~kPosMask) | jB; key[eB] = (uint16_t)cB; }
     }
+    if (kTrail && front) {                                                   // the symbol in front of an element that stopped on its first step
+        if (hadA) front[slot0 + (wA >> kShift)] = (onA && stopA) ? (uint8_t)cA : (uint8_t)0xFF;
+        if (hadB) front[slot0 + (wB >> kShift)] = (onB && stopB) ? (uint8_t)cB : (uint8_t)0xFF;
+    }
 }
 
 __global__ void __launch_bounds__(256) sweep_chunk_lists_kernel(const uint64_t* __restrict__ out_off, uint64_t n_pat, uint64_t t0, uint64_t t1,
@@ -901,7 +909,7 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
                                                           uint64_t t0, uint64_t total, uint64_t* __restrict__ val, uint16_t* __restrict__ key,
                                                           pos_t* __restrict__ out, unsigned long long* __restrict__ stats,
                                                           unsigned long long* __restrict__ n_done, const Block* __restrict__ member,
-                                                          uint64_t* __restrict__ rec, const uint32_t* __restrict__ chunk_list)
+                                                          uint64_t* __restrict__ rec, const uint32_t* __restrict__ chunk_list, uint8_t* __restrict__ front)
 {
     __shared__ WalkLds<BV> s;
     __shared__ ListStage s_lists;
@@ -938,14 +946,14 @@ __global__ void __launch_bounds__(256) sweep_first_kernel(IndexView iv, const ui
                 const uint64_t tA = base + i * 256 + threadIdx.x, tB = tA + 256;
                 const bool onA = tA < total, onB = tB < total;
                 const uint64_t wA = onA ? word_of(tA) : 0, wB = onB ? word_of(tB) : 0;
-                sweep_first_pair<pos_t, kTrail, kWide, kAhead>(iv, s, sampling, onA, tA - t0, wA, onB, tB - t0, wB, val, key, out, member, rec, t0, n_lv, n_lf, n_fin);
+                sweep_first_pair<pos_t, kTrail, kWide, kAhead>(iv, s, sampling, onA, tA - t0, wA, onB, tB - t0, wB, val, key, out, member, rec, t0, n_lv, n_lf, n_fin, front);
             }
         } else {
 #pragma unroll 1
             for (uint32_t i = 0; i < kPer; ++i) {
                 const uint64_t t = base + i * 256 + threadIdx.x;
                 if (t < total)
-                    sweep_element<BV, pos_t, kTrail, kWide, true, kAhead>(iv, s, sampling, t - t0, word_of(t), val, key, 0u, out, member, rec, t0, n_lv, n_lf, n_fin);
+                    sweep_element<BV, pos_t, kTrail, kWide, true, kAhead>(iv, s, sampling, t - t0, word_of(t), val, key, 0u, out, member, rec, t0, n_lv, n_lf, n_fin, false, front);
             }
         }
     }
@@ -978,6 +986,93 @@ constexpr uint32_t kResolveHops = 4096;       // (64 left 2·10⁵ of C3's 6·10
 #define VLG_RESOLVE_CHUNK 4096
 #endif
 constexpr uint32_t kResolveChunk = VLG_RESOLVE_CHUNK;
+// The first pass, regrouped.  The 64 consecutive elements a wave holds have ~20 different symbols in front of them, so the records they
+// follow lie in ~20 other lists, three side by side in each: ~40 lines per wave-wide hop (VLG_RESOLVE_STATS).  Elements with the SAME
+// symbol in front follow CONSECUTIVE records (LF restricted to a symbol is monotone), so a workgroup sorts its kGroupChunk records by that
+// symbol (front[]: written in round 0 for the elements that stopped on their first step -- six in ten on C3, nine in ten on C4; a counting
+// sort in LDS, the kernel's VALU is idle) and takes the hops in that order: the first hop of a wave reads 8 lines.  Results are staged in
+// LDS and written back in record order, coalesced.
+constexpr uint32_t kGroupChunk = 2048;
+template <typename pos_t, bool kWide>
+__global__ void __launch_bounds__(256) trail_resolve_grouped_kernel(uint64_t* __restrict__ rec, uint64_t count, pos_t* __restrict__ out,
+                                                                    const uint8_t* __restrict__ front, unsigned long long* __restrict__ n_open)
+{
+    constexpr uint32_t kShift = kWide ? 33 : 32, kPer = kGroupChunk / 256;
+    constexpr uint64_t kLow = (1ull << kShift) - 1;
+    __shared__ uint64_t s_rec[kGroupChunk];
+    __shared__ uint16_t s_idx[kGroupChunk];
+    __shared__ uint32_t s_bin[258];
+    uint32_t open = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * kGroupChunk; base < count; base += (uint64_t)gridDim.x * kGroupChunk) {
+        const uint32_t n = (uint32_t)(count - base < kGroupChunk ? count - base : kGroupChunk);
+        for (uint32_t j = threadIdx.x; j < 258; j += 256) s_bin[j] = 0;
+        __syncthreads();
+        uint32_t grp[kPer], arr[kPer];
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t e = threadIdx.x + 256 * k;
+            grp[k] = 257; arr[k] = 0;
+            if (e < n) {
+                const uint64_t r = rec[base + e];
+                s_rec[e] = r;
+                grp[k] = (r >> kShift) ? (uint32_t)front[base + e] : 256u;       // positions (nothing to follow) stand last
+                arr[k] = atomicAdd(&s_bin[grp[k]], 1u);
+            }
+        }
+        __syncthreads();
+        {   // exclusive scan of the 257 counters (one wave does it: 5 per lane)
+            if (threadIdx.x < 64) {
+                uint32_t v[5], sum = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 5; ++i) { const uint32_t b = threadIdx.x * 5 + i; v[i] = b < 257 ? s_bin[b] : 0; sum += v[i]; }
+                uint32_t incl = sum;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += u; }
+                uint32_t run = incl - sum;
+#pragma unroll
+                for (uint32_t i = 0; i < 5; ++i) { const uint32_t b = threadIdx.x * 5 + i; if (b < 257) s_bin[b] = run; run += v[i]; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t e = threadIdx.x + 256 * k;
+            if (e < n) s_idx[s_bin[grp[k]] + arr[k]] = (uint16_t)e;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t p = threadIdx.x + 256 * k;
+            if (p < n) {
+                const uint32_t e = s_idx[p];
+                uint64_t r = s_rec[e];
+                if (r >> kShift) {
+                    for (uint32_t h = 0; h < kResolveHops && (r >> kShift); ++h) {
+                        const uint64_t ro = rec[r & kLow];
+                        const uint64_t delta = r >> kShift;
+                        r = (ro >> kShift) == 0 ? ro + delta : ro + (delta << kShift);
+                    }
+                    s_rec[e] = r;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t e = threadIdx.x + 256 * k;
+            if (e < n) {
+                const uint64_t r = s_rec[e];
+                rec[base + e] = r;
+                if ((r >> kShift) == 0) out[base + e] = (pos_t)r;
+                else ++open;
+            }
+        }
+        __syncthreads();
+    }
+    unsigned long long v[1] = {open};
+    unsigned long long* const dst[1] = {n_open};
+    block_add<1>(v, dst);
+}
+
 template <typename pos_t, bool kWide>
 __global__ void __launch_bounds__(256) trail_resolve_kernel(uint64_t* __restrict__ rec, uint64_t count, pos_t* __restrict__ out,
                                                             unsigned long long* __restrict__ n_open, uint32_t round, bool diag)
@@ -1345,10 +1440,12 @@ vlg_status run_locate_sweep(const SweepKernels& K, const uint64_t* d_l, const ui
         // more than one sweep: an element may stop at an element of a LATER sweep, whose record must read "still walking" until then
         if (total > batch_max) VLG_HIP_TRY(hipMemsetAsync(rec, 0xFF, total * 8, stream));
     }
+    bool front_valid = K.front != nullptr && [] { const char* e = getenv("VLG_RESOLVE_GROUPED"); return !(e && e[0] == '0'); }();
     for (uint64_t t0 = 0; t0 < total; t0 += batch_max) {
         const uint64_t t1 = std::min(total, t0 + batch_max);
         // (a sweep too short for a single round hands its elements to the stragglers' kernel, which reads their words)
         const bool fused_first = t1 - t0 > tail_threshold && [] { const char* e = getenv("VLG_NO_FUSED_FIRST_ROUND"); return !(e && e[0] == '1'); }();
+        if (!fused_first) front_valid = false;                   // (front[] is written by the fused first round only)
         static const bool ahead = [] { const char* e = getenv("VLG_SWEEP_LOOKAHEAD"); return !(e && e[0] == '0'); }();
         if (!fused_first) {
             if (member) VLG_HIP_TRY(hipMemsetAsync(rec + t0, 0xFF, (t1 - t0) * 8, stream));     // "still walking" (the first-round kernel writes it itself)
@@ -1403,8 +1500,12 @@ vlg_status run_locate_sweep(const SweepKernels& K, const uint64_t* d_l, const ui
         for (uint32_t round = 0;; ++round) {
             VLG_HIP_TRY(hipMemsetAsync(d_counter, 0, diag ? 32 : 8, stream));
             if (timer) timer->begin(2, round == 0 ? total * (8ull + sizeof(pos_t)) : 0);     // every record read, every position written
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_kernel<pos_t, kWide>), dim3((uint32_t)std::min<uint64_t>((total + kResolveChunk - 1) / kResolveChunk, 65536)),
-                               dim3(256), 0, stream, rec, total, d_out, d_counter, round, diag);
+            if (round == 0 && front_valid && !diag)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_grouped_kernel<pos_t, kWide>), dim3((uint32_t)std::min<uint64_t>((total + kGroupChunk - 1) / kGroupChunk, 1u << 20)),
+                                   dim3(256), 0, stream, rec, total, d_out, K.front, d_counter);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(trail_resolve_kernel<pos_t, kWide>), dim3((uint32_t)std::min<uint64_t>((total + kResolveChunk - 1) / kResolveChunk, 65536)),
+                                   dim3(256), 0, stream, rec, total, d_out, d_counter, round, diag);
             if (timer) timer->end(2);
             VLG_HIP_TRY(hipGetLastError());
             unsigned long long open = 0;
@@ -1432,7 +1533,7 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
                                pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
                                hipStream_t stream, LaunchTimer* timer, Block* member, uint32_t n_member_lists, uint64_t* rec,
-                               const std::function<vlg_status()>* while_first_step)
+                               const std::function<vlg_status()>* while_first_step, uint8_t* front)
 {
     if (iv.sample_bytes != (kWide ? 8u : 4u)) return fail(VLG_E_INTERNAL, "sorted sweep: sample width does not match the instantiation");
     const bool rrr = iv.bv_kind == kBvRrr63, text_order = iv.sampling == kSamplingTextOrder;
@@ -1449,13 +1550,15 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
     SweepKernels K;
     K.n = iv.n;
     K.sigma = iv.sigma;
+    K.front = rec ? front : nullptr;
+    uint8_t* const fr = K.front;
     K.first = [&](uint64_t t0, uint64_t t1, uint64_t* val, uint16_t* key, void* out_, unsigned long long* counter, const Block* mem, uint64_t* rc, bool ahead,
                   uint32_t* chunk_list) {
         pos_t* out = static_cast<pos_t*>(out_);
         launch_sweep_chunk_lists(d_out_off, n_pat, t0, t1, chunk_list, stream);
         const dim3 grid_first(grid_for((t1 - t0 + 7) / 8, 8192));
-#define VLG_FIRST(BV, TR, TO) do { if (ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, TR>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val, key, out, d_stats, counter, mem, rc, chunk_list); \
-                                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, false>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val, key, out, d_stats, counter, mem, rc, chunk_list); } while (0)
+#define VLG_FIRST(BV, TR, TO) do { if (ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, TR>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val, key, out, d_stats, counter, mem, rc, chunk_list, fr); \
+                                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sweep_first_kernel<BV, pos_t, TR, kWide, TO, false>), grid_first, dim3(256), 0, stream, iv, d_l, d_out_off, n_pat, t0, t1, val, key, out, d_stats, counter, mem, rc, chunk_list, fr); } while (0)
 #define VLG_FIRST_BV(TR, TO) do { if (rrr) VLG_FIRST(RrrBV, TR, TO); else VLG_FIRST(PlainBV, TR, TO); } while (0)
         if (text_order) { if (mem) VLG_FIRST_BV(true, true); else VLG_FIRST_BV(false, true); }
         else { if (mem) VLG_FIRST_BV(true, false); else VLG_FIRST_BV(false, false); }
@@ -1576,7 +1679,7 @@ template vlg_status launch_unsample<true>(const IndexView&, const uint64_t*, con
     template vlg_status launch_locate_sweep<P, W>(const IndexView&, const uint64_t*, const uint64_t*, uint64_t, uint64_t, P*, uint64_t*, \
                                                   uint64_t*, uint16_t*, uint16_t*, void*, size_t, unsigned long long*, unsigned long long*, \
                                                   uint64_t, hipStream_t, LaunchTimer*, Block*, uint32_t, uint64_t*,                       \
-                                                  const std::function<vlg_status()>*);
+                                                  const std::function<vlg_status()>*, uint8_t*);
 VLG_SWEEP_INST(uint32_t, false)
 VLG_SWEEP_INST(uint32_t, true)        // n = 2^32 + 1 (BASELINE config 4): 33-bit SA indices, 32-bit text positions
 VLG_SWEEP_INST(uint64_t, true)

@@ -30,7 +30,8 @@ vlg_status launch_locate_sweep(const IndexView& iv, const uint64_t* d_l, const u
                                pos_t* d_out, uint64_t* val_a, uint64_t* val_b, uint16_t* key_a, uint16_t* key_b, void* temp,
                                size_t temp_bytes, unsigned long long* d_counter, unsigned long long* d_stats, uint64_t tail_threshold,
                                hipStream_t stream, LaunchTimer* timer, Block* member, uint32_t n_member_lists, uint64_t* rec,
-                               const std::function<vlg_status()>* while_first_step = nullptr);
+                               const std::function<vlg_status()>* while_first_step = nullptr,
+                               uint8_t* front = nullptr /* with rec: one byte per element, the symbol in front of it (see SweepKernels) */);
 // The three launches of a sorted sweep over some index; run_locate_sweep owns the rounds, the partitions, the member bit-vector, the
 // records and their resolution.  `out` is the sweep's slice of the position array (pos_t*), `rec` null when no LF step is shared.
 constexpr uint32_t kSweepChunk = 2048;          // elements a workgroup of the first round takes per turn
@@ -38,6 +39,9 @@ constexpr uint32_t kSweepChunk = 2048;          // elements a workgroup of the f
 // one lane of every workgroup in front of its work (a binary search is seventeen dependent loads)
 void launch_sweep_chunk_lists(const uint64_t* d_out_off, uint64_t n_pat, uint64_t t0, uint64_t t1, uint32_t* chunk_list, hipStream_t stream);
 struct SweepKernels {
+    // front[slot] (optional, with records): the compact symbol read in front of an element that stopped on its first step, 0xFF otherwise
+    // -- what the resolve regroups a workgroup's records by, so that the first hop of neighbouring lanes reads neighbouring records
+    uint8_t* front = nullptr;
     uint64_t n = 0;
     uint32_t sigma = 0;                  // partition keys are the symbols 0 .. sigma - 1 (16 bits at most); sigma = finished
     // round 0 of the elements [t0, t1): their words follow from their places (lists l / out_off are the launcher's business)

@@ -883,10 +883,12 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
     if (d_goff64) VLG_HIP_TRY(hipMemcpyAsync(d_goff64, goff64.data(), (gnd + 1) * 8, hipMemcpyHostToDevice, st));
     uint64_t* rec = nullptr;
     Block* member = nullptr;
+    uint8_t* front = nullptr;
     const uint32_t n_member_lists = n_outer > sl ? std::min(n_outer - sl, nd) : 0u;      // this rank's outer lists: a prefix of its share
     if (use_sweep && !use_unsample && share_steps && acc <= 0xFFFFFF00ull) {
         rec = A.take<uint64_t>(acc);
         member = A.take<Block>(member_blocks(idx->hdr.n));
+        if (!idx->is_int) front = A.take<uint8_t>(acc);             // the symbol in front of every element that stops on its first step (kernels.hpp: SweepKernels)
         if (A.failed) return fail(VLG_E_INTERNAL, "arena carve failed (member bit-vector, records)");
     }
     // the sort's tables only depend on the list lengths: they are built and uploaded while the first step of locate runs
@@ -938,10 +940,10 @@ vlg_status build_physical(const vlg_index* idx, vlg_workspace* ws, vlg_result* r
             else s = fail(VLG_E_INTERNAL, "integer-alphabet index with 64-bit positions");
         } else if (wide)
             s = launch_locate_sweep<pos_t, true>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b, d_tmp, sort_tmp, d_counter, d_stats,
-                                                 ws->sweep_tail, st, &timer, member, n_member_lists, rec, &plan_sort);
+                                                 ws->sweep_tail, st, &timer, member, n_member_lists, rec, &plan_sort, front);
         else if constexpr (sizeof(pos_t) == 4)                      // (a 64-bit position type always comes with wide indices)
             s = launch_locate_sweep<uint32_t, false>(idx->view, d_lh, d_off64, nd, acc, Pa, val_a, val_b, key_a, key_b, d_tmp, sort_tmp, d_counter, d_stats,
-                                                     ws->sweep_tail, st, &timer, member, n_member_lists, rec, &plan_sort);
+                                                     ws->sweep_tail, st, &timer, member, n_member_lists, rec, &plan_sort, front);
         else s = fail(VLG_E_INTERNAL, "64-bit positions with 32-bit SA indices");
         if (s) return s;
         ws->sample_reads += acc;
@@ -1733,7 +1735,7 @@ vlg_status run_batch(const vlg_index* idx, const vlg_queries* q, vlg_workspace* 
         const bool dense_sa = idx->hdr.dens == 1 && idx->hdr.sampling == kSamplingSaOrder;
         // (nor does a batch dense enough to rebuild the whole suffix array, K3u: its arrays fit the sweep's scratch)
         const bool will_unsample = will_sweep && !dense_sa && sizeof(pos_t) == 4 && unsample_applies(idx, ws, phys / (uint64_t)std::max(1, ws->x_ranks));
-        uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup && !dense_sa && !will_unsample ? member_blocks(idx->hdr.n) * sizeof(Block) + phys * 8 + 1024 : 0;
+        uint64_t trail_bytes = will_sweep && ws->trail && ws->dedup && !dense_sa && !will_unsample ? member_blocks(idx->hdr.n) * sizeof(Block) + phys * 9 + 2048 : 0;
         // (+ fences: < 1 B per element; + the pivot filter's ladder, a third of the lists, when its searches outweigh building it:
         // one pass over the lists against two descents per pivot element)
         ws->want_rungs = pivot_elems && (ws->pivot_rungs == 2 || (pivot_elems >= phys / 16 && pivot_elems >= 4096));
