@@ -991,8 +991,13 @@ constexpr uint32_t kResolveChunk = VLG_RESOLVE_CHUNK;
 // symbol in front follow CONSECUTIVE records (LF restricted to a symbol is monotone), so a workgroup sorts its kGroupChunk records by that
 // symbol (front[]: written in round 0 for the elements that stopped on their first step -- six in ten on C3, nine in ten on C4; a counting
 // sort in LDS, the kernel's VALU is idle) and takes the hops in that order: the first hop of a wave reads 8 lines.  Results are staged in
-// LDS and written back in record order, coalesced.
-constexpr uint32_t kGroupChunk = 2048;
+// LDS and written back in record order, coalesced.  (Measured, round 4: chunks of 1024 / 2048 / 4096 records -- C3 16.7 / 16.9 / 22.9 ms, C4
+// 118 / 109 / 145 ms: the kernel needs its waves; a second, stable regrouping by the symbol in front of the OWNER for the second hop -- rocPRIM's
+// match ranking twice per chunk -- 17.4 vs 17.2 ms: not kept.)
+#ifndef VLG_GROUP_CHUNK
+#define VLG_GROUP_CHUNK 2048
+#endif
+constexpr uint32_t kGroupChunk = VLG_GROUP_CHUNK;
 template <typename pos_t, bool kWide>
 __global__ void __launch_bounds__(256) trail_resolve_grouped_kernel(uint64_t* __restrict__ rec, uint64_t count, pos_t* __restrict__ out,
                                                                     const uint8_t* __restrict__ front, unsigned long long* __restrict__ n_open)
