@@ -118,15 +118,16 @@ CLASSES = {
     "backward_search": ("backward_search_kernel", ["backward_search_kernel"], "32 B per wavelet-tree level of every rank (SURVEY 8d K2)"),
     "expand": ("expand_kernel", [], ""),
     "locate": ("sweep_step_kernel (rounds 1..; round 0 is sweep_first_kernel, the stragglers are finished by locate_kernel<.., kTail>: one launch each)",
-               ["sweep_step_kernel", "sweep_first_kernel", "locate_kernel"],
+               ["sweep_step_kernel", "sweep_first_kernel", "locate_kernel", "member_build_kernel", "sweep_chunk_lists_kernel"],
                "32 B per tree level actually walked + one SA sample per occurrence (SURVEY 8d K3)"),
     "locate_partition": ("rocprim radix_sort_pairs (u16 symbol key, u64 element): one 5-bit pass per round",
                          ["rocprim:radix_sort_onesweep<unsigned_short,unsigned_long>"],
                          "per element of the round: key + value read once, written once (2 x 10 B)"),
-    "locate_resolve": ("trail_resolve_kernel", ["trail_resolve_kernel", "trail_resolve_round_kernel"], "8 B record read + 4..8 B position written per occurrence"),
-    "sort": ("list_sort_* (LSD radix sort of the 32-bit positions inside every list; short lists in LDS)",
+    "locate_resolve": ("trail_resolve_grouped_kernel (first pass: a workgroup's records regrouped by the symbol in front; trail_resolve_kernel for later passes)",
+                       ["trail_resolve_grouped_kernel", "trail_resolve_kernel"], "8 B record read + 4..8 B position written per occurrence"),
+    "sort": ("list_sort_* (32-bit positions inside every list: short lists bucket-sorted in LDS, long ones by two radix passes + windows)",
              ["list_sort_small_kernel", "list_sort_hist_kernel", "list_sort_chunk_kernel", "list_sort_scan_kernel", "list_sort_prefix_kernel",
-              "list_sort_scatter_kernel"],
+              "list_sort_scatter_kernel", "list_sort_window_plan_kernel", "list_sort_window_desc_kernel", "list_sort_window_kernel"],
              "one read + one write of every position (2 x 4 B); the radix passes in between are overhead"),
     "filter_ladder": ("rung_build_kernel (4-ary search ladder over the sorted lists, for the pivot filter)", ["rung_build_kernel"],
                       "every list element read once (4 B); a third as many entries written"),
