@@ -647,7 +647,10 @@ __global__ void filter_gather_counts_kernel(const uint32_t* __restrict__ task_ci
 
 // survivors of the chunk's segments -> Pc, in task order; run_cnt = the gathered counts, run_off = their exclusive scan.
 // A wave looks at kCompactRuns runs and works on the ones that have survivors.
-constexpr uint32_t kCompactRuns = 16;
+#ifndef VLG_COMPACT_RUNS
+#define VLG_COMPACT_RUNS 16
+#endif
+constexpr uint32_t kCompactRuns = VLG_COMPACT_RUNS;
 #ifndef VLG_SPARSE_TURN
 #define VLG_SPARSE_TURN 8
 #endif
